@@ -1,0 +1,233 @@
+/*
+ * gsplat.h — C ABI of libgsplat_hip.so, the MI355X (gfx950) differentiable 3D-Gaussian
+ * rasterizer + distCUDA2 kNN + Haar-DWT / patch-ELF / SSIM loss kernels.
+ *
+ * This is the drop-in boundary for the hot path of sparse-view-3dgs-pack (LGDWT-GS).
+ * Every entry point takes plain pointers + sizes + a hipStream_t passed as void*; no torch
+ * types cross it.  All pointers are DEVICE pointers unless a parameter says "host".
+ * Every function returns 0 on success, <0 for an invalid argument (GS_E_*), >0 = hipError_t.
+ * Nothing throws across this ABI and nothing here allocates, frees or synchronises the
+ * device except where stated (gs_forward_geometry's optional host read-back).
+ *
+ * Reference interfaces replaced (paths under
+ * /root/reference/fs3dgs_benchmark/gaussian-splatting/submodules/):
+ *   gs_forward_geometry + gs_forward_render
+ *        = CudaRasterizer::Rasterizer::forward   diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.cu:198-341
+ *          as bound by RasterizeGaussiansCUDA     diff-gaussian-rasterization/rasterize_points.cu:35-124
+ *          and pybind `rasterize_gaussians`       diff-gaussian-rasterization/ext.cpp:15-19
+ *   gs_backward
+ *        = CudaRasterizer::Rasterizer::backward   cuda_rasterizer/rasterizer_impl.cu:345-450
+ *          as bound by RasterizeGaussiansBackwardCUDA  rasterize_points.cu:126-223
+ *   gs_mark_visible
+ *        = Rasterizer::markVisible                rasterizer_impl.cu:141-153, rasterize_points.cu:225-244
+ *   gs_knn_mean_dist2
+ *        = SimpleKNN::knn / distCUDA2             simple-knn/simple_knn.cu:186-222, simple-knn/spatial.cu:15-26
+ *   gs_ssim_fwd / gs_ssim_bwd
+ *        = fusedssim / fusedssim_backward         fused-ssim/ssim.cu:187-366
+ *   gs_dwt_* / gs_elf_* / gs_patch_*
+ *        = get_dwt_subbands / compute_elf_map / compute_patch_dwt_loss
+ *          /root/reference/fs3dgs_benchmark/LGDWT-GS/utils/loss_utils.py:106-153,336-442
+ *          (arithmetic of the un-vendored pytorch_wavelets DWTForward(J=1,'db1','symmetric'))
+ */
+#ifndef GSPLAT_H_INCLUDED
+#define GSPLAT_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+/* error codes (negative = caller error) */
+#define GS_OK 0
+#define GS_E_NULL (-1)      /* required pointer is NULL */
+#define GS_E_SHAPE (-2)     /* inconsistent sizes / exclusive-argument rule violated */
+#define GS_E_SCRATCH (-3)   /* scratch buffer too small */
+#define GS_E_OVERFLOW (-4)  /* num_rendered exceeded binning capacity (re-run gs_forward_render) */
+#define GS_E_UNSUPPORTED (-5)
+
+#define GS_TILE_X 16 /* cuda_rasterizer/config.h:16 */
+#define GS_TILE_Y 16 /* cuda_rasterizer/config.h:17 */
+#define GS_NUM_CHANNELS 3 /* cuda_rasterizer/config.h:15 */
+
+/* Per-call camera / raster configuration.
+ * Mirrors GaussianRasterizationSettings (dgr_3dgs/__init__.py:143-156).  Matrices are the
+ * transposed (row-vector) forms the reference's Python hands over: viewmatrix = W2C^T,
+ * projmatrix = (P*W2C)^T, each 16 contiguous floats. */
+typedef struct GsView {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  float scale_modifier;
+  int32_t sh_degree;   /* active degree D, 0..3 */
+  int32_t prefiltered; /* bool */
+  int32_t antialiasing; /* bool */
+  int32_t debug;       /* bool: synchronise + check after every launch (auxiliary.h:178-185) */
+  int32_t _pad;
+  const float* bg;         /* [3] */
+  const float* viewmatrix; /* [16] */
+  const float* projmatrix; /* [16] */
+  const float* campos;     /* [3] */
+} GsView;
+
+/* Per-Gaussian inputs.  Exactly one of {shs, colors_precomp} and exactly one of
+ * {scales+rotations, cov3D_precomp} is non-NULL (dgr_3dgs/__init__.py:178-182).
+ * "Absent" is an explicit NULL (the reference passed data_ptr() of an empty tensor). */
+typedef struct GsGaussians {
+  int32_t P; /* number of Gaussians */
+  int32_t M; /* SH coefficients stored per Gaussian (16 for degree 3); 0 when shs == NULL */
+  const float* means3D;        /* [P,3] */
+  const float* shs;            /* [P,M,3] or NULL */
+  const float* colors_precomp; /* [P,3] or NULL */
+  const float* opacities;      /* [P]   (the [P,1] tensor) */
+  const float* scales;         /* [P,3] or NULL */
+  const float* rotations;      /* [P,4] or NULL (r,x,y,z; NOT renormalised, forward.cu:123) */
+  const float* cov3D_precomp;  /* [P,6] or NULL */
+} GsGaussians;
+
+/* Caller-owned scratch.  geom and img sizes depend on (P, W, H); binning on the capacity in
+ * instances (Gaussian x tile pairs).  The three buffers are the private fwd<->bwd contract
+ * (the reference's geomBuffer / binningBuffer / imgBuffer byte tensors): backward must get
+ * back exactly the bytes forward wrote. */
+typedef struct GsScratch {
+  void* geom;
+  size_t geom_bytes;
+  void* img;
+  size_t img_bytes;
+  void* binning;
+  size_t binning_bytes;
+  int64_t binning_capacity; /* instances the binning buffer was sized for */
+} GsScratch;
+
+/* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by
+ * the call (rows of culled Gaussians become 0) - the caller need not zero them.  Any pointer
+ * may be NULL when that gradient is not wanted, except that dL_dsh / dL_dcolors follow the
+ * colour mode and dL_dscales+dL_drotations / dL_dcov3D follow the covariance mode. */
+typedef struct GsGrads {
+  float* dL_dmeans3D;   /* [P,3] */
+  float* dL_dmeans2D;   /* [P,3]  (z = 0) */
+  float* dL_dsh;        /* [P,M,3] */
+  float* dL_dcolors;    /* [P,3] */
+  float* dL_dopacity;   /* [P] */
+  float* dL_dscales;    /* [P,3] */
+  float* dL_drotations; /* [P,4] */
+  float* dL_dcov3D;     /* [P,6] */
+} GsGrads;
+
+int gs_abi_version(void);
+/* Human readable build string: arch, compiler, kernel variants. */
+const char* gs_build_info(void);
+
+/* out[0..2] = bytes needed for geom, img, binning given capacity R_capacity instances.
+ * workspace_bytes (may be NULL) = bytes gs_backward needs as its workspace. */
+int gs_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R_capacity, size_t out[3],
+                     size_t* backward_workspace_bytes);
+
+/* Phase 1 of forward: per-Gaussian preprocess (cull, project, cov3D, EWA cov2D, conic,
+ * radius, tile rect, SH->RGB) and the prefix sum of tiles_touched.  Writes radii[P].
+ * num_rendered is left in the geom header on the device; if num_rendered_host != NULL it is
+ * also copied there with hipMemcpyAsync on `stream` (pass pinned memory, then wait on the
+ * stream/an event before reading it).  Does not block the host. */
+int gs_forward_geometry(const GsView* view, const GsGaussians* g, GsScratch* scratch,
+                        int32_t* radii, int32_t* num_rendered_host, void* stream);
+
+/* Phase 2 of forward: duplicate (tile|depth) keys, stable radix sort on the low
+ * 32+ceil_log2(T) key bits, tile ranges, front-to-back alpha blend.  Reads num_rendered from
+ * the geom header on the device.  If it exceeds scratch->binning_capacity nothing is blended,
+ * an overflow flag is left in the geom header and the image outputs are undefined: the caller
+ * (who learns num_rendered from phase 1) re-runs this phase with a larger binning buffer.
+ * out_color [3,H,W], out_invdepth [H,W] (may be NULL). */
+int gs_forward_render(const GsView* view, const GsGaussians* g, GsScratch* scratch,
+                      float* out_color, float* out_invdepth, void* stream);
+
+/* Backward of the whole rasterizer.  num_rendered is the value forward produced.
+ * dL_dinvdepth may be NULL (then no inverse-depth gradient path runs).
+ * workspace: >= backward_workspace_bytes from gs_scratch_bytes. */
+int gs_backward(const GsView* view, const GsGaussians* g, const int32_t* radii,
+                const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
+                const float* dL_dinvdepth, const GsGrads* grads, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* present[i] = (view-space z of means3D[i]) > 0.2   (rasterizer_impl.cu:54-66) */
+int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
+                    const float* projmatrix, uint8_t* present, void* stream);
+
+/* ---- debug / parity exports: copy internal state into plain arrays (any pointer may be
+ * NULL).  Used by the parity tests to compare against the oracle; not on the hot path. ---- */
+int gs_export_geom(const GsScratch* scratch, int32_t P, float* depths, float* means2D /*[P,2]*/,
+                   float* cov3D /*[P,6]*/, float* conic_opacity /*[P,4]*/, float* rgb /*[P,3]*/,
+                   uint8_t* clamped /*[P,3]*/, uint32_t* tiles_touched, uint32_t* point_offsets,
+                   void* stream);
+int gs_export_binning(const GsScratch* scratch, int64_t num_rendered, uint64_t* keys_sorted,
+                      uint32_t* point_list, void* stream);
+int gs_export_img(const GsScratch* scratch, int32_t W, int32_t H, float* final_T,
+                  uint32_t* n_contrib, uint32_t* ranges /*[T,2]*/, void* stream);
+
+/* ---- simple-knn ---- */
+/* out[i] = mean of the 3 smallest squared distances from point i to the other points.
+ * tmp: >= gs_knn_tmp_bytes(P) bytes of device scratch. */
+size_t gs_knn_tmp_bytes(int32_t P);
+int gs_knn_mean_dist2(const float* xyz /*[P,3]*/, int32_t P, float* out /*[P]*/, void* tmp,
+                      size_t tmp_bytes, void* stream);
+
+/* ---- losses (images are [C,H,W] or [N,C,H,W] contiguous fp32) ---- */
+
+/* sums[0] = sum |a-b| over n elements (atomically added: zero it first).
+ * grad (may be NULL) = coef * sign(a-b). */
+int gs_l1_fwd(const float* a, const float* b, int64_t n, float* sum, void* stream);
+int gs_l1_bwd(const float* a, const float* b, int64_t n, float coef, float* grad_a,
+              int32_t accumulate, void* stream);
+
+/* One level of the Haar analysis ('db1', mode 'symmetric': odd sizes repeat the last sample).
+ * x [NC,H,W] -> ll, lh, hl, hh each [NC, ceil(H/2), ceil(W/2)].  lh = low along W, high along H. */
+int gs_dwt_haar_fwd(const float* x, int32_t NC, int32_t H, int32_t W, float* ll, float* lh,
+                    float* hl, float* hh, void* stream);
+/* adjoint: dx [NC,H,W] (=, not +=) from the four band gradients (any may be NULL = zero). */
+int gs_dwt_haar_bwd(const float* dll, const float* dlh, const float* dhl, const float* dhh,
+                    int32_t NC, int32_t H, int32_t W, float* dx, void* stream);
+
+/* Fused global 2-level DWT L1 loss (train.py:132-164).
+ * band_sums[8] += sum |band(pred) - band(gt)| for LL1,LH1,HL1,HH1,LL2,LH2,HL2,HH2 (zero first).
+ * counts: level-1 bands have C*ceil(H/2)*ceil(W/2) elements, level-2 C*ceil(h1/2)*ceil(w1/2). */
+int gs_dwt2_l1_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
+                   float* band_sums, void* stream);
+/* grad_pred (+= if accumulate) = sum_b coef[b] * DWT_b^T sign(band_b(pred-gt)); coef is a
+ * DEVICE array of 8 floats (w_b * upstream / N_b). */
+int gs_dwt2_l1_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
+                   const float* coef_dev, float* grad_pred, int32_t accumulate, void* stream);
+
+/* ELF map (loss_utils.py:336-366): elf_low = LL/(LL+LH+HL+HH+1e-8) with per-pixel channel-L1
+ * of the level-1 bands, then bilinear x2 upsample (align_corners=False) to [H,W]. */
+int gs_elf_map(const float* img, int32_t C, int32_t H, int32_t W, float* elf_low /*[h1,w1] tmp*/,
+               float* elf /*[H,W]*/, void* stream);
+/* means[L] = mean of elf over each non-overlapping patch (row-major patch order, remainder
+ * dropped: F.unfold semantics, loss_utils.py:391-400). */
+int gs_patch_means(const float* elf, int32_t H, int32_t W, int32_t patch, float* means,
+                   void* stream);
+/* Patch DWT loss over the selected patches (mask[L] != 0): sums[3] += sum |band(pred-gt)| for
+ * LH1, HL1, HH1 restricted to selected patches (zero first). */
+int gs_patch_dwt_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
+                     int32_t patch, const uint8_t* mask, float* sums, void* stream);
+int gs_patch_dwt_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
+                     int32_t patch, const uint8_t* mask, const float* coef_dev /*[3]*/,
+                     float* grad_pred, int32_t accumulate, void* stream);
+
+/* Fused SSIM, 11-tap sigma=1.5 separable window, zero padding ("same").
+ * img1,img2 [B,C,H,W]; ssim_map and the three partial-derivative maps (may be NULL when no
+ * backward is wanted) have the same shape. */
+int gs_ssim_fwd(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W,
+                float C1, float C2, float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq,
+                float* dm_dsigma12, void* stream);
+int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W,
+                float C1, float C2, const float* dL_dmap, const float* dm_dmu1,
+                const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_H_INCLUDED */

@@ -1,0 +1,388 @@
+/*
+ * TEST INFRASTRUCTURE — CPU oracle for the LGDWT-GS loss terms.  Never on the product path.
+ *
+ * Restates (fp32, -ffp-contract=off; reductions accumulate in double):
+ *   l1_loss                       /root/reference/fs3dgs_benchmark/LGDWT-GS/utils/loss_utils.py:40-41
+ *   get_dwt_subbands              .../LGDWT-GS/utils/loss_utils.py:106-153
+ *   global DWT loss               .../LGDWT-GS/train.py:132-164
+ *   compute_elf_map               .../LGDWT-GS/utils/loss_utils.py:336-366
+ *   compute_patch_dwt_loss        .../LGDWT-GS/utils/loss_utils.py:368-442
+ *   fusedssim / fusedssim_backward  .../gaussian-splatting/submodules/fused-ssim/ssim.cu:187-366
+ *
+ * The Haar arithmetic itself lives in the third-party package pytorch_wavelets (DWTForward,
+ * J=1, wave='db1', mode='symmetric'), which is NOT vendored in /root/reference, NOT version
+ * pinned anywhere in it, and not installed here: **DWT parity is unpinned** by the reference.
+ * What is restated is that package's published algorithm (pytorch_wavelets/dwt/lowlevel.py,
+ * afb1d/AFB2D): analysis filters h0 = [c, c], h1 = [c, -c] with c = float32(0.7071067811865476)
+ * (pywt 'db1' dec_lo / dec_hi, reversed by prep_filt_afb1d), correlation with stride 2 first along
+ * W (dim 3) then along H (dim 2); for an odd length one sample is appended that repeats the last
+ * one ('symmetric' pad p = 1 placed on the right); band order Yh[:, :, 0/1/2] = LH/HL/HH with
+ * LH = low along W, high along H.
+ * Pinned by: analytic KATs (constant / ramp / checkerboard images), orthonormality
+ * (energy preservation, perfect reconstruction through the adjoint), torch autograd of a torch
+ * restatement for the gradients, and for SSIM / L1 by golden values produced by the importable
+ * reference python (tests/golden/make_golden.py).
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/gsplat.h"
+
+static const float HC = 0.7071067811865476f; /* float32(pywt db1 coefficient) */
+
+static inline int cdiv2(int n) { return (n + 1) / 2; }
+/* symmetric right pad by one: index n (only reachable for odd n) repeats n-1 */
+static inline int symi(int i, int n) { return i < n ? i : n - 1; }
+
+struct Bands {
+  float ll, lh, hl, hh;
+};
+static inline Bands haar_block(float a, float b, float c, float d) {
+  /* stage 1 along W */
+  float lo_t = HC * a + HC * b, hi_t = HC * a - HC * b;
+  float lo_b = HC * c + HC * d, hi_b = HC * c - HC * d;
+  /* stage 2 along H */
+  Bands r;
+  r.ll = HC * lo_t + HC * lo_b;
+  r.lh = HC * lo_t - HC * lo_b;
+  r.hl = HC * hi_t + HC * hi_b;
+  r.hh = HC * hi_t - HC * hi_b;
+  return r;
+}
+/* adjoint of haar_block: gradients wrt a,b,c,d */
+static inline void haar_block_adj(float gll, float glh, float ghl, float ghh, float& da, float& db,
+                                  float& dc, float& dd) {
+  float dlo_t = HC * gll + HC * glh, dlo_b = HC * gll - HC * glh;
+  float dhi_t = HC * ghl + HC * ghh, dhi_b = HC * ghl - HC * ghh;
+  da = HC * dlo_t + HC * dhi_t;
+  db = HC * dlo_t - HC * dhi_t;
+  dc = HC * dlo_b + HC * dhi_b;
+  dd = HC * dlo_b - HC * dhi_b;
+}
+static inline float sgn(float x) { return (float)((x > 0.f) - (x < 0.f)); }
+
+static void dwt_level(const float* x, int NC, int H, int W, float* ll, float* lh, float* hl, float* hh) {
+  const int h = cdiv2(H), w = cdiv2(W);
+  for (int c = 0; c < NC; c++)
+    for (int i = 0; i < h; i++)
+      for (int j = 0; j < w; j++) {
+        const float* p = x + (size_t)c * H * W;
+        int y0 = 2 * i, y1 = symi(2 * i + 1, H), x0 = 2 * j, x1 = symi(2 * j + 1, W);
+        Bands b = haar_block(p[(size_t)y0 * W + x0], p[(size_t)y0 * W + x1], p[(size_t)y1 * W + x0],
+                             p[(size_t)y1 * W + x1]);
+        size_t o = ((size_t)c * h + i) * w + j;
+        if (ll) ll[o] = b.ll;
+        if (lh) lh[o] = b.lh;
+        if (hl) hl[o] = b.hl;
+        if (hh) hh[o] = b.hh;
+      }
+}
+static void dwt_level_adj(const float* dll, const float* dlh, const float* dhl, const float* dhh, int NC,
+                          int H, int W, float* dx, bool accumulate) {
+  const int h = cdiv2(H), w = cdiv2(W);
+  if (!accumulate) memset(dx, 0, sizeof(float) * (size_t)NC * H * W);
+  for (int c = 0; c < NC; c++)
+    for (int i = 0; i < h; i++)
+      for (int j = 0; j < w; j++) {
+        size_t o = ((size_t)c * h + i) * w + j;
+        float da, db, dc, dd;
+        haar_block_adj(dll ? dll[o] : 0.f, dlh ? dlh[o] : 0.f, dhl ? dhl[o] : 0.f, dhh ? dhh[o] : 0.f, da, db, dc, dd);
+        float* p = dx + (size_t)c * H * W;
+        int y0 = 2 * i, y1 = symi(2 * i + 1, H), x0 = 2 * j, x1 = symi(2 * j + 1, W);
+        p[(size_t)y0 * W + x0] += da;
+        p[(size_t)y0 * W + x1] += db;
+        p[(size_t)y1 * W + x0] += dc;
+        p[(size_t)y1 * W + x1] += dd;
+      }
+}
+
+/* fused-ssim/ssim.cu:9-19 */
+static const float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f,
+                             0.10936068743467331f,  0.21300552785396576f,  0.26601171493530273f,
+                             0.21300552785396576f,  0.10936068743467331f,  0.036000773310661316f,
+                             0.0075987582094967365f, 0.001028380123898387f};
+
+/* separable 11-tap zero-padded convolution of one [H,W] plane: x pass then y pass, taps
+ * accumulated in order 0..10 starting from 0 (ssim.cu:104-184) */
+static void sepconv(const float* in, int H, int W, std::vector<float>& tmp, float* out) {
+  tmp.assign((size_t)H * W, 0.f);
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      float val = 0.f;
+      for (int k = 0; k < 11; k++) {
+        int xx = x + k - 5;
+        float v = (xx >= 0 && xx < W) ? in[(size_t)y * W + xx] : 0.f;
+        val += GW[k] * v;
+      }
+      tmp[(size_t)y * W + x] = val;
+    }
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      float val = 0.f;
+      for (int k = 0; k < 11; k++) {
+        int yy = y + k - 5;
+        float v = (yy >= 0 && yy < H) ? tmp[(size_t)yy * W + x] : 0.f;
+        val += GW[k] * v;
+      }
+      out[(size_t)y * W + x] = val;
+    }
+}
+
+extern "C" {
+
+int gso_l1_fwd(const float* a, const float* b, int64_t n, float* sum, void*) {
+  if (!a || !b || !sum) return GS_E_NULL;
+  double s = 0;
+  for (int64_t i = 0; i < n; i++) s += (double)fabsf(a[i] - b[i]);
+  *sum += (float)s;
+  return GS_OK;
+}
+int gso_l1_bwd(const float* a, const float* b, int64_t n, float coef, float* g, int32_t accumulate, void*) {
+  if (!a || !b || !g) return GS_E_NULL;
+  for (int64_t i = 0; i < n; i++) {
+    float v = coef * sgn(a[i] - b[i]);
+    g[i] = accumulate ? g[i] + v : v;
+  }
+  return GS_OK;
+}
+
+int gso_dwt_haar_fwd(const float* x, int32_t NC, int32_t H, int32_t W, float* ll, float* lh, float* hl,
+                     float* hh, void*) {
+  if (!x) return GS_E_NULL;
+  dwt_level(x, NC, H, W, ll, lh, hl, hh);
+  return GS_OK;
+}
+int gso_dwt_haar_bwd(const float* dll, const float* dlh, const float* dhl, const float* dhh, int32_t NC,
+                     int32_t H, int32_t W, float* dx, void*) {
+  if (!dx) return GS_E_NULL;
+  dwt_level_adj(dll, dlh, dhl, dhh, NC, H, W, dx, false);
+  return GS_OK;
+}
+
+int gso_dwt2_l1_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* band_sums,
+                    void*) {
+  if (!pred || !gt || !band_sums) return GS_E_NULL;
+  const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
+  const size_t n1 = (size_t)C * h1 * w1, n2 = (size_t)C * h2 * w2;
+  std::vector<float> p1[4], g1[4], p2[4], g2[4];
+  for (int k = 0; k < 4; k++) {
+    p1[k].resize(n1); g1[k].resize(n1); p2[k].resize(n2); g2[k].resize(n2);
+  }
+  dwt_level(pred, C, H, W, p1[0].data(), p1[1].data(), p1[2].data(), p1[3].data());
+  dwt_level(gt, C, H, W, g1[0].data(), g1[1].data(), g1[2].data(), g1[3].data());
+  dwt_level(p1[0].data(), C, h1, w1, p2[0].data(), p2[1].data(), p2[2].data(), p2[3].data());
+  dwt_level(g1[0].data(), C, h1, w1, g2[0].data(), g2[1].data(), g2[2].data(), g2[3].data());
+  for (int k = 0; k < 4; k++) {
+    double s = 0;
+    for (size_t i = 0; i < n1; i++) s += (double)fabsf(p1[k][i] - g1[k][i]);
+    band_sums[k] += (float)s;
+    s = 0;
+    for (size_t i = 0; i < n2; i++) s += (double)fabsf(p2[k][i] - g2[k][i]);
+    band_sums[4 + k] += (float)s;
+  }
+  return GS_OK;
+}
+
+int gso_dwt2_l1_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* coef,
+                    float* grad_pred, int32_t accumulate, void*) {
+  if (!pred || !gt || !coef || !grad_pred) return GS_E_NULL;
+  const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
+  const size_t n1 = (size_t)C * h1 * w1, n2 = (size_t)C * h2 * w2;
+  std::vector<float> p1[4], g1[4], p2[4], g2[4];
+  for (int k = 0; k < 4; k++) {
+    p1[k].resize(n1); g1[k].resize(n1); p2[k].resize(n2); g2[k].resize(n2);
+  }
+  dwt_level(pred, C, H, W, p1[0].data(), p1[1].data(), p1[2].data(), p1[3].data());
+  dwt_level(gt, C, H, W, g1[0].data(), g1[1].data(), g1[2].data(), g1[3].data());
+  dwt_level(p1[0].data(), C, h1, w1, p2[0].data(), p2[1].data(), p2[2].data(), p2[3].data());
+  dwt_level(g1[0].data(), C, h1, w1, g2[0].data(), g2[1].data(), g2[2].data(), g2[3].data());
+  std::vector<float> d2[4], d1[4], dll1(n1);
+  for (int k = 0; k < 4; k++) {
+    d2[k].resize(n2);
+    for (size_t i = 0; i < n2; i++) d2[k][i] = coef[4 + k] * sgn(p2[k][i] - g2[k][i]);
+  }
+  dwt_level_adj(d2[0].data(), d2[1].data(), d2[2].data(), d2[3].data(), C, h1, w1, dll1.data(), false);
+  for (int k = 0; k < 4; k++) {
+    d1[k].resize(n1);
+    for (size_t i = 0; i < n1; i++) d1[k][i] = coef[k] * sgn(p1[k][i] - g1[k][i]);
+  }
+  for (size_t i = 0; i < n1; i++) d1[0][i] += dll1[i];
+  dwt_level_adj(d1[0].data(), d1[1].data(), d1[2].data(), d1[3].data(), C, H, W, grad_pred, accumulate != 0);
+  return GS_OK;
+}
+
+int gso_elf_map(const float* img, int32_t C, int32_t H, int32_t W, float* elf_low, float* elf, void*) {
+  if (!img || !elf) return GS_E_NULL;
+  const int h = cdiv2(H), w = cdiv2(W);
+  const size_t n1 = (size_t)C * h * w;
+  std::vector<float> b[4];
+  for (int k = 0; k < 4; k++) b[k].resize(n1);
+  dwt_level(img, C, H, W, b[0].data(), b[1].data(), b[2].data(), b[3].data());
+  std::vector<float> low((size_t)h * w);
+  for (int i = 0; i < h * w; i++) {
+    float s[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; k++)
+      for (int c = 0; c < C; c++) s[k] += fabsf(b[k][(size_t)c * h * w + i]);
+    float HF = s[1] + s[2] + s[3];
+    low[i] = s[0] / (s[0] + HF + 1e-8f);
+  }
+  if (elf_low) memcpy(elf_low, low.data(), sizeof(float) * h * w);
+  /* F.interpolate(size=(H,W), mode='bilinear', align_corners=False): ATen upsample_bilinear2d */
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  for (int y = 0; y < H; y++) {
+    float sy = sh * ((float)y + 0.5f) - 0.5f;
+    if (sy < 0) sy = 0;
+    int y0 = (int)sy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+    for (int x = 0; x < W; x++) {
+      float sx = sw * ((float)x + 0.5f) - 0.5f;
+      if (sx < 0) sx = 0;
+      int x0 = (int)sx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+      elf[(size_t)y * W + x] = ly0 * (lx0 * low[(size_t)y0 * w + x0] + lx1 * low[(size_t)y0 * w + x1]) +
+                               ly1 * (lx0 * low[(size_t)y1 * w + x0] + lx1 * low[(size_t)y1 * w + x1]);
+    }
+  }
+  return GS_OK;
+}
+
+int gso_patch_means(const float* elf, int32_t H, int32_t W, int32_t ps, float* means, void*) {
+  if (!elf || !means) return GS_E_NULL;
+  const int ny = H / ps, nx = W / ps;
+  for (int py = 0; py < ny; py++)
+    for (int px = 0; px < nx; px++) {
+      double s = 0;
+      for (int y = 0; y < ps; y++)
+        for (int x = 0; x < ps; x++) s += (double)elf[(size_t)(py * ps + y) * W + px * ps + x];
+      means[py * nx + px] = (float)(s / ((double)ps * ps));
+    }
+  return GS_OK;
+}
+
+static void patch_bands(const float* img, int C, int H, int W, int ps, int py, int px, int c, int i, int j, Bands& b) {
+  const float* p = img + (size_t)c * H * W;
+  int y0 = py * ps + 2 * i, x0 = px * ps + 2 * j;
+  /* patch size is even (128) in every reference configuration; odd patches pad inside the patch */
+  int y1 = (2 * i + 1 < ps) ? y0 + 1 : y0, x1 = (2 * j + 1 < ps) ? x0 + 1 : x0;
+  b = haar_block(p[(size_t)y0 * W + x0], p[(size_t)y0 * W + x1], p[(size_t)y1 * W + x0], p[(size_t)y1 * W + x1]);
+  (void)C;
+}
+
+int gso_patch_dwt_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps,
+                      const uint8_t* mask, float* sums, void*) {
+  if (!pred || !gt || !mask || !sums) return GS_E_NULL;
+  const int ny = H / ps, nx = W / ps, hp = cdiv2(ps);
+  double s[3] = {0, 0, 0};
+  for (int py = 0; py < ny; py++)
+    for (int px = 0; px < nx; px++) {
+      if (!mask[py * nx + px]) continue;
+      for (int c = 0; c < C; c++)
+        for (int i = 0; i < hp; i++)
+          for (int j = 0; j < hp; j++) {
+            Bands a, b;
+            patch_bands(pred, C, H, W, ps, py, px, c, i, j, a);
+            patch_bands(gt, C, H, W, ps, py, px, c, i, j, b);
+            s[0] += (double)fabsf(a.lh - b.lh);
+            s[1] += (double)fabsf(a.hl - b.hl);
+            s[2] += (double)fabsf(a.hh - b.hh);
+          }
+    }
+  for (int k = 0; k < 3; k++) sums[k] += (float)s[k];
+  return GS_OK;
+}
+
+int gso_patch_dwt_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps,
+                      const uint8_t* mask, const float* coef, float* grad, int32_t accumulate, void*) {
+  if (!pred || !gt || !mask || !coef || !grad) return GS_E_NULL;
+  const int ny = H / ps, nx = W / ps, hp = cdiv2(ps);
+  if (!accumulate) memset(grad, 0, sizeof(float) * (size_t)C * H * W);
+  for (int py = 0; py < ny; py++)
+    for (int px = 0; px < nx; px++) {
+      if (!mask[py * nx + px]) continue;
+      for (int c = 0; c < C; c++)
+        for (int i = 0; i < hp; i++)
+          for (int j = 0; j < hp; j++) {
+            Bands a, b;
+            patch_bands(pred, C, H, W, ps, py, px, c, i, j, a);
+            patch_bands(gt, C, H, W, ps, py, px, c, i, j, b);
+            float da, db, dc, dd;
+            haar_block_adj(0.f, coef[0] * sgn(a.lh - b.lh), coef[1] * sgn(a.hl - b.hl), coef[2] * sgn(a.hh - b.hh),
+                           da, db, dc, dd);
+            float* p = grad + (size_t)c * H * W;
+            int y0 = py * ps + 2 * i, x0 = px * ps + 2 * j;
+            int y1 = (2 * i + 1 < ps) ? y0 + 1 : y0, x1 = (2 * j + 1 < ps) ? x0 + 1 : x0;
+            p[(size_t)y0 * W + x0] += da;
+            p[(size_t)y0 * W + x1] += db;
+            p[(size_t)y1 * W + x0] += dc;
+            p[(size_t)y1 * W + x1] += dd;
+          }
+    }
+  return GS_OK;
+}
+
+/* fused-ssim/ssim.cu:187-286 */
+int gso_ssim_fwd(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1,
+                 float C2, float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void*) {
+  if (!img1 || !img2 || !ssim_map) return GS_E_NULL;
+  const size_t np = (size_t)H * W;
+  std::vector<float> tmp, a(np), mu1(np), mu2(np), s11(np), s22(np), s12(np);
+  for (int bc = 0; bc < B * C; bc++) {
+    const float* x = img1 + bc * np;
+    const float* y = img2 + bc * np;
+    sepconv(x, H, W, tmp, mu1.data());
+    for (size_t i = 0; i < np; i++) a[i] = x[i] * x[i];
+    sepconv(a.data(), H, W, tmp, s11.data());
+    sepconv(y, H, W, tmp, mu2.data());
+    for (size_t i = 0; i < np; i++) a[i] = y[i] * y[i];
+    sepconv(a.data(), H, W, tmp, s22.data());
+    for (size_t i = 0; i < np; i++) a[i] = x[i] * y[i];
+    sepconv(a.data(), H, W, tmp, s12.data());
+    for (size_t i = 0; i < np; i++) {
+      float m1 = mu1[i], m2 = mu2[i];
+      float sigma1_sq = s11[i] - m1 * m1;
+      float sigma2_sq = s22[i] - m2 * m2;
+      float sigma12 = s12[i] - m1 * m2;
+      float mu1_sq = m1 * m1, mu2_sq = m2 * m2, mu1_mu2 = m1 * m2;
+      float Cc = (2.0f * mu1_mu2 + C1);
+      float D = (2.0f * sigma12 + C2);
+      float A = (mu1_sq + mu2_sq + C1);
+      float Bb = (sigma1_sq + sigma2_sq + C2);
+      float m = (Cc * D) / (A * Bb);
+      size_t o = bc * np + i;
+      ssim_map[o] = m;
+      if (dm_dmu1) {
+        dm_dmu1[o] = ((m2 * 2.0f * D) / (A * Bb) - (m2 * 2.0f * Cc) / (A * Bb) - (m1 * 2.0f * Cc * D) / (A * A * Bb) +
+                      (m1 * 2.0f * Cc * D) / (A * Bb * Bb));
+        dm_dsigma1_sq[o] = ((-Cc * D) / (A * Bb * Bb));
+        dm_dsigma12[o] = ((2 * Cc) / (A * Bb));
+      }
+    }
+  }
+  return GS_OK;
+}
+
+/* fused-ssim/ssim.cu:288-366 */
+int gso_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float, float,
+                 const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                 float* dL_dimg1, void*) {
+  if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return GS_E_NULL;
+  const size_t np = (size_t)H * W;
+  std::vector<float> tmp, a(np), r(np);
+  for (int bc = 0; bc < B * C; bc++) {
+    const size_t o = bc * np;
+    for (size_t i = 0; i < np; i++) a[i] = dm_dmu1[o + i] * dL_dmap[o + i];
+    sepconv(a.data(), H, W, tmp, r.data());
+    for (size_t i = 0; i < np; i++) dL_dimg1[o + i] = 0.0f + r[i];
+    for (size_t i = 0; i < np; i++) a[i] = dm_dsigma1_sq[o + i] * dL_dmap[o + i];
+    sepconv(a.data(), H, W, tmp, r.data());
+    for (size_t i = 0; i < np; i++) dL_dimg1[o + i] += img1[o + i] * 2.0f * r[i];
+    for (size_t i = 0; i < np; i++) a[i] = dm_dsigma12[o + i] * dL_dmap[o + i];
+    sepconv(a.data(), H, W, tmp, r.data());
+    for (size_t i = 0; i < np; i++) dL_dimg1[o + i] += img2[o + i] * r[i];
+  }
+  return GS_OK;
+}
+}

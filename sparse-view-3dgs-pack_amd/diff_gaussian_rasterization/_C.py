@@ -1,0 +1,20 @@
+"""Stand-in for the reference's compiled extension module `diff_gaussian_rasterization._C`
+(diff-gaussian-rasterization/ext.cpp:15-19): the same three entry points, same positional
+arguments and return tuples, served by libgsplat_hip.so.
+
+Deliberately NOT exported: `fusedssim` / `fusedssim_backward` (LGDWT-GS/utils/loss_utils.py:16-19
+probes for them in a try/except; the fused SSIM lives in the separate `fused_ssim` package here).
+"""
+from gsplat_amd import hip_backend
+
+
+def rasterize_gaussians(*args):
+    return hip_backend().rasterize_gaussians(*args)
+
+
+def rasterize_gaussians_backward(*args):
+    return hip_backend().rasterize_gaussians_backward(*args)
+
+
+def mark_visible(*args):
+    return hip_backend().mark_visible(*args)

@@ -1,0 +1,24 @@
+"""Loads the product library csrc/libgsplat_hip.so (prefix ``gs_``).
+
+There is deliberately no fallback: if the HIP library has not been built, or the process has no
+GPU, every operator raises.
+"""
+import os
+import threading
+
+from .capi import CApi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgsplat_hip.so")
+
+_lock = threading.Lock()
+_api = None
+
+
+def hip_api():
+    global _api
+    if _api is None:
+        with _lock:
+            if _api is None:
+                _api = CApi(LIB_PATH, "gs_")
+    return _api

@@ -1,0 +1,149 @@
+"""ctypes view of the C ABI declared in include/gsplat.h.
+
+This module only describes the ABI (structs + prototypes) and loads a shared library that
+implements it.  The product loads ``csrc/libgsplat_hip.so`` with the ``gs_`` prefix (see
+``gsplat_amd/_lib.py``); it raises if that library is missing - there is no CPU fallback.
+(The test-suite binds the same prototypes, prefix ``gso_``, onto the CPU oracle.)
+"""
+import ctypes as C
+import os
+
+c_f_p = C.c_void_p  # all device/host array pointers travel as raw addresses
+
+
+class GsView(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32),
+        ("image_width", C.c_int32),
+        ("tanfovx", C.c_float),
+        ("tanfovy", C.c_float),
+        ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32),
+        ("prefiltered", C.c_int32),
+        ("antialiasing", C.c_int32),
+        ("debug", C.c_int32),
+        ("_pad", C.c_int32),
+        ("bg", C.c_void_p),
+        ("viewmatrix", C.c_void_p),
+        ("projmatrix", C.c_void_p),
+        ("campos", C.c_void_p),
+    ]
+
+
+class GsGaussians(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32),
+        ("M", C.c_int32),
+        ("means3D", C.c_void_p),
+        ("shs", C.c_void_p),
+        ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p),
+        ("scales", C.c_void_p),
+        ("rotations", C.c_void_p),
+        ("cov3D_precomp", C.c_void_p),
+    ]
+
+
+class GsScratch(C.Structure):
+    _fields_ = [
+        ("geom", C.c_void_p),
+        ("geom_bytes", C.c_size_t),
+        ("img", C.c_void_p),
+        ("img_bytes", C.c_size_t),
+        ("binning", C.c_void_p),
+        ("binning_bytes", C.c_size_t),
+        ("binning_capacity", C.c_int64),
+    ]
+
+
+class GsGrads(C.Structure):
+    _fields_ = [
+        ("dL_dmeans3D", C.c_void_p),
+        ("dL_dmeans2D", C.c_void_p),
+        ("dL_dsh", C.c_void_p),
+        ("dL_dcolors", C.c_void_p),
+        ("dL_dopacity", C.c_void_p),
+        ("dL_dscales", C.c_void_p),
+        ("dL_drotations", C.c_void_p),
+        ("dL_dcov3D", C.c_void_p),
+    ]
+
+
+_P = C.c_void_p
+_I32 = C.c_int32
+_I64 = C.c_int64
+_F = C.c_float
+_SZ = C.c_size_t
+
+# name -> (restype, argtypes); the single source of truth for "every symbol include/gsplat.h
+# declares" (tests/test_abi.py checks this table against the header and against the .so).
+PROTOTYPES = {
+    "abi_version": (C.c_int, []),
+    "build_info": (C.c_char_p, []),
+    "scratch_bytes": (C.c_int, [_I32, _I32, _I32, _I64, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "forward_geometry": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P]),
+    "forward_render": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P]),
+    "backward": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P,
+                           C.POINTER(GsGrads), _P, _SZ, _P]),
+    "mark_visible": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
+    "export_geom": (C.c_int, [C.POINTER(GsScratch), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "export_binning": (C.c_int, [C.POINTER(GsScratch), _I64, _P, _P, _P]),
+    "export_img": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _P, _P, _P, _P]),
+    "knn_tmp_bytes": (_SZ, [_I32]),
+    "knn_mean_dist2": (C.c_int, [_P, _I32, _P, _P, _SZ, _P]),
+    "l1_fwd": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "l1_bwd": (C.c_int, [_P, _P, _I64, _F, _P, _I32, _P]),
+    "dwt_haar_fwd": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "dwt_haar_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
+    "dwt2_l1_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
+    "dwt2_l1_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _I32, _P]),
+    "elf_map": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P]),
+    "patch_means": (C.c_int, [_P, _I32, _I32, _I32, _P, _P]),
+    "patch_dwt_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "patch_dwt_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
+    "ssim_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
+    "ssim_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P, _P]),
+}
+
+ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}
+
+
+class GsError(RuntimeError):
+    def __init__(self, fn, code):
+        self.code = code
+        what = ERRORS.get(code, "hipError_t %d" % code if code > 0 else "error %d" % code)
+        super().__init__("%s failed: %s" % (fn, what))
+
+
+class CApi:
+    """A loaded implementation of the gsplat C ABI."""
+
+    def __init__(self, path, prefix="gs_", optional=()):
+        if not os.path.exists(path):
+            raise ImportError(
+                "gsplat native library not found at %s - build it first (python __graft_entry__.py "
+                "or `make -C sparse-view-3dgs-pack_amd/csrc`); there is no fallback path." % path)
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path)
+        self.missing = []
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                f = getattr(self.lib, prefix + name)
+            except AttributeError:
+                if name in optional:
+                    self.missing.append(name)
+                    continue
+                raise ImportError("%s does not export %s%s" % (path, prefix, name))
+            f.restype = res
+            f.argtypes = args
+            setattr(self, "_" + name, f)
+
+    def call(self, name, *args):
+        """Call an int-status entry point; raise GsError on a non-zero status."""
+        rc = getattr(self, "_" + name)(*args)
+        if rc != 0:
+            raise GsError(self.prefix + name, rc)
+
+    def raw(self, name):
+        return getattr(self, "_" + name)

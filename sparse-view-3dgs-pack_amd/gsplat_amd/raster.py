@@ -1,0 +1,244 @@
+"""Host glue between torch tensors and the C ABI (include/gsplat.h).
+
+``RasterBackend`` re-creates the three pybind entry points of the reference extension module
+(`rasterize_gaussians`, `rasterize_gaussians_backward`, `mark_visible`:
+diff-gaussian-rasterization/ext.cpp:15-19, rasterize_points.cu:35-244) with identical positional
+arguments and return tuples, on top of the two-phase C ABI.  Tensors stay torch-owned; only raw
+addresses and the current HIP stream cross the boundary.
+"""
+import ctypes as C
+
+import torch
+
+from .capi import GsGaussians, GsGrads, GsScratch, GsView
+
+NUM_CHANNELS = 3
+
+
+def _ptr(t):
+    """Explicit NULL for 'absent' (the reference relied on data_ptr() of an empty tensor)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _prep(t, device):
+    """contiguous fp32 on `device`; empty stays empty (rasterize_points.cu:101-120)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+class RasterBackend:
+    """Binds one implementation of the C ABI (`api`) to one torch device type."""
+
+    def __init__(self, api, device_type="cuda"):
+        self.api = api
+        self.device_type = device_type
+        self._pinned = None
+        # optimistic binning capacity (instances): skips the forward's host sync when the previous
+        # call's num_rendered is a good predictor; see rasterize_gaussians().
+        self._capacity_hint = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self, device):
+        if device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        return None
+
+    def _check_device(self, t):
+        if t.device.type != self.device_type:
+            raise RuntimeError(
+                "gsplat %s backend got a tensor on %s - the rasterizer has no fallback path"
+                % (self.device_type, t.device))
+
+    def _view(self, keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
+              degree, prefiltered, antialiasing, debug):
+        v = GsView()
+        v.image_height, v.image_width = int(H), int(W)
+        v.tanfovx, v.tanfovy = float(tanfovx), float(tanfovy)
+        v.scale_modifier = float(scale_modifier)
+        v.sh_degree = int(degree)
+        v.prefiltered, v.antialiasing, v.debug = int(bool(prefiltered)), int(bool(antialiasing)), int(bool(debug))
+        bg, viewmatrix, projmatrix, campos = (_prep(x, device) for x in (bg, viewmatrix, projmatrix, campos))
+        keep += [bg, viewmatrix, projmatrix, campos]
+        v.bg, v.viewmatrix, v.projmatrix, v.campos = _ptr(bg), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
+        return v
+
+    def _gauss(self, keep, device, means3D, sh, colors, opacities, scales, rotations, cov3D):
+        g = GsGaussians()
+        means3D, sh, colors, opacities, scales, rotations, cov3D = (
+            _prep(x, device) for x in (means3D, sh, colors, opacities, scales, rotations, cov3D))
+        keep += [means3D, sh, colors, opacities, scales, rotations, cov3D]
+        g.P = int(means3D.shape[0]) if means3D is not None else 0
+        g.M = int(sh.shape[1]) if sh is not None else 0
+        g.means3D, g.shs, g.colors_precomp, g.opacities = _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacities)
+        g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D)
+        return g
+
+    def scratch_bytes(self, P, W, H, R):
+        out = (C.c_size_t * 3)()
+        ws = C.c_size_t(0)
+        self.api.call("scratch_bytes", P, W, H, R, out, C.byref(ws))
+        return out[0], out[1], out[2], ws.value
+
+    @staticmethod
+    def _scratch(geom, img, binning, capacity):
+        s = GsScratch()
+        s.geom, s.geom_bytes = _ptr(geom), geom.numel()
+        s.img, s.img_bytes = _ptr(img), img.numel()
+        s.binning, s.binning_bytes = _ptr(binning), binning.numel()
+        s.binning_capacity = int(capacity)
+        return s
+
+    # ------------------------------------------------------------------ forward
+    def rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
+                            cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
+                            sh, degree, campos, prefiltered, antialiasing, debug):
+        """= RasterizeGaussiansCUDA (rasterize_points.cu:35-124).
+
+        Returns (num_rendered, color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
+        invdepth[1,H,W]).  binningBuffer carries its capacity in its length (see _capacity)."""
+        if means3D.ndim != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:58-60
+        self._check_device(means3D)
+        device = means3D.device
+        P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+        f32 = dict(dtype=torch.float32, device=device)
+        u8 = dict(dtype=torch.uint8, device=device)
+        out_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
+        out_invdepth = torch.zeros((1, H, W), **f32)
+        radii = torch.zeros((P,), dtype=torch.int32, device=device)
+        if P == 0:  # rasterize_points.cu:88
+            e = torch.empty((0,), **u8)
+            return 0, out_color, radii, e, e.clone(), e.clone(), out_invdepth
+
+        keep = []
+        view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
+                          degree, prefiltered, antialiasing, debug)
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+        stream = self._stream(device)
+
+        gb, ib, _, _ = self.scratch_bytes(P, W, H, 0)
+        geom = torch.empty((gb,), **u8)
+        img = torch.empty((ib,), **u8)
+        empty = torch.empty((0,), **u8)
+        s = self._scratch(geom, img, empty, 0)
+
+        if device.type == "cuda":
+            if self._pinned is None:
+                self._pinned = torch.empty((1,), dtype=torch.int32).pin_memory()
+            nr_host = self._pinned
+            self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(),
+                          nr_host.data_ptr(), stream)
+            torch.cuda.current_stream(device).synchronize()  # the reference's blocking D2H (rasterizer_impl.cu:284)
+            num_rendered = int(nr_host[0])
+        else:
+            nr = (C.c_int32 * 1)()
+            self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(),
+                          C.cast(nr, C.c_void_p), stream)
+            num_rendered = int(nr[0])
+
+        _, _, bb, _ = self.scratch_bytes(P, W, H, num_rendered)
+        binning = torch.empty((bb,), **u8)
+        s = self._scratch(geom, img, binning, num_rendered)
+        self.api.call("forward_render", C.byref(view), C.byref(g), C.byref(s), out_color.data_ptr(),
+                      out_invdepth.data_ptr(), stream)
+        return num_rendered, out_color, radii, geom, binning, img, out_invdepth
+
+    # ------------------------------------------------------------------ backward
+    def rasterize_gaussians_backward(self, bg, means3D, radii, colors_precomp, opacities, scales, rotations,
+                                     scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy,
+                                     dL_dout_color, dL_dout_invdepth, sh, degree, campos, geomBuffer, R,
+                                     binningBuffer, imgBuffer, antialiasing, debug):
+        """= RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-223).
+
+        Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+        dL_drotations)."""
+        self._check_device(means3D)
+        device = means3D.device
+        P = int(means3D.shape[0])
+        H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+        M = int(sh.shape[1]) if (sh is not None and sh.numel() != 0) else 0
+        f32 = dict(dtype=torch.float32, device=device)
+        # every row is written by gs_backward (culled rows become 0): empty, not zeros
+        alloc = torch.empty if P != 0 else torch.zeros
+        dL_dmeans3D = alloc((P, 3), **f32)
+        dL_dmeans2D = alloc((P, 3), **f32)
+        dL_dcolors = alloc((P, NUM_CHANNELS), **f32)
+        dL_dopacity = alloc((P, 1), **f32)
+        dL_dcov3D = alloc((P, 6), **f32)
+        dL_dsh = alloc((P, M, 3), **f32)
+        dL_dscales = alloc((P, 3), **f32)
+        dL_drotations = alloc((P, 4), **f32)
+        ret = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+        if P == 0:
+            return ret
+        keep = []
+        view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
+                          degree, False, antialiasing, debug)
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+        stream = self._stream(device)
+        dL_dout_color = _prep(dL_dout_color, device)
+        dL_dout_invdepth = _prep(dL_dout_invdepth, device)
+        radii = radii.contiguous()
+        _, _, _, wsb = self.scratch_bytes(P, W, H, R)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
+        s = self._scratch(geomBuffer, imgBuffer, binningBuffer, R)
+        grads = GsGrads()
+        grads.dL_dmeans3D, grads.dL_dmeans2D = dL_dmeans3D.data_ptr(), dL_dmeans2D.data_ptr()
+        grads.dL_dsh = _ptr(dL_dsh)
+        grads.dL_dcolors, grads.dL_dopacity = dL_dcolors.data_ptr(), dL_dopacity.data_ptr()
+        grads.dL_dscales, grads.dL_drotations = dL_dscales.data_ptr(), dL_drotations.data_ptr()
+        grads.dL_dcov3D = dL_dcov3D.data_ptr()
+        if g.scales is None:
+            dL_dscales.zero_()
+            dL_drotations.zero_()
+        self.api.call("backward", C.byref(view), C.byref(g), radii.data_ptr(), C.byref(s), int(R),
+                      dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(grads), _ptr(ws), ws.numel(), stream)
+        return ret
+
+    # ------------------------------------------------------------------ markVisible
+    def mark_visible(self, means3D, viewmatrix, projmatrix):
+        """= markVisible (rasterize_points.cu:225-244)."""
+        self._check_device(means3D)
+        device = means3D.device
+        P = int(means3D.shape[0])
+        present = torch.zeros((P,), dtype=torch.bool, device=device)
+        if P != 0:
+            m, vm, pm = (_prep(x, device) for x in (means3D, viewmatrix, projmatrix))
+            self.api.call("mark_visible", P, m.data_ptr(), vm.data_ptr(), pm.data_ptr(), present.data_ptr(),
+                          self._stream(device))
+        return present
+
+    # ------------------------------------------------------------------ parity exports
+    def export_state(self, P, W, H, R, geom, binning, img):
+        """Plain-array copies of the forward's internal state (tests / debugging only)."""
+        device = geom.device
+        s = self._scratch(geom, img, binning, R)
+        f32 = dict(dtype=torch.float32, device=device)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        out = dict(
+            depths=torch.zeros((P,), **f32), means2D=torch.zeros((P, 2), **f32), cov3D=torch.zeros((P, 6), **f32),
+            conic_opacity=torch.zeros((P, 4), **f32), rgb=torch.zeros((P, 3), **f32),
+            clamped=torch.zeros((P, 3), dtype=torch.uint8, device=device),
+            tiles_touched=torch.zeros((P,), dtype=torch.int32, device=device),
+            point_offsets=torch.zeros((P,), dtype=torch.int32, device=device),
+            keys_sorted=torch.zeros((R,), dtype=torch.int64, device=device),
+            point_list=torch.zeros((R,), dtype=torch.int32, device=device),
+            final_T=torch.zeros((H, W), **f32), n_contrib=torch.zeros((H, W), dtype=torch.int32, device=device),
+            ranges=torch.zeros((T, 2), dtype=torch.int32, device=device))
+        st = self._stream(device)
+        o = out
+        self.api.call("export_geom", C.byref(s), P, _ptr(o["depths"]), _ptr(o["means2D"]), _ptr(o["cov3D"]),
+                      _ptr(o["conic_opacity"]), _ptr(o["rgb"]), _ptr(o["clamped"]), _ptr(o["tiles_touched"]),
+                      _ptr(o["point_offsets"]), st)
+        self.api.call("export_binning", C.byref(s), R, _ptr(o["keys_sorted"]), _ptr(o["point_list"]), st)
+        self.api.call("export_img", C.byref(s), W, H, _ptr(o["final_T"]), _ptr(o["n_contrib"]), _ptr(o["ranges"]), st)
+        if device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()
+        return out

@@ -1,0 +1,60 @@
+"""Shared helpers for the test-suite: running a scene through a rasterizer class and
+threshold-aware comparisons."""
+import math
+
+import torch
+
+
+def settings_for(Settings, cam, bg, sh_degree, device, antialiasing=False, scale_modifier=1.0, debug=False):
+    return Settings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=bg.to(device), scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(device),
+        projmatrix=cam.full_proj_transform.to(device), sh_degree=sh_degree, campos=cam.camera_center.to(device),
+        prefiltered=False, debug=debug, antialiasing=antialiasing)
+
+
+PARAMS = ("means3D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")
+
+
+def run_scene(Rasterizer, Settings, scene, cam, device, bg=None, antialiasing=False, dL_dcolor=None,
+              dL_dinvdepth=None, backward=True):
+    """Render `scene` (dict of activated tensors) and, if asked, backprop the given image gradients.
+    Returns dict(color, radii, invdepth, grads{name: tensor}, means2D_grad)."""
+    bg = torch.zeros(3) if bg is None else bg
+    p = {}
+    for k in PARAMS:
+        v = scene.get(k)
+        p[k] = None if v is None else v.detach().clone().to(device).requires_grad_(backward)
+    means2D = torch.zeros_like(p["means3D"], requires_grad=backward)
+    rs = settings_for(Settings, cam, bg, scene.get("sh_degree", 0), device, antialiasing,
+                      scene.get("scale_modifier", 1.0))
+    rast = Rasterizer(raster_settings=rs)
+    color, radii, invdepth = rast(means3D=p["means3D"], means2D=means2D, opacities=p["opacities"], shs=p["shs"],
+                                  colors_precomp=p["colors_precomp"], scales=p["scales"], rotations=p["rotations"],
+                                  cov3D_precomp=p["cov3D_precomp"])
+    out = dict(color=color.detach(), radii=radii.detach(), invdepth=invdepth.detach(), grads={})
+    if backward:
+        H, W = cam.image_height, cam.image_width
+        if dL_dcolor is None:
+            g = torch.Generator().manual_seed(99)
+            dL_dcolor = torch.randn((3, H, W), generator=g)
+        loss = (color * dL_dcolor.to(device)).sum()
+        if dL_dinvdepth is not None:
+            loss = loss + (invdepth * dL_dinvdepth.to(device)).sum()
+        loss.backward()
+        for k in PARAMS:
+            if p[k] is not None:
+                out["grads"][k] = p[k].grad.detach() if p[k].grad is not None else torch.zeros_like(p[k])
+        out["grads"]["means2D"] = means2D.grad.detach() if means2D.grad is not None else torch.zeros_like(means2D)
+    return out
+
+
+def rel_err(a, b):
+    """max |a-b| / max(1e-12, max|b|) - tensor-level relative error."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
+
+
+def assert_close(a, b, tol, what=""):
+    e = rel_err(a, b)
+    assert e <= tol, "%s: relative error %.3e > %.1e" % (what, e, tol)

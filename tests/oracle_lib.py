@@ -1,0 +1,60 @@
+"""Test-side loader of the CPU oracle (oracle/libgs_oracle.so, prefix gso_).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "sparse-view-3dgs-pack_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libgs_oracle.so")
+
+_cache = None
+
+
+def build():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h"))]
+    if os.path.exists(ORACLE_SO) and all(os.path.getmtime(ORACLE_SO) >= os.path.getmtime(s) for s in srcs):
+        return
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+class Oracle:
+    def __init__(self):
+        import diff_gaussian_rasterization as dgr
+        from gsplat_amd.capi import CApi
+        from gsplat_amd.raster import RasterBackend
+        build()
+        self.api = CApi(ORACLE_SO, "gso_")
+        self.backend = RasterBackend(self.api, "cpu")
+        backend = self.backend
+        lib = self.api.lib
+        self.lib = lib
+
+        class _Impl:
+            rasterize_gaussians = staticmethod(backend.rasterize_gaussians)
+            rasterize_gaussians_backward = staticmethod(backend.rasterize_gaussians_backward)
+            mark_visible = staticmethod(backend.mark_visible)
+
+        class _OracleFn(dgr._RasterizeGaussians):
+            _impl = _Impl
+
+        class OracleRasterizer(dgr.GaussianRasterizer):
+            _fn = _OracleFn
+
+        self.Rasterizer = OracleRasterizer
+        self.Settings = dgr.GaussianRasterizationSettings
+        for name in ("gso_test_sh_fwd", "gso_test_sh_bwd", "gso_knn_mean_dist2_ex"):
+            getattr(lib, name).restype = C.c_int
+
+
+def get():
+    global _cache
+    if _cache is None:
+        _cache = Oracle()
+    return _cache
