@@ -1,0 +1,278 @@
+// gs_api.hip - extern "C" entry points of libgsplat_hip.so for the rasterizer (include/gsplat.h).
+// Argument checking, scratch carving and launch orchestration only; kernels live in the other files.
+#include <stdio.h>
+#include <string.h>
+
+#include "gs_common.h"
+
+static int check_args(const GsView* v, const GsGaussians* g) {
+  if (!v || !g) return GS_E_NULL;
+  if (g->P < 0 || v->image_width <= 0 || v->image_height <= 0) return GS_E_SHAPE;
+  if (g->P == 0) return GS_OK;
+  if (!g->means3D || !g->opacities || !v->viewmatrix || !v->projmatrix || !v->bg) return GS_E_NULL;
+  if ((g->shs == nullptr) == (g->colors_precomp == nullptr)) return GS_E_SHAPE;
+  const bool has_sr = g->scales != nullptr && g->rotations != nullptr;
+  const bool any_sr = g->scales != nullptr || g->rotations != nullptr;
+  if ((!has_sr && g->cov3D_precomp == nullptr) || (any_sr && g->cov3D_precomp != nullptr)) return GS_E_SHAPE;
+  if (g->shs && (g->M < (v->sh_degree + 1) * (v->sh_degree + 1) || !v->campos)) return GS_E_SHAPE;
+  if (v->sh_degree < 0 || v->sh_degree > 3) return GS_E_SHAPE;
+  if (v->image_width > 65535 * TILE_X || v->image_height > 65535 * TILE_Y) return GS_E_UNSUPPORTED;
+  return GS_OK;
+}
+
+static inline void tile_grid(const GsView* v, int& gx, int& gy) {
+  gx = (v->image_width + TILE_X - 1) / TILE_X;
+  gy = (v->image_height + TILE_Y - 1) / TILE_Y;
+}
+
+extern "C" {
+
+int gs_abi_version(void) { return GS_ABI_VERSION; }
+
+const char* gs_build_info(void) {
+  return "libgsplat_hip gfx950 | hipcc " __VERSION__
+         " | preprocess/knn: -ffp-contract=off, blend: fast contract | radix 8-bit LSD | tile 16x16, wave64 8x8 quadrants";
+}
+
+int gs_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R_capacity, size_t out[3], size_t* bwd_ws) {
+  if (!out) return GS_E_NULL;
+  if (P < 0 || W <= 0 || H <= 0 || R_capacity < 0) return GS_E_SHAPE;
+  const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+  out[0] = geom_bytes((size_t)P);
+  out[1] = img_bytes((size_t)W * H, T);
+  out[2] = bin_bytes((size_t)R_capacity);
+  if (bwd_ws) *bwd_ws = gs_align((size_t)P * GR_STRIDE * sizeof(float));
+  return GS_OK;
+}
+
+int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, int32_t* radii,
+                        int32_t* num_rendered_host, void* stream) {
+  int rc = check_args(v, g);
+  if (rc) return rc;
+  if (!sc || !sc->geom) return GS_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = g->P;
+  if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
+  GeomView gv = geom_view(sc->geom, (size_t)P);
+  if (P == 0) {
+    GS_HIP_CHECK(hipMemsetAsync(gv.hdr, 0, sizeof(GeomHeader), s));
+    if (num_rendered_host) GS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, &gv.hdr->num_rendered, 4, hipMemcpyDeviceToHost, s));
+    return GS_OK;
+  }
+  if (!radii) return GS_E_NULL;
+  PreprocessArgs a;
+  a.P = P;
+  a.D = v->sh_degree;
+  a.M = g->M;
+  a.means3D = g->means3D;
+  a.scales = g->scales;
+  a.scale_modifier = v->scale_modifier;
+  a.rotations = g->rotations;
+  a.opacities = g->opacities;
+  a.shs = g->shs;
+  a.cov3D_precomp = g->cov3D_precomp;
+  a.colors_precomp = g->colors_precomp;
+  a.viewmatrix = v->viewmatrix;
+  a.projmatrix = v->projmatrix;
+  a.campos = v->campos;
+  a.W = v->image_width;
+  a.H = v->image_height;
+  // rasterizer_impl.cu:224-225
+  a.focal_y = v->image_height / (2.0f * v->tanfovy);
+  a.focal_x = v->image_width / (2.0f * v->tanfovx);
+  a.tan_fovx = v->tanfovx;
+  a.tan_fovy = v->tanfovy;
+  a.radii = radii;
+  tile_grid(v, a.grid_x, a.grid_y);
+  a.antialiasing = v->antialiasing;
+  launch_preprocess_fwd(a, gv, s);
+  GS_LAUNCH_CHECK(s, v->debug);
+  launch_scan_block_sums(gv, P, s);
+  GS_LAUNCH_CHECK(s, v->debug);
+  if (num_rendered_host)
+    GS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, &gv.hdr->num_rendered, 4, hipMemcpyDeviceToHost, s));
+  return GS_OK;
+}
+
+int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_invdepth,
+                      void* stream) {
+  int rc = check_args(v, g);
+  if (rc) return rc;
+  if (!sc || !sc->geom || !sc->img || !out_color) return GS_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = g->P, W = v->image_width, H = v->image_height;
+  int gx, gy;
+  tile_grid(v, gx, gy);
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  if (sc->img_bytes < img_bytes(N, T)) return GS_E_SCRATCH;
+  if (P == 0) {  // rasterize_points.cu:88 - outputs stay zero
+    GS_HIP_CHECK(hipMemsetAsync(out_color, 0, sizeof(float) * GS_NUM_CHANNELS * N, s));
+    if (out_invdepth) GS_HIP_CHECK(hipMemsetAsync(out_invdepth, 0, sizeof(float) * N, s));
+    return GS_OK;
+  }
+  if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
+  const int64_t cap = sc->binning_capacity;
+  if (cap < 0) return GS_E_SHAPE;
+  if (cap > 0 && (!sc->binning || sc->binning_bytes < bin_bytes((size_t)cap))) return GS_E_SCRATCH;
+  if (cap > 0xFFFFFFFFll) return GS_E_UNSUPPORTED;
+  GeomView gv = geom_view(sc->geom, (size_t)P);
+  ImgView iv = img_view(sc->img, N, T);
+  BinView bv = bin_view(sc->binning, (size_t)cap);
+
+  launch_bin_prepare(gv, cap, s);
+  GS_LAUNCH_CHECK(s, v->debug);
+  if (cap > 0) {
+    // the unsorted list goes into the ping-pong half from which an LSD sort of `passes` passes
+    // ends in half 0, so that backward / exports always find the sorted list in half 0
+    const int bit = (int)gs_higher_msb((uint32_t)(gx * gy));
+    const int passes = (32 + bit + RS_BITS - 1) / RS_BITS;
+    const int start = passes & 1;
+    launch_duplicate(gv, P, gx, bv, start, s);
+    GS_LAUNCH_CHECK(s, v->debug);
+    rc = launch_radix_sort(bv, &gv.hdr->sort_n, cap, 32 + bit, start, s, v->debug);
+    if (rc) return rc;
+  }
+  rc = launch_tile_ranges(bv.keys[0], &gv.hdr->sort_n, cap, iv.ranges, (int)T, s);
+  if (rc) return rc;
+  GS_LAUNCH_CHECK(s, v->debug);
+  launch_render_fwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
+                    out_invdepth, s);
+  GS_LAUNCH_CHECK(s, v->debug);
+  return GS_OK;
+}
+
+int gs_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
+                int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const GsGrads* grads,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_args(v, g);
+  if (rc) return rc;
+  if (!sc || !grads || !dL_dcolor) return GS_E_NULL;
+  const int P = g->P, W = v->image_width, H = v->image_height;
+  if (P == 0) return GS_OK;
+  if (!radii || !sc->geom || !sc->img || !workspace) return GS_E_NULL;
+  if (workspace_bytes < (size_t)P * GR_STRIDE * sizeof(float)) return GS_E_SCRATCH;
+  if (num_rendered < 0 || num_rendered > sc->binning_capacity) return GS_E_SHAPE;
+  if (num_rendered > 0 && !sc->binning) return GS_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  int gx, gy;
+  tile_grid(v, gx, gy);
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  GeomView gv = geom_view(sc->geom, (size_t)P);
+  ImgView iv = img_view(sc->img, N, T);
+  BinView bv = bin_view(sc->binning, (size_t)sc->binning_capacity);
+  float* rows = (float*)workspace;
+  GS_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)P * GR_STRIDE * sizeof(float), s));
+  if (num_rendered > 0) {
+    launch_render_bwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
+                      dL_dinvdepth, rows, s);
+    GS_LAUNCH_CHECK(s, v->debug);
+  }
+  PreprocessBwdArgs a;
+  a.P = P;
+  a.D = v->sh_degree;
+  a.M = g->M;
+  a.means3D = g->means3D;
+  a.radii = radii;
+  a.shs = g->shs;
+  a.scales = g->scales;
+  a.rotations = g->rotations;
+  a.opacities = g->opacities;
+  a.colors_precomp = g->colors_precomp;
+  a.scale_modifier = v->scale_modifier;
+  a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : gv.cov3D;
+  a.viewmatrix = v->viewmatrix;
+  a.projmatrix = v->projmatrix;
+  a.campos = v->campos;
+  a.focal_y = H / (2.0f * v->tanfovy);
+  a.focal_x = W / (2.0f * v->tanfovx);
+  a.tan_fovx = v->tanfovx;
+  a.tan_fovy = v->tanfovy;
+  a.antialiasing = v->antialiasing;
+  a.has_invdepth = dL_dinvdepth != nullptr;
+  a.grad_rows = rows;
+  a.splat = gv.splat;
+  a.out = *grads;
+  launch_preprocess_bwd(a, s);
+  GS_LAUNCH_CHECK(s, v->debug);
+  return GS_OK;
+}
+
+int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* /*projmatrix*/,
+                    uint8_t* present, void* stream) {
+  if (P < 0) return GS_E_SHAPE;
+  if (P == 0) return GS_OK;
+  if (!means3D || !viewmatrix || !present) return GS_E_NULL;
+  launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+  GS_LAUNCH_CHECK((hipStream_t)stream, 0);
+  return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parity exports
+// ------------------------------------------------------------------------------------------------
+__global__ void export_geom_kernel(GeomView g, int P, float* depths, float* means2D, float* cov3D, float* conic_opacity,
+                                   float* rgb, uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_offsets) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const Splat sp = g.splat[i];
+  const bool vis = sp.radius > 0;
+  if (depths) depths[i] = vis ? sp.depth : 0.f;
+  if (means2D) {
+    means2D[2 * i] = vis ? sp.x : 0.f;
+    means2D[2 * i + 1] = vis ? sp.y : 0.f;
+  }
+  if (conic_opacity) {
+    conic_opacity[4 * i] = vis ? sp.cxx : 0.f;
+    conic_opacity[4 * i + 1] = vis ? sp.cxy : 0.f;
+    conic_opacity[4 * i + 2] = vis ? sp.cyy : 0.f;
+    conic_opacity[4 * i + 3] = vis ? sp.opacity : 0.f;
+  }
+  if (rgb) {
+    rgb[3 * i] = vis ? sp.r : 0.f;
+    rgb[3 * i + 1] = vis ? sp.g : 0.f;
+    rgb[3 * i + 2] = vis ? sp.b : 0.f;
+  }
+  if (clamped)
+    for (int c = 0; c < 3; c++) clamped[3 * i + c] = vis ? ((sp.clamped >> c) & 1u) : 0;
+  if (cov3D)
+    for (int k = 0; k < 6; k++) cov3D[6 * i + k] = vis ? g.cov3D[6 * (size_t)i + k] : 0.f;
+  if (tiles_touched) tiles_touched[i] = g.tiles_touched[i];
+  if (point_offsets) point_offsets[i] = g.point_offsets[i];
+}
+
+int gs_export_geom(const GsScratch* sc, int32_t P, float* depths, float* means2D, float* cov3D, float* conic_opacity,
+                   float* rgb, uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_offsets, void* stream) {
+  if (!sc || !sc->geom) return GS_E_NULL;
+  if (P <= 0) return GS_OK;
+  GeomView gv = geom_view(sc->geom, (size_t)P);
+  hipLaunchKernelGGL(export_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, gv, P, depths,
+                     means2D, cov3D, conic_opacity, rgb, clamped, tiles_touched, point_offsets);
+  GS_LAUNCH_CHECK((hipStream_t)stream, 0);
+  return GS_OK;
+}
+
+int gs_export_img(const GsScratch* sc, int32_t W, int32_t H, float* final_T, uint32_t* n_contrib, uint32_t* ranges,
+                  void* stream) {
+  if (!sc || !sc->img) return GS_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  ImgView iv = img_view(sc->img, N, T);
+  if (final_T) GS_HIP_CHECK(hipMemcpyAsync(final_T, iv.final_T, 4 * N, hipMemcpyDeviceToDevice, s));
+  if (n_contrib) GS_HIP_CHECK(hipMemcpyAsync(n_contrib, iv.n_contrib, 4 * N, hipMemcpyDeviceToDevice, s));
+  if (ranges) GS_HIP_CHECK(hipMemcpyAsync(ranges, iv.ranges, 8 * T, hipMemcpyDeviceToDevice, s));
+  return GS_OK;
+}
+
+int gs_export_binning(const GsScratch* sc, int64_t R, uint64_t* keys_sorted, uint32_t* point_list, void* stream) {
+  if (!sc) return GS_E_NULL;
+  if (R <= 0) return GS_OK;
+  if (!sc->binning) return GS_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  BinView bv = bin_view(sc->binning, (size_t)sc->binning_capacity);
+  if (keys_sorted) GS_HIP_CHECK(hipMemcpyAsync(keys_sorted, bv.keys[0], 8 * (size_t)R, hipMemcpyDeviceToDevice, s));
+  if (point_list) GS_HIP_CHECK(hipMemcpyAsync(point_list, bv.vals[0], 4 * (size_t)R, hipMemcpyDeviceToDevice, s));
+  return GS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// gs_common.h - shared host/device definitions of libgsplat_hip (gfx950 only).
+//
+// HBM layout of the private fwd<->bwd state (the three byte buffers of include/gsplat.h):
+//
+//  geom   : GeomHeader (256 B)
+//           splat[P]        64-byte record per Gaussian (one cache line per gather in the blend kernels)
+//           cov3D[P][6]     fp32, only read again by the backward per-Gaussian kernel
+//           tiles_touched[P] u32   (scan input)
+//           point_offsets[P] u32   (inclusive scan, written by the duplicate kernel)
+//           block_sums[ceil(P/256)] u32 -> exclusive block offsets after the scan kernel
+//  img    : final_T[N] f32 | n_contrib[N] u32 | ranges[T] uint2
+//  binning: keys[2][cap] u64 | vals[2][cap] u32 | radix histograms
+//
+// All sub-arrays start on 256-byte boundaries.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsplat.h"
+
+#define GS_BLOCK 256
+#define TILE_X GS_TILE_X
+#define TILE_Y GS_TILE_Y
+
+// ---------------------------------------------------------------------------------------------
+struct GeomHeader {
+  uint32_t num_rendered;  // R = sum tiles_touched
+  uint32_t overflow;      // set by the duplicate kernel when R > binning capacity
+  uint32_t P;
+  uint32_t sort_n;        // instances the binning stage really processes: overflow ? 0 : num_rendered
+  uint32_t pad[60];
+};
+static_assert(sizeof(GeomHeader) == 256, "header is one 256-B block");
+
+// 64-byte per-Gaussian record written by the forward preprocess kernel.
+struct __attribute__((aligned(64))) Splat {
+  float x, y;        // pixel-space mean (ndc2Pix)
+  float depth;       // view-space z
+  float invdepth;    // 1 / depth (what the blend accumulates, forward.cu:375)
+  float cxx, cxy, cyy;  // conic
+  float opacity;     // opacity * antialiasing scaling
+  float r, g, b;     // SH colour (+0.5, clamped) or colors_precomp
+  int32_t radius;    // 0 = culled
+  uint32_t rect_min; // x | y << 16
+  uint32_t rect_max;
+  uint32_t tiles;    // tiles_touched
+  uint32_t clamped;  // bit c set = channel c was clamped to 0
+};
+static_assert(sizeof(Splat) == 64, "Splat is one 64-B line");
+
+static inline __host__ __device__ size_t gs_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct GeomView {
+  GeomHeader* hdr;
+  Splat* splat;
+  float* cov3D;
+  uint32_t* tiles_touched;
+  uint32_t* point_offsets;
+  uint32_t* block_sums;
+};
+static inline __host__ __device__ size_t geom_bytes(size_t P) {
+  size_t nb = (P + GS_BLOCK - 1) / GS_BLOCK;
+  return sizeof(GeomHeader) + gs_align(64 * P) + gs_align(24 * P) + gs_align(4 * P) + gs_align(4 * P) +
+         gs_align(4 * (nb + 1));
+}
+static inline __host__ __device__ GeomView geom_view(void* buf, size_t P) {
+  char* p = (char*)buf;
+  size_t nb = (P + GS_BLOCK - 1) / GS_BLOCK;
+  GeomView g;
+  g.hdr = (GeomHeader*)p; p += sizeof(GeomHeader);
+  g.splat = (Splat*)p; p += gs_align(64 * P);
+  g.cov3D = (float*)p; p += gs_align(24 * P);
+  g.tiles_touched = (uint32_t*)p; p += gs_align(4 * P);
+  g.point_offsets = (uint32_t*)p; p += gs_align(4 * P);
+  g.block_sums = (uint32_t*)p; p += gs_align(4 * (nb + 1));
+  return g;
+}
+
+struct ImgView {
+  float* final_T;
+  uint32_t* n_contrib;
+  uint2* ranges;
+};
+static inline __host__ __device__ size_t img_bytes(size_t N, size_t T) {
+  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T);
+}
+static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T) {
+  char* p = (char*)buf;
+  ImgView v;
+  v.final_T = (float*)p; p += gs_align(4 * N);
+  v.n_contrib = (uint32_t*)p; p += gs_align(4 * N);
+  v.ranges = (uint2*)p;
+  (void)T;
+  return v;
+}
+
+// radix sort geometry: 8-bit digits, 256 threads x 16 keys per block
+#define RS_BITS 8
+#define RS_RADIX 256
+#define RS_ITEMS 16
+#define RS_TILE (GS_BLOCK * RS_ITEMS)
+
+struct BinView {
+  uint64_t* keys[2];
+  uint32_t* vals[2];
+  uint32_t* hist;      // [RS_RADIX][nblk] digit-major block histograms (+ scan scratch behind it)
+  uint32_t* scan_tmp;  // block sums of the histogram scan
+  size_t nblk;
+  size_t hist_n;
+};
+static inline __host__ __device__ size_t bin_bytes(size_t cap) {
+  if (cap == 0) cap = 1;
+  size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
+  size_t hist_n = nblk * RS_RADIX;
+  size_t nscan = (hist_n + RS_TILE - 1) / RS_TILE;
+  return 2 * gs_align(8 * cap) + 2 * gs_align(4 * cap) + gs_align(4 * hist_n) + gs_align(4 * (nscan + 1));
+}
+static inline __host__ __device__ BinView bin_view(void* buf, size_t cap) {
+  if (cap == 0) cap = 1;
+  char* p = (char*)buf;
+  BinView b;
+  b.nblk = (cap + RS_TILE - 1) / RS_TILE;
+  b.hist_n = b.nblk * RS_RADIX;
+  size_t nscan = (b.hist_n + RS_TILE - 1) / RS_TILE;
+  b.keys[0] = (uint64_t*)p; p += gs_align(8 * cap);
+  b.keys[1] = (uint64_t*)p; p += gs_align(8 * cap);
+  b.vals[0] = (uint32_t*)p; p += gs_align(4 * cap);
+  b.vals[1] = (uint32_t*)p; p += gs_align(4 * cap);
+  b.hist = (uint32_t*)p; p += gs_align(4 * b.hist_n);
+  b.scan_tmp = (uint32_t*)p; p += gs_align(4 * (nscan + 1));
+  return b;
+}
+
+// per-Gaussian gradient row accumulated by the backward blend (one 64-B line per Gaussian)
+enum { GR_MX = 0, GR_MY, GR_CXX, GR_CXY, GR_CYY, GR_OP, GR_CR, GR_CG, GR_CB, GR_ID, GR_N, GR_STRIDE = 16 };
+
+// rasterizer_impl.cu:35-50 (host)
+static inline uint32_t gs_higher_msb(uint32_t n) {
+  uint32_t msb = sizeof(n) * 4;
+  uint32_t step = msb;
+  while (step > 1) {
+    step /= 2;
+    if (n >> msb)
+      msb += step;
+    else
+      msb -= step;
+  }
+  if (n >> msb) msb++;
+  return msb;
+}
+
+#define GS_HIP_CHECK(expr)                 \
+  do {                                     \
+    hipError_t _e = (expr);                \
+    if (_e != hipSuccess) return (int)_e;  \
+  } while (0)
+
+// after a launch: surface launch errors; in debug mode also synchronise (auxiliary.h:178-185)
+static inline int gs_after_launch(hipStream_t s, int debug) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (debug) {
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+#define GS_LAUNCH_CHECK(stream, debug)             \
+  do {                                             \
+    int _rc = gs_after_launch((stream), (debug));  \
+    if (_rc) return _rc;                           \
+  } while (0)
+
+// ---- launchers implemented in the kernel files (host functions, C++ linkage) ----
+struct PreprocessArgs {
+  int P, D, M;
+  const float* means3D;
+  const float* scales;
+  float scale_modifier;
+  const float* rotations;
+  const float* opacities;
+  const float* shs;
+  const float* cov3D_precomp;
+  const float* colors_precomp;
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* campos;
+  int W, H;
+  float focal_x, focal_y, tan_fovx, tan_fovy;
+  int* radii;
+  int grid_x, grid_y;
+  int antialiasing;
+};
+int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_t s);
+int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s);
+int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+
+int launch_bin_prepare(const GeomView& g, int64_t capacity, hipStream_t s);
+int launch_duplicate(const GeomView& g, int P, int grid_x, const BinView& b, int buf, hipStream_t s);
+int launch_radix_sort(const BinView& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
+                      hipStream_t s, int debug);
+int launch_tile_ranges(const uint64_t* keys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
+                       hipStream_t s);
+
+int launch_render_fwd(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
+                      const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
+                      float* out_invdepth, hipStream_t s);
+int launch_render_bwd(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
+                      const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                      const float* dL_dpix, const float* dL_dinvdepth, float* grad_rows, hipStream_t s);
+
+struct PreprocessBwdArgs {
+  int P, D, M;
+  const float* means3D;
+  const int* radii;
+  const float* shs;
+  const float* scales;
+  const float* rotations;
+  const float* opacities;
+  const float* colors_precomp;
+  float scale_modifier;
+  const float* cov3D;  // precomputed or geom.cov3D
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* campos;
+  float focal_x, focal_y, tan_fovx, tan_fovy;
+  int antialiasing;
+  int has_invdepth;
+  const float* grad_rows;  // [P][GR_STRIDE]
+  const Splat* splat;
+  GsGrads out;
+};
+int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);

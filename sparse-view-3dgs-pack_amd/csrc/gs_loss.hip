@@ -1,0 +1,591 @@
+// gs_loss.hip - image-space loss kernels of LGDWT-GS (all HBM-bound streaming kernels).
+//
+//   L1                          LGDWT-GS/utils/loss_utils.py:40-41
+//   Haar DWT ('db1','symmetric')  the arithmetic of pytorch_wavelets.DWTForward as used by
+//                               LGDWT-GS/utils/loss_utils.py:106-153 (two separable stages with
+//                               c = float32(0.70710678...), first along W then along H; odd sizes repeat
+//                               the last sample; LH = low along W / high along H)
+//   global 2-level DWT L1 loss  LGDWT-GS/train.py:132-164 - ONE pass over pred and gt computes all eight
+//                               sub-band L1 sums (the reference runs a wasted J=2 transform plus two J=1
+//                               transforms per image and materialises 16 band tensors)
+//   ELF map / patch selection   LGDWT-GS/utils/loss_utils.py:336-442
+//   fused SSIM                  fused-ssim/ssim.cu:187-366 (11-tap sigma=1.5 separable window, zero padding)
+#include "gs_common.h"
+
+#define HC 0.7071067811865476f
+
+struct Bands {
+  float ll, lh, hl, hh;
+};
+__device__ __forceinline__ Bands haar_block(float a, float b, float c, float d) {
+  const float lo_t = HC * a + HC * b, hi_t = HC * a - HC * b;
+  const float lo_b = HC * c + HC * d, hi_b = HC * c - HC * d;
+  Bands r;
+  r.ll = HC * lo_t + HC * lo_b;
+  r.lh = HC * lo_t - HC * lo_b;
+  r.hl = HC * hi_t + HC * hi_b;
+  r.hh = HC * hi_t - HC * hi_b;
+  return r;
+}
+__device__ __forceinline__ void haar_block_adj(float gll, float glh, float ghl, float ghh, float& da, float& db,
+                                               float& dc, float& dd) {
+  const float dlo_t = HC * gll + HC * glh, dlo_b = HC * gll - HC * glh;
+  const float dhi_t = HC * ghl + HC * ghh, dhi_b = HC * ghl - HC * ghh;
+  da = HC * dlo_t + HC * dhi_t;
+  db = HC * dlo_t - HC * dhi_t;
+  dc = HC * dlo_b + HC * dhi_b;
+  dd = HC * dlo_b - HC * dhi_b;
+}
+__device__ __forceinline__ float sgnf(float x) { return (float)((x > 0.f) - (x < 0.f)); }
+__device__ __forceinline__ int cdiv2(int n) { return (n + 1) >> 1; }
+
+template <int N>
+__device__ __forceinline__ void block_sum_atomic(float (&v)[N], float* out) {
+  __shared__ float red[GS_BLOCK / 64][N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    float x = v[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    float s = 0.f;
+    for (int w = 0; w < GS_BLOCK / 64; w++) s += red[w][threadIdx.x];
+    if (s != 0.f) atomicAdd(&out[threadIdx.x], s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ L1
+__global__ void __launch_bounds__(GS_BLOCK) l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          int64_t n, float* sum) {
+  float acc[1] = {0.f};
+  const int64_t n4 = n >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  for (int64_t i = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * GS_BLOCK) {
+    const float4 x = a4[i], y = b4[i];
+    acc[0] += fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) acc[0] += fabsf(a[n4 * 4 + threadIdx.x] - b[n4 * 4 + threadIdx.x]);
+  block_sum_atomic<1>(acc, sum);
+}
+__global__ void __launch_bounds__(GS_BLOCK) l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          int64_t n, float coef, float* __restrict__ g, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GS_BLOCK) {
+    const float v = coef * sgnf(a[i] - b[i]);
+    g[i] = accumulate ? g[i] + v : v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ single-level DWT
+__global__ void __launch_bounds__(GS_BLOCK) dwt_fwd_kernel(const float* __restrict__ x, int NC, int H, int W, float* ll,
+                                                           float* lh, float* hl, float* hh) {
+  const int h = cdiv2(H), w = cdiv2(W);
+  const int64_t total = (int64_t)NC * h * w;
+  for (int64_t o = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; o < total; o += (int64_t)gridDim.x * GS_BLOCK) {
+    const int j = (int)(o % w), i = (int)((o / w) % h), c = (int)(o / ((int64_t)w * h));
+    const float* p = x + (size_t)c * H * W;
+    const int y0 = 2 * i, y1 = min(2 * i + 1, H - 1), x0 = 2 * j, x1 = min(2 * j + 1, W - 1);
+    const Bands b = haar_block(p[(size_t)y0 * W + x0], p[(size_t)y0 * W + x1], p[(size_t)y1 * W + x0], p[(size_t)y1 * W + x1]);
+    if (ll) ll[o] = b.ll;
+    if (lh) lh[o] = b.lh;
+    if (hl) hl[o] = b.hl;
+    if (hh) hh[o] = b.hh;
+  }
+}
+// adjoint: one thread per 2x2 block owns its four output pixels (padded duplicates fold onto the last row/col)
+__global__ void __launch_bounds__(GS_BLOCK) dwt_bwd_kernel(const float* dll, const float* dlh, const float* dhl,
+                                                           const float* dhh, int NC, int H, int W, float* __restrict__ dx) {
+  const int h = cdiv2(H), w = cdiv2(W);
+  const int64_t total = (int64_t)NC * h * w;
+  for (int64_t o = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; o < total; o += (int64_t)gridDim.x * GS_BLOCK) {
+    const int j = (int)(o % w), i = (int)((o / w) % h), c = (int)(o / ((int64_t)w * h));
+    float da, db, dc, dd;
+    haar_block_adj(dll ? dll[o] : 0.f, dlh ? dlh[o] : 0.f, dhl ? dhl[o] : 0.f, dhh ? dhh[o] : 0.f, da, db, dc, dd);
+    float* p = dx + (size_t)c * H * W;
+    const int y0 = 2 * i, x0 = 2 * j;
+    const bool py = 2 * i + 1 >= H, pxp = 2 * j + 1 >= W;  // padded row / column
+    // clamped targets: fold in the oracle's order  p[y0,x0]+=da; p[y0,x1]+=db; p[y1,x0]+=dc; p[y1,x1]+=dd
+    if (!py && !pxp) {
+      p[(size_t)y0 * W + x0] = da;
+      p[(size_t)y0 * W + x0 + 1] = db;
+      p[(size_t)(y0 + 1) * W + x0] = dc;
+      p[(size_t)(y0 + 1) * W + x0 + 1] = dd;
+    } else if (py && !pxp) {
+      p[(size_t)y0 * W + x0] = da + dc;
+      p[(size_t)y0 * W + x0 + 1] = db + dd;
+    } else if (!py && pxp) {
+      p[(size_t)y0 * W + x0] = da + db;
+      p[(size_t)(y0 + 1) * W + x0] = dc + dd;
+    } else {
+      p[(size_t)y0 * W + x0] = ((da + db) + dc) + dd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fused 2-level DWT L1
+// One thread per level-2 coefficient = a 4x4 pixel block of one channel.  It forms the four level-1
+// blocks (bands of pred and gt separately, as the reference does) and the level-2 block of their LL1.
+struct Blk44 {
+  float l1[2][2][4];  // [r][c][band] level-1 bands (r,c = position inside the level-2 block)
+  float l2[4];
+};
+__device__ __forceinline__ void load_blk44(const float* __restrict__ p, int H, int W, int i2, int j2, int h1, int w1,
+                                           Blk44& o) {
+  float ll[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int r1 = min(2 * i2 + r, h1 - 1), c1 = min(2 * j2 + c, w1 - 1);  // symmetric repeat of LL1's last sample
+      const int y0 = 2 * r1, y1 = min(2 * r1 + 1, H - 1), x0 = 2 * c1, x1 = min(2 * c1 + 1, W - 1);
+      const Bands b = haar_block(p[(size_t)y0 * W + x0], p[(size_t)y0 * W + x1], p[(size_t)y1 * W + x0], p[(size_t)y1 * W + x1]);
+      o.l1[r][c][0] = b.ll; o.l1[r][c][1] = b.lh; o.l1[r][c][2] = b.hl; o.l1[r][c][3] = b.hh;
+      ll[r][c] = b.ll;
+    }
+  const Bands b2 = haar_block(ll[0][0], ll[0][1], ll[1][0], ll[1][1]);
+  o.l2[0] = b2.ll; o.l2[1] = b2.lh; o.l2[2] = b2.hl; o.l2[3] = b2.hh;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                               int C, int H, int W, float* band_sums) {
+  const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
+  const int64_t total = (int64_t)C * h2 * w2;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t o = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; o < total; o += (int64_t)gridDim.x * GS_BLOCK) {
+    const int j2 = (int)(o % w2), i2 = (int)((o / w2) % h2), c = (int)(o / ((int64_t)w2 * h2));
+    Blk44 a, b;
+    load_blk44(pred + (size_t)c * H * W, H, W, i2, j2, h1, w1, a);
+    load_blk44(gt + (size_t)c * H * W, H, W, i2, j2, h1, w1, b);
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int cc = 0; cc < 2; cc++)
+        if (2 * i2 + r < h1 && 2 * j2 + cc < w1) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) s[k] += fabsf(a.l1[r][cc][k] - b.l1[r][cc][k]);
+        }
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[4 + k] += fabsf(a.l2[k] - b.l2[k]);
+  }
+  block_sum_atomic<8>(s, band_sums);
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                               int C, int H, int W, const float* __restrict__ coef,
+                                                               float* __restrict__ grad, int accumulate) {
+  const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
+  const int64_t total = (int64_t)C * h2 * w2;
+  float cf[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) cf[k] = coef[k];
+  for (int64_t o = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; o < total; o += (int64_t)gridDim.x * GS_BLOCK) {
+    const int j2 = (int)(o % w2), i2 = (int)((o / w2) % h2), c = (int)(o / ((int64_t)w2 * h2));
+    Blk44 a, b;
+    load_blk44(pred + (size_t)c * H * W, H, W, i2, j2, h1, w1, a);
+    load_blk44(gt + (size_t)c * H * W, H, W, i2, j2, h1, w1, b);
+    // level-2 adjoint -> gradient of the four LL1 inputs (padded duplicates fold onto the last sample)
+    float dl[2][2];
+    {
+      float da, db, dc, dd;
+      haar_block_adj(cf[4] * sgnf(a.l2[0] - b.l2[0]), cf[5] * sgnf(a.l2[1] - b.l2[1]), cf[6] * sgnf(a.l2[2] - b.l2[2]),
+                     cf[7] * sgnf(a.l2[3] - b.l2[3]), da, db, dc, dd);
+      const bool pr = 2 * i2 + 1 >= h1, pc = 2 * j2 + 1 >= w1;
+      dl[0][0] = da; dl[0][1] = db; dl[1][0] = dc; dl[1][1] = dd;
+      if (pr && pc) { dl[0][0] = ((da + db) + dc) + dd; }
+      else if (pr) { dl[0][0] = da + dc; dl[0][1] = db + dd; }
+      else if (pc) { dl[0][0] = da + db; dl[1][0] = dc + dd; }
+    }
+    float* gp = grad + (size_t)c * H * W;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int cc = 0; cc < 2; cc++) {
+        const int r1 = 2 * i2 + r, c1 = 2 * j2 + cc;
+        if (r1 >= h1 || c1 >= w1) continue;
+        float da, db, dc, dd;
+        haar_block_adj(cf[0] * sgnf(a.l1[r][cc][0] - b.l1[r][cc][0]) + dl[r][cc], cf[1] * sgnf(a.l1[r][cc][1] - b.l1[r][cc][1]),
+                       cf[2] * sgnf(a.l1[r][cc][2] - b.l1[r][cc][2]), cf[3] * sgnf(a.l1[r][cc][3] - b.l1[r][cc][3]), da, db,
+                       dc, dd);
+        const int y0 = 2 * r1, x0 = 2 * c1;
+        const bool py = y0 + 1 >= H, pxp = x0 + 1 >= W;
+        float v00 = da, v01 = db, v10 = dc, v11 = dd;
+        if (py && pxp) v00 = ((da + db) + dc) + dd;
+        else if (py) { v00 = da + dc; v01 = db + dd; }
+        else if (pxp) { v00 = da + db; v10 = dc + dd; }
+        float* q = gp + (size_t)y0 * W + x0;
+        if (accumulate) {
+          q[0] += v00;
+          if (!pxp) q[1] += v01;
+          if (!py) { q[W] += v10; if (!pxp) q[W + 1] += v11; }
+        } else {
+          q[0] = v00;
+          if (!pxp) q[1] = v01;
+          if (!py) { q[W] = v10; if (!pxp) q[W + 1] = v11; }
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ ELF
+__global__ void __launch_bounds__(GS_BLOCK) elf_low_kernel(const float* __restrict__ img, int C, int H, int W,
+                                                           float* __restrict__ low) {
+  const int h = cdiv2(H), w = cdiv2(W);
+  const int o = blockIdx.x * GS_BLOCK + threadIdx.x;
+  if (o >= h * w) return;
+  const int j = o % w, i = o / w;
+  const int y0 = 2 * i, y1 = min(2 * i + 1, H - 1), x0 = 2 * j, x1 = min(2 * j + 1, W - 1);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int c = 0; c < C; c++) {
+    const float* p = img + (size_t)c * H * W;
+    const Bands b = haar_block(p[(size_t)y0 * W + x0], p[(size_t)y0 * W + x1], p[(size_t)y1 * W + x0], p[(size_t)y1 * W + x1]);
+    s0 += fabsf(b.ll); s1 += fabsf(b.lh); s2 += fabsf(b.hl); s3 += fabsf(b.hh);
+  }
+  const float HF = s1 + s2 + s3;
+  low[o] = s0 / (s0 + HF + 1e-8f);
+}
+// F.interpolate(size=(H,W), mode='bilinear', align_corners=False)
+__global__ void __launch_bounds__(GS_BLOCK) bilinear_up_kernel(const float* __restrict__ low, int h, int w, int H, int W,
+                                                               float* __restrict__ out) {
+  const int o = blockIdx.x * GS_BLOCK + threadIdx.x;
+  if (o >= H * W) return;
+  const int x = o % W, y = o / W;
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  float sy = sh * ((float)y + 0.5f) - 0.5f;
+  if (sy < 0) sy = 0;
+  const int y0 = (int)sy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+  const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+  float sx = sw * ((float)x + 0.5f) - 0.5f;
+  if (sx < 0) sx = 0;
+  const int x0 = (int)sx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+  out[o] = ly0 * (lx0 * low[(size_t)y0 * w + x0] + lx1 * low[(size_t)y0 * w + x1]) +
+           ly1 * (lx0 * low[(size_t)y1 * w + x0] + lx1 * low[(size_t)y1 * w + x1]);
+}
+// one workgroup per patch
+__global__ void __launch_bounds__(GS_BLOCK) patch_means_kernel(const float* __restrict__ elf, int H, int W, int ps,
+                                                               float* __restrict__ means) {
+  const int nx = W / ps;
+  const int px = blockIdx.x % nx, py = blockIdx.x / nx;
+  float acc[1] = {0.f};
+  for (int k = threadIdx.x; k < ps * ps; k += GS_BLOCK) {
+    const int y = k / ps, x = k % ps;
+    acc[0] += elf[(size_t)(py * ps + y) * W + px * ps + x];
+  }
+  __shared__ float red[GS_BLOCK / 64];
+  float v = acc[0];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) means[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) / ((float)ps * (float)ps);
+}
+
+// patch DWT loss: grid.x = patch, grid.y = chunk of the patch's C*hp*hp level-1 blocks
+template <bool BWD>
+__global__ void __launch_bounds__(GS_BLOCK) patch_dwt_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                             int C, int H, int W, int ps, const uint8_t* __restrict__ mask,
+                                                             float* sums, const float* __restrict__ coef,
+                                                             float* __restrict__ grad) {
+  const int patch = blockIdx.x;
+  if (!mask[patch]) return;
+  const int nx = W / ps, hp = cdiv2(ps);
+  const int px = patch % nx, py = patch / nx;
+  const int total = C * hp * hp;
+  float s[3] = {0.f, 0.f, 0.f};
+  float cf0 = 0.f, cf1 = 0.f, cf2 = 0.f;
+  if (BWD) { cf0 = coef[0]; cf1 = coef[1]; cf2 = coef[2]; }
+  for (int o = blockIdx.y * GS_BLOCK + threadIdx.x; o < total; o += gridDim.y * GS_BLOCK) {
+    const int j = o % hp, i = (o / hp) % hp, c = o / (hp * hp);
+    const int y0 = py * ps + 2 * i, x0 = px * ps + 2 * j;
+    const bool pyb = 2 * i + 1 >= ps, pxb = 2 * j + 1 >= ps;
+    const int y1 = pyb ? y0 : y0 + 1, x1 = pxb ? x0 : x0 + 1;
+    const float* p = pred + (size_t)c * H * W;
+    const float* q = gt + (size_t)c * H * W;
+    const Bands a = haar_block(p[(size_t)y0 * W + x0], p[(size_t)y0 * W + x1], p[(size_t)y1 * W + x0], p[(size_t)y1 * W + x1]);
+    const Bands b = haar_block(q[(size_t)y0 * W + x0], q[(size_t)y0 * W + x1], q[(size_t)y1 * W + x0], q[(size_t)y1 * W + x1]);
+    if (!BWD) {
+      s[0] += fabsf(a.lh - b.lh);
+      s[1] += fabsf(a.hl - b.hl);
+      s[2] += fabsf(a.hh - b.hh);
+    } else {
+      float da, db, dc, dd;
+      haar_block_adj(0.f, cf0 * sgnf(a.lh - b.lh), cf1 * sgnf(a.hl - b.hl), cf2 * sgnf(a.hh - b.hh), da, db, dc, dd);
+      float* g = grad + (size_t)c * H * W;
+      float v00 = da, v01 = db, v10 = dc, v11 = dd;
+      if (pyb && pxb) v00 = ((da + db) + dc) + dd;
+      else if (pyb) { v00 = da + dc; v01 = db + dd; }
+      else if (pxb) { v00 = da + db; v10 = dc + dd; }
+      g[(size_t)y0 * W + x0] += v00;
+      if (!pxb) g[(size_t)y0 * W + x1] += v01;
+      if (!pyb) { g[(size_t)y1 * W + x0] += v10; if (!pxb) g[(size_t)y1 * W + x1] += v11; }
+    }
+  }
+  if (!BWD) block_sum_atomic<3>(s, sums);
+}
+
+// ------------------------------------------------------------------------------------------------ SSIM
+// 32x32 output tile per 256-thread workgroup; 42x42 input halo tile in LDS, horizontal pass to LDS,
+// vertical pass from LDS.  fused-ssim/ssim.cu:9-19:
+__constant__ float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f,
+                             0.10936068743467331f,  0.21300552785396576f,  0.26601171493530273f,
+                             0.21300552785396576f,  0.10936068743467331f,  0.036000773310661316f,
+                             0.0075987582094967365f, 0.001028380123898387f};
+#define ST 32
+#define SH (ST + 10)
+
+template <int NQ>
+__device__ __forceinline__ void ssim_conv_tile(float (*tile)[SH][SH + 1], float (*hor)[SH][ST + 1], float (&out)[4][NQ]) {
+  // horizontal: SH rows x ST cols, NQ quantities
+  for (int k = threadIdx.x; k < SH * ST; k += GS_BLOCK) {
+    const int r = k / ST, c = k % ST;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < 11; t++) v += GW[t] * tile[q][r][c + t];
+      hor[q][r][c] = v;
+    }
+  }
+  __syncthreads();
+  // vertical: each thread 4 output rows (ly = threadIdx.x/32 + 8*m), column threadIdx.x % 32
+  const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int ly = ly0 + 8 * m;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < 11; t++) v += GW[t] * hor[q][ly + t][lx];
+      out[m][q] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                            int H, int W, float C1, float C2, float* __restrict__ ssim_map,
+                                                            float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
+                                                            float* __restrict__ dm_dsigma12) {
+  __shared__ float tile[5][SH][SH + 1];
+  __shared__ float hor[5][SH][ST + 1];
+  const size_t plane = (size_t)blockIdx.z * H * W;
+  const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
+  for (int k = threadIdx.x; k < SH * SH; k += GS_BLOCK) {
+    const int r = k / SH, c = k % SH;
+    const int y = by + r - 5, x = bx + c - 5;
+    float a = 0.f, b = 0.f;
+    if (x >= 0 && x < W && y >= 0 && y < H) {
+      a = img1[plane + (size_t)y * W + x];
+      b = img2[plane + (size_t)y * W + x];
+    }
+    tile[0][r][c] = a;
+    tile[1][r][c] = a * a;
+    tile[2][r][c] = b;
+    tile[3][r][c] = b * b;
+    tile[4][r][c] = a * b;
+  }
+  __syncthreads();
+  float out[4][5];
+  ssim_conv_tile<5>(tile, hor, out);
+  const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int x = bx + lx, y = by + ly0 + 8 * m;
+    if (x >= W || y >= H) continue;
+    const float mu1 = out[m][0], mu2 = out[m][2];
+    const float sigma1_sq = out[m][1] - mu1 * mu1;
+    const float sigma2_sq = out[m][3] - mu2 * mu2;
+    const float sigma12 = out[m][4] - mu1 * mu2;
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+    const float Cc = (2.0f * mu1_mu2 + C1);
+    const float D = (2.0f * sigma12 + C2);
+    const float A = (mu1_sq + mu2_sq + C1);
+    const float B = (sigma1_sq + sigma2_sq + C2);
+    const size_t o = plane + (size_t)y * W + x;
+    ssim_map[o] = (Cc * D) / (A * B);
+    if (dm_dmu1) {
+      dm_dmu1[o] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * Cc) / (A * B) - (mu1 * 2.0f * Cc * D) / (A * A * B) +
+                    (mu1 * 2.0f * Cc * D) / (A * B * B));
+      dm_dsigma1_sq[o] = ((-Cc * D) / (A * B * B));
+      dm_dsigma12[o] = ((2 * Cc) / (A * B));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                            int H, int W, const float* __restrict__ dL_dmap,
+                                                            const float* __restrict__ dm_dmu1,
+                                                            const float* __restrict__ dm_dsigma1_sq,
+                                                            const float* __restrict__ dm_dsigma12,
+                                                            float* __restrict__ dL_dimg1) {
+  __shared__ float tile[3][SH][SH + 1];
+  __shared__ float hor[3][SH][ST + 1];
+  const size_t plane = (size_t)blockIdx.z * H * W;
+  const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
+  for (int k = threadIdx.x; k < SH * SH; k += GS_BLOCK) {
+    const int r = k / SH, c = k % SH;
+    const int y = by + r - 5, x = bx + c - 5;
+    float g = 0.f, a = 0.f, b = 0.f, d = 0.f;
+    if (x >= 0 && x < W && y >= 0 && y < H) {
+      const size_t o = plane + (size_t)y * W + x;
+      g = dL_dmap[o];
+      a = dm_dmu1[o];
+      b = dm_dsigma1_sq[o];
+      d = dm_dsigma12[o];
+    }
+    tile[0][r][c] = a * g;
+    tile[1][r][c] = b * g;
+    tile[2][r][c] = d * g;
+  }
+  __syncthreads();
+  float out[4][3];
+  ssim_conv_tile<3>(tile, hor, out);
+  const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int x = bx + lx, y = by + ly0 + 8 * m;
+    if (x >= W || y >= H) continue;
+    const size_t o = plane + (size_t)y * W + x;
+    float dL = 0.0f;
+    dL += out[m][0];
+    dL += img1[o] * 2.0f * out[m][1];
+    dL += img2[o] * out[m][2];
+    dL_dimg1[o] = dL;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ entry points
+static inline int nblocks(int64_t n, int per = GS_BLOCK, int cap = 8192) {
+  int64_t b = (n + per - 1) / per;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+extern "C" {
+
+int gs_l1_fwd(const float* a, const float* b, int64_t n, float* sum, void* stream) {
+  if (!a || !b || !sum) return GS_E_NULL;
+  if (n <= 0) return GS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return GS_E_UNSUPPORTED;  // torch allocations are 256-B aligned
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblocks(n / 4 + 1, GS_BLOCK, 2048)), dim3(GS_BLOCK), 0, s, a, b, n, sum);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_l1_bwd(const float* a, const float* b, int64_t n, float coef, float* g, int32_t accumulate, void* stream) {
+  if (!a || !b || !g) return GS_E_NULL;
+  if (n <= 0) return GS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblocks(n)), dim3(GS_BLOCK), 0, s, a, b, n, coef, g, accumulate);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_dwt_haar_fwd(const float* x, int32_t NC, int32_t H, int32_t W, float* ll, float* lh, float* hl, float* hh,
+                    void* stream) {
+  if (!x) return GS_E_NULL;
+  if (NC <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)NC * ((H + 1) / 2) * ((W + 1) / 2);
+  hipLaunchKernelGGL(dwt_fwd_kernel, dim3(nblocks(total)), dim3(GS_BLOCK), 0, s, x, NC, H, W, ll, lh, hl, hh);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_dwt_haar_bwd(const float* dll, const float* dlh, const float* dhl, const float* dhh, int32_t NC, int32_t H,
+                    int32_t W, float* dx, void* stream) {
+  if (!dx) return GS_E_NULL;
+  if (NC <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)NC * ((H + 1) / 2) * ((W + 1) / 2);
+  hipLaunchKernelGGL(dwt_bwd_kernel, dim3(nblocks(total)), dim3(GS_BLOCK), 0, s, dll, dlh, dhl, dhh, NC, H, W, dx);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_dwt2_l1_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* band_sums, void* stream) {
+  if (!pred || !gt || !band_sums) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
+  hipLaunchKernelGGL(dwt2_l1_fwd_kernel, dim3(nblocks((int64_t)C * h2 * w2, GS_BLOCK, 4096)), dim3(GS_BLOCK), 0, s, pred, gt,
+                     C, H, W, band_sums);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_dwt2_l1_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* coef_dev,
+                   float* grad_pred, int32_t accumulate, void* stream) {
+  if (!pred || !gt || !coef_dev || !grad_pred) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
+  hipLaunchKernelGGL(dwt2_l1_bwd_kernel, dim3(nblocks((int64_t)C * h2 * w2)), dim3(GS_BLOCK), 0, s, pred, gt, C, H, W,
+                     coef_dev, grad_pred, accumulate);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_elf_map(const float* img, int32_t C, int32_t H, int32_t W, float* elf_low, float* elf, void* stream) {
+  if (!img || !elf || !elf_low) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int h = (H + 1) / 2, w = (W + 1) / 2;
+  hipLaunchKernelGGL(elf_low_kernel, dim3((h * w + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, img, C, H, W, elf_low);
+  hipLaunchKernelGGL(bilinear_up_kernel, dim3((H * W + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, elf_low, h, w, H, W, elf);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_patch_means(const float* elf, int32_t H, int32_t W, int32_t ps, float* means, void* stream) {
+  if (!elf || !means) return GS_E_NULL;
+  if (ps <= 0 || H < ps || W < ps) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(patch_means_kernel, dim3((H / ps) * (W / ps)), dim3(GS_BLOCK), 0, s, elf, H, W, ps, means);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_patch_dwt_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps, const uint8_t* mask,
+                     float* sums, void* stream) {
+  if (!pred || !gt || !mask || !sums) return GS_E_NULL;
+  if (ps <= 0 || H < ps || W < ps || C <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int hp = (ps + 1) / 2;
+  const int chunks = nblocks((int64_t)C * hp * hp, GS_BLOCK * 4, 64);
+  hipLaunchKernelGGL(patch_dwt_kernel<false>, dim3((H / ps) * (W / ps), chunks), dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, ps,
+                     mask, sums, (const float*)nullptr, (float*)nullptr);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_patch_dwt_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps, const uint8_t* mask,
+                     const float* coef_dev, float* grad_pred, int32_t accumulate, void* stream) {
+  if (!pred || !gt || !mask || !coef_dev || !grad_pred) return GS_E_NULL;
+  if (ps <= 0 || H < ps || W < ps || C <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) GS_HIP_CHECK(hipMemsetAsync(grad_pred, 0, sizeof(float) * (size_t)C * H * W, s));
+  const int hp = (ps + 1) / 2;
+  const int chunks = nblocks((int64_t)C * hp * hp, GS_BLOCK * 4, 64);
+  hipLaunchKernelGGL(patch_dwt_kernel<true>, dim3((H / ps) * (W / ps), chunks), dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, ps,
+                     mask, (float*)nullptr, coef_dev, grad_pred);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_ssim_fwd(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1, float C2,
+                float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream) {
+  if (!img1 || !img2 || !ssim_map) return GS_E_NULL;
+  if (dm_dmu1 && (!dm_dsigma1_sq || !dm_dsigma12)) return GS_E_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float, float,
+                const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                float* dL_dimg1, void* stream) {
+  if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return GS_E_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+}

@@ -1,0 +1,244 @@
+// gs_preprocess.hip - forward per-Gaussian stage (HBM-bound streaming kernel).
+// Compiled with -ffp-contract=off: see gs_math.h.
+//
+// Replaces preprocessCUDA<3> (forward.cu:151-269) + checkFrustum (rasterizer_impl.cu:54-66) and
+// produces the per-block partial sums for the tiles_touched prefix sum (cub InclusiveSum,
+// rasterizer_impl.cu:280).  One thread per Gaussian, 256 per workgroup; each Gaussian costs
+// 236 B of reads (12 xyz + 12 scale + 16 quat + 4 opacity + 192 SH) and 96 B of writes
+// (64-B splat record, 24 B cov3D, 4 B tiles, 4 B radii).
+#include "gs_common.h"
+#include "gs_math.h"
+
+// forward.cu:20-71.  sh points at this Gaussian's coefficients as 3*M floats.
+template <typename SH>
+GS_DEV V3 color_from_sh(int deg, V3 pos, V3 campos, const SH& sh, uint32_t& clamped) {
+  V3 dir = pos - campos;
+  dir = dir / length3(dir);
+  V3 result = SH_C0 * sh(0);
+  if (deg > 0) {
+    float x = dir.x, y = dir.y, z = dir.z;
+    result = result - SH_C1 * y * sh(1) + SH_C1 * z * sh(2) - SH_C1 * x * sh(3);
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z;
+      float xy = x * y, yz = y * z, xz = x * z;
+      result = result + SH_C2_0 * xy * sh(4) + SH_C2_1 * yz * sh(5) + SH_C2_2 * (2.0f * zz - xx - yy) * sh(6) +
+               SH_C2_3 * xz * sh(7) + SH_C2_4 * (xx - yy) * sh(8);
+      if (deg > 2) {
+        result = result + SH_C3_0 * y * (3.0f * xx - yy) * sh(9) + SH_C3_1 * xy * z * sh(10) +
+                 SH_C3_2 * y * (4.0f * zz - xx - yy) * sh(11) + SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh(12) +
+                 SH_C3_4 * x * (4.0f * zz - xx - yy) * sh(13) + SH_C3_5 * z * (xx - yy) * sh(14) +
+                 SH_C3_6 * x * (xx - 3.0f * yy) * sh(15);
+      }
+    }
+  }
+  result.x += 0.5f;
+  result.y += 0.5f;
+  result.z += 0.5f;
+  clamped = (result.x < 0 ? 1u : 0u) | (result.y < 0 ? 2u : 0u) | (result.z < 0 ? 4u : 0u);
+  return {fmaxf(result.x, 0.0f), fmaxf(result.y, 0.0f), fmaxf(result.z, 0.0f)};
+}
+
+struct ShRegs {  // coefficients held in registers, loaded as float4 (M == 16 layout, 192 B per Gaussian)
+  float f[48];
+  __device__ __forceinline__ V3 operator()(int k) const { return {f[3 * k], f[3 * k + 1], f[3 * k + 2]}; }
+};
+struct ShMem {  // generic M: scalar loads
+  const float* p;
+  __device__ __forceinline__ V3 operator()(int k) const { return {p[3 * k], p[3 * k + 1], p[3 * k + 2]}; }
+};
+
+__global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs a, GeomView g) {
+  const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
+  uint32_t tiles = 0;
+  if (idx < a.P) {
+    Splat sp;
+    sp.x = sp.y = sp.depth = sp.invdepth = 0.f;
+    sp.cxx = sp.cxy = sp.cyy = sp.opacity = 0.f;
+    sp.r = sp.g = sp.b = 0.f;
+    sp.radius = 0;
+    sp.rect_min = sp.rect_max = sp.tiles = sp.clamped = 0;
+    float cov3D[6] = {0, 0, 0, 0, 0, 0};
+    bool write_cov = false;
+    do {
+      V3 p_orig = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+      // in_frustum, auxiliary.h:151-176
+      V3 p_view = xform4x3(p_orig, a.viewmatrix);
+      if (p_view.z <= 0.2f) break;
+      V4 p_hom = xform4x4(p_orig, a.projmatrix);
+      float p_w = 1.0f / (p_hom.w + 0.0000001f);
+      V3 p_proj = {p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w};
+
+      if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[(size_t)idx * 6 + k];
+      } else {
+        // computeCov3D, forward.cu:114-148
+        V3 sc = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+        const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
+        V4 rq = {q4.x, q4.y, q4.z, q4.w};
+        M3 S = mat3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
+        S.c[0][0] = a.scale_modifier * sc.x;
+        S.c[1][1] = a.scale_modifier * sc.y;
+        S.c[2][2] = a.scale_modifier * sc.z;
+        M3 R = quat_to_R(rq);
+        M3 Mm = mul3(S, R);
+        M3 Sigma = mul3(transpose3(Mm), Mm);
+        cov3D[0] = Sigma.c[0][0];
+        cov3D[1] = Sigma.c[0][1];
+        cov3D[2] = Sigma.c[0][2];
+        cov3D[3] = Sigma.c[1][1];
+        cov3D[4] = Sigma.c[1][2];
+        cov3D[5] = Sigma.c[2][2];
+        write_cov = true;
+      }
+      // computeCov2D, forward.cu:74-109
+      Cov2DInter ci;
+      cov2d_common(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.viewmatrix, ci);
+      M3 cv = mul3(mul3(transpose3(ci.T), transpose3(ci.Vrk)), ci.T);
+      V3 cov = {cv.c[0][0], cv.c[0][1], cv.c[1][1]};
+
+      const float h_var = 0.3f;
+      const float det_cov = cov.x * cov.z - cov.y * cov.y;
+      cov.x += h_var;
+      cov.z += h_var;
+      const float det_cov_plus_h_cov = cov.x * cov.z - cov.y * cov.y;
+      float h_convolution_scaling = 1.0f;
+      if (a.antialiasing) h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
+      const float det = det_cov_plus_h_cov;
+      if (det == 0.0f) break;
+      float det_inv = 1.f / det;
+      V3 conic = {cov.z * det_inv, -cov.y * det_inv, cov.x * det_inv};
+      float mid = 0.5f * (cov.x + cov.z);
+      float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+      float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+      float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+      float pix_x = ndc2pix(p_proj.x, a.W), pix_y = ndc2pix(p_proj.y, a.H);
+      uint32_t minx, miny, maxx, maxy;
+      const int radius_i = f2i_sat(my_radius);
+      get_rect(pix_x, pix_y, radius_i, a.grid_x, a.grid_y, minx, miny, maxx, maxy);
+      if ((maxx - minx) * (maxy - miny) == 0) break;
+
+      if (a.colors_precomp == nullptr) {
+        V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
+        V3 rgb;
+        uint32_t cl = 0;
+        if (a.M == 16) {
+          ShRegs sh;
+          const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
+          const int nvec = a.D == 0 ? 1 : (a.D == 1 ? 3 : (a.D == 2 ? 7 : 12));
+#pragma unroll
+          for (int k = 0; k < 12; k++) {
+            if (k < nvec) {
+              float4 v = src[k];
+              sh.f[4 * k] = v.x; sh.f[4 * k + 1] = v.y; sh.f[4 * k + 2] = v.z; sh.f[4 * k + 3] = v.w;
+            } else {
+              sh.f[4 * k] = sh.f[4 * k + 1] = sh.f[4 * k + 2] = sh.f[4 * k + 3] = 0.f;
+            }
+          }
+          rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
+        } else {
+          ShMem sh{a.shs + (size_t)idx * a.M * 3};
+          rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
+        }
+        sp.r = rgb.x; sp.g = rgb.y; sp.b = rgb.z;
+        sp.clamped = cl;
+      } else {
+        sp.r = a.colors_precomp[3 * idx];
+        sp.g = a.colors_precomp[3 * idx + 1];
+        sp.b = a.colors_precomp[3 * idx + 2];
+      }
+      sp.depth = p_view.z;
+      sp.invdepth = 1 / p_view.z;
+      sp.radius = radius_i;
+      sp.x = pix_x;
+      sp.y = pix_y;
+      sp.cxx = conic.x; sp.cxy = conic.y; sp.cyy = conic.z;
+      sp.opacity = a.opacities[idx] * h_convolution_scaling;
+      sp.rect_min = minx | (miny << 16);
+      sp.rect_max = maxx | (maxy << 16);
+      tiles = (maxy - miny) * (maxx - minx);
+      sp.tiles = tiles;
+    } while (false);
+
+    float4* dst = reinterpret_cast<float4*>(&g.splat[idx]);
+    const float4* srcv = reinterpret_cast<const float4*>(&sp);
+    dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2]; dst[3] = srcv[3];
+    if (a.cov3D_precomp == nullptr) {
+      float2* cd = reinterpret_cast<float2*>(g.cov3D + (size_t)idx * 6);
+      if (!write_cov) { cov3D[0] = cov3D[1] = cov3D[2] = cov3D[3] = cov3D[4] = cov3D[5] = 0.f; }
+      cd[0] = make_float2(cov3D[0], cov3D[1]);
+      cd[1] = make_float2(cov3D[2], cov3D[3]);
+      cd[2] = make_float2(cov3D[4], cov3D[5]);
+    }
+    g.tiles_touched[idx] = tiles;
+    a.radii[idx] = sp.radius;
+  }
+  // per-workgroup partial sum of tiles_touched for the prefix sum
+  __shared__ uint32_t red[GS_BLOCK / 64];
+  uint32_t v = tiles;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) g.block_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Exclusive scan of the per-workgroup sums, in place, one workgroup (nb <= 2^22); the grand total
+// (num_rendered) goes to the header and to block_sums[nb].
+__global__ void __launch_bounds__(1024) scan_block_sums_kernel(GeomView g, int nb) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    int i = base + tid;
+    uint32_t v = (i < nb) ? g.block_sums[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; w++) woff += wsum[w];
+    uint32_t carry = carry_s;
+    if (i < nb) g.block_sums[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    g.block_sums[nb] = carry_s;
+    g.hdr->num_rendered = carry_s;
+    g.hdr->overflow = 0;
+  }
+}
+
+// rasterizer_impl.cu:54-66
+__global__ void __launch_bounds__(GS_BLOCK) mark_visible_kernel(int P, const float* means3D, const float* vm,
+                                                                uint8_t* present) {
+  const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
+  if (idx >= P) return;
+  V3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+  V3 pv = xform4x3(p, vm);
+  present[idx] = !(pv.z <= 0.2f);
+}
+
+int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_t s) {
+  const int nb = (a.P + GS_BLOCK - 1) / GS_BLOCK;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, a, g);
+  return 0;
+}
+int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s) {
+  const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, g, nb);
+  return 0;
+}
+int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((P + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, P, means3D,
+                     viewmatrix, present);
+  return 0;
+}

@@ -47,7 +47,7 @@ def gen_sh():
     means = (torch.rand((P, 3), generator=g) * 2.6 - 1.3)
     campos = torch.tensor([2.5, -3.0, 1.2])
     sh = torch.randn((P, 16, 3), generator=g) * 0.6
-    sh[:, 0, :] -= 0.3  # make a good share of channels clamp at 0
+    sh[:, 0, :] = sh[:, 0, :] * 3.0 - 0.9  # make a good share of channels clamp at 0
     w = torch.randn((P, 3), generator=g)
     out["means"], out["campos"], out["sh"], out["w"] = means.numpy(), campos.numpy(), sh.numpy(), w.numpy()
     for deg in range(4):
