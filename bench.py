@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py - train-step views/s (fwd+bwd) of the MI355X rasterizer + LGDWT loss path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1|tiny]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+              --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one camera per GPU: activations -> GaussianRasterizer forward -> clamp -> LGDWT loss
+(0.8 L1 + 0.2 (1-SSIM) + running-mean-scaled global 2-level DWT + 0.1 patch DWT) -> backward to the
+six parameter tensors -> (N>1: one RCCL all-reduce of the 59-float/Gaussian gradient buffer + the
+densification statistics) -> Adam.  Synthetic "trained-like" Gaussians, NeRF-synthetic-
+like orbit cameras, inputs resident in HBM before the timed region.  Cameras are sharded over ranks
+and per-GPU work is fixed, so scaling is "weak".
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     for the dominant kernel: algorithmic bytes per launch / mean launch duration measured
+               with HIP events on the launch stream (library profiler, include/gsplat.h gs_profile_*)
+  cpu_baseline the CPU oracle ("port") timed on this box's host cores on ONE view of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "sparse-view-3dgs-pack_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # name: (P, W, H, dwt, patch, description)
+    "c3": (1_000_000, 1920, 1080, True, True, "BASELINE configs[2]: 1M Gaussians, 1080p, global+patch DWT"),
+    "c2": (500_000, 800, 800, True, False, "BASELINE configs[1]: 500k Gaussians, 800x800, global DWT"),
+    "c1": (10_000, 400, 400, False, False, "BASELINE configs[0]: 10k Gaussians, 400x400, DWT off"),
+    "tiny": (2_000, 256, 160, True, True, "plumbing check"),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def stage_bytes(P, R, N):
+    """Algorithmic (compulsory) bytes per launch of each rasterizer stage, SURVEY.md 8(d):
+    per view 902 P + 172 R + 48 N split over the stages that move them."""
+    return {
+        "preprocess_fwd": 311 * P, "scan": 8 * P, "duplicate": 20 * P + 12 * R, "sort": 24 * R,
+        "tile_ranges": 8 * R, "render_fwd": 44 * R + 24 * N, "render_bwd": 84 * R + 24 * N,
+        "preprocess_bwd": 563 * P,
+    }
+
+
+def build_workload(cfg, device, rank, world, seed=0):
+    import diff_gaussian_rasterization as dgr
+    import lgdwt_loss
+    from gsplat_amd import synthetic
+    from gsplat_amd.trainer import GaussianModelLite, Trainer, camera_to, render
+    from simple_knn._C import distCUDA2
+
+    P, W, H, dwt, patch, _ = CONFIGS[cfg]
+    knn = lambda x: distCUDA2(x.to(device)).cpu()  # noqa: E731
+    scene = synthetic.trained_like(P, seed=seed, knn=knn)
+    cams = [camera_to(c, device) for c in synthetic.orbit_cameras(W, H)]
+    bg = torch.zeros(3, device=device)
+    # ground truth: renders of a differently seeded scene, quantised to 8 bit like PILtoTorch
+    gt_scene = synthetic.trained_like(P, seed=seed + 1, knn=knn)
+    gt_model = GaussianModelLite(gt_scene, device)
+    # every rank only ever touches cameras rank, rank+world, ...: render just those
+    needed = sorted({(k * world + rank) % len(cams) for k in range(len(cams))})
+    gts = [None] * len(cams)
+    with torch.no_grad():
+        for ci in needed:
+            img = render(cams[ci], gt_model, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg)["render"]
+            gts[ci] = (torch.round(img * 255.0) / 255.0).contiguous()
+    del gt_model
+    model = GaussianModelLite(scene, device)
+    crit = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch)
+    masks = None
+    if patch:  # ELF / patch selection depends on the ground truth only: cached per camera
+        masks = [None if g is None else crit.elf_mask(g) for g in gts]
+    tr = Trainer(model, cams, gts, crit, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg, rank, world,
+                 optimizer_step=True, masks=masks)
+    return tr, scene, cams, gts
+
+
+def host_cpu_share():
+    """CPUs this process may really use: min(affinity mask, cgroup quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("GS_CPU_THREADS", n))))
+
+
+def cpu_baseline(cfg, scene, cam, gt, log):
+    """The CPU oracle (C++ restatement of the reference kernels, OpenMP) on ONE view of the same
+    workload: forward + loss + backward on the host cores.  Reported, never the thing measured above."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from gsplat_amd.losses import LGDWTCriterion, LossOps
+    from gsplat_amd.trainer import GaussianModelLite, camera_to, render
+
+    P, W, H, dwt, patch, _ = CONFIGS[cfg]
+    orc = oracle_lib.get()
+    cpu = torch.device("cpu")
+    model = GaussianModelLite({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in scene.items()}, cpu)
+    crit = LGDWTCriterion(LossOps(orc.api), dwt_enable=dwt, patch_dwt_enable=patch)
+    cam = camera_to(cam, cpu)
+    gt = gt.cpu()
+    cores = host_cpu_share()
+    orc.lib.gso_set_num_threads.restype = int
+    cores = int(orc.lib.gso_set_num_threads(cores))
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    pkg = render(cam, model, orc.Rasterizer, orc.Settings, torch.zeros(3), filter_as_indices=False)
+    loss, _ = crit(pkg["render"], gt)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    log("cpu_baseline: 1 view in %.2f s on %d threads (loss %.5f)" % (dt, cores, float(loss.detach())))
+    return {"value": 1.0 / dt, "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": "1 view (fwd + loss + bwd, no Adam) of the same %s workload through the CPU oracle "
+                      "(oracle/libgs_oracle.so, OpenMP over Gaussians / tiles), no warm-up" % cfg}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def log(*a):
+        if rank == 0:
+            print("[bench]", *a, file=sys.stderr, flush=True)
+
+    from gsplat_amd._lib import hip_api
+    from gsplat_amd.capi import read_profile
+    api = hip_api()
+    P, W, H, dwt, patch, desc = CONFIGS[args.config]
+    t_setup = time.perf_counter()
+    tr, scene, cams, gts = build_workload(args.config, device, rank, world)
+    torch.cuda.synchronize()
+    log("workload %s built in %.1f s" % (args.config, time.perf_counter() - t_setup))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k = 0
+    for _ in range(args.warmup):
+        tr.step(k)
+        k += 1
+    barrier()
+    if not args.no_stage_timers:
+        api.call("profile_reset")
+        api.call("profile_enable", 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(k)
+        k += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = {}
+    if not args.no_stage_timers:
+        api.call("profile_enable", 0)
+        prof = read_profile(api)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+
+    if rank == 0:
+        # instance count of the timed cameras (R drives the cost, not P)
+        Rs = []
+        import diff_gaussian_rasterization as dgr  # noqa: F401
+        from gsplat_amd import hip_backend
+        R_last = int(hip_backend()._pinned[0]) if hip_backend()._pinned is not None else 0
+        N = W * H
+        views = args.steps * world
+        value = views / dt
+        sb = stage_bytes(P, R_last, N)
+        stages = {}
+        if "sort_depth" in prof and "sort" in prof:  # the two halves of the (tile|depth) sort: one SURVEY stage
+            prof["sort"] = (prof["sort"][0] + prof.pop("sort_depth")[0], prof["sort"][1])
+        for name, (ms, cnt) in prof.items():
+            e = {"ms_per_launch": ms / cnt, "launches": cnt}
+            if name in sb:
+                e["algorithmic_GB"] = sb[name] / 1e9
+                e["GBps"] = sb[name] / 1e9 / (ms / cnt / 1e3)
+            stages[name] = e
+        roofline = None
+        if stages:
+            dom = max((n for n in stages if n in sb), key=lambda n: stages[n]["ms_per_launch"])
+            ach = stages[dom]["GBps"]
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": sb[dom], "ms_per_launch": stages[dom]["ms_per_launch"],
+                        "note": "blend kernels are VALU/LDS-bound by construction (SURVEY 8d); "
+                                "step-level algorithmic bytes %.3f GB/view -> %.1f GB/s" % (
+                                    (902 * P + 172 * R_last + 84 * N) / 1e9,
+                                    (902 * P + 172 * R_last + 84 * N) / 1e9 * value / world)}
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    roofline["traffic"] = json.load(open(tf)).get(dom)
+                except Exception:
+                    pass
+        out = {
+            "metric": "train-step views/s (fwd+bwd) @1M Gaussians 1080p" if args.config == "c3"
+                      else "train-step views/s (fwd+bwd) [%s]" % args.config,
+            "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "gaussians": P, "image": "%dx%d" % (W, H), "sh_degree": 3,
+                       "scene": "trained-like (SURVEY 8d), seed 0", "cameras_per_step": world,
+                       "num_rendered_last_view": R_last, "loss": "L1+SSIM" + ("+DWT2" if dwt else "") +
+                       ("+patchDWT" if patch else ""), "optimizer": "Adam (torch, eps 1e-15)",
+                       "parallelism": "camera-sharded dp%d, one all-reduce of 59 f32/Gaussian" % world},
+            "roofline": roofline,
+            "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ci = tr.camera_index(k - 1)
+            out["cpu_baseline"] = cpu_baseline(args.config, scene, cams[ci], gts[ci], log)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -227,6 +227,17 @@ int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
                 const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                 void* stream);
 
+/* ---- optional per-stage timing (HIP events recorded on the caller's stream around every kernel
+ * group).  Off by default.  bench.py enables it over the timed region to get each kernel's average
+ * launch duration on the stream it is launched on.  (No reference counterpart: the reference only
+ * brackets whole iterations with a torch.cuda.Event pair, LGDWT-GS/train.py:65-66,97,220.) ---- */
+int gs_profile_enable(int32_t on);
+int gs_profile_reset(void);
+int gs_profile_stage_count(void);
+const char* gs_profile_stage_name(int32_t stage);
+/* Waits for every recorded event, then ms[i] / counts[i] = accumulated milliseconds / launches of stage i. */
+int gs_profile_read(double* ms, int64_t* counts, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

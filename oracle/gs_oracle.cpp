@@ -1037,4 +1037,15 @@ int gso_test_sh_bwd(int32_t P, int32_t deg, int32_t M, const float* means, const
   return GS_OK;
 }
 
+/* thread control for the cpu_baseline leg of bench.py ("cores" = threads actually used) */
+int gso_set_num_threads(int32_t n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
 } /* extern "C" */

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "gs_common.h"
+#include "gs_prof.h"
 
 static int check_args(const GsView* v, const GsGaussians* g) {
   if (!v || !g) return GS_E_NULL;
@@ -85,9 +86,15 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   a.radii = radii;
   tile_grid(v, a.grid_x, a.grid_y);
   a.antialiasing = v->antialiasing;
-  launch_preprocess_fwd(a, gv, s);
+  {
+    GS_PROF(ST_PREPROCESS_FWD, s);
+    launch_preprocess_fwd(a, gv, s);
+  }
   GS_LAUNCH_CHECK(s, v->debug);
-  launch_scan_block_sums(gv, P, s);
+  {
+    GS_PROF(ST_SCAN, s);
+    launch_scan_block_sums(gv, P, s);
+  }
   GS_LAUNCH_CHECK(s, v->debug);
   if (num_rendered_host)
     GS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, &gv.hdr->num_rendered, 4, hipMemcpyDeviceToHost, s));
@@ -117,26 +124,43 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
   if (cap > 0xFFFFFFFFll) return GS_E_UNSUPPORTED;
   GeomView gv = geom_view(sc->geom, (size_t)P);
   ImgView iv = img_view(sc->img, N, T);
-  BinView bv = bin_view(sc->binning, (size_t)cap);
+  SortBufs bv = sort_view(sc->binning, (size_t)cap);
 
   launch_bin_prepare(gv, cap, s);
   GS_LAUNCH_CHECK(s, v->debug);
   if (cap > 0) {
-    // the unsorted list goes into the ping-pong half from which an LSD sort of `passes` passes
-    // ends in half 0, so that backward / exports always find the sorted list in half 0
+    {  // 1. depth order of the P Gaussians: 4 passes, starts in half 0 (keys written by preprocess), ends in half 0
+      GS_PROF(ST_SORT_DEPTH, s);
+      rc = launch_radix_sort(gv.gsort, &gv.hdr->P, P, 32, 0, /*iota_values=*/true, s, v->debug);
+      if (rc) return rc;
+    }
+    // 2. instances in depth order; 3. stable partition by tile id.  The unsorted list goes into the ping-pong
+    // half from which `passes` passes end in half 0, so backward / exports always find the result in half 0.
     const int bit = (int)gs_higher_msb((uint32_t)(gx * gy));
-    const int passes = (32 + bit + RS_BITS - 1) / RS_BITS;
+    const int passes = (bit + RS_BITS - 1) / RS_BITS;
     const int start = passes & 1;
-    launch_duplicate(gv, P, gx, bv, start, s);
-    GS_LAUNCH_CHECK(s, v->debug);
-    rc = launch_radix_sort(bv, &gv.hdr->sort_n, cap, 32 + bit, start, s, v->debug);
-    if (rc) return rc;
+    {
+      GS_PROF(ST_DUPLICATE, s);
+      rc = launch_emit_instances(gv, P, gx, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
+      if (rc) return rc;
+    }
+    {
+      GS_PROF(ST_SORT, s);
+      rc = launch_radix_sort(bv, &gv.hdr->sort_n, cap, bit, start, /*iota_values=*/false, s, v->debug);
+      if (rc) return rc;
+    }
   }
-  rc = launch_tile_ranges(bv.keys[0], &gv.hdr->sort_n, cap, iv.ranges, (int)T, s);
+  {
+    GS_PROF(ST_RANGES, s);
+    rc = launch_tile_ranges(bv.keys[0], &gv.hdr->sort_n, cap, iv.ranges, (int)T, s);
+  }
   if (rc) return rc;
   GS_LAUNCH_CHECK(s, v->debug);
-  launch_render_fwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
-                    out_invdepth, s);
+  {
+    GS_PROF(ST_RENDER_FWD, s);
+    launch_render_fwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
+                      out_invdepth, s);
+  }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
 }
@@ -159,12 +183,18 @@ int gs_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, con
   const size_t T = (size_t)gx * gy, N = (size_t)W * H;
   GeomView gv = geom_view(sc->geom, (size_t)P);
   ImgView iv = img_view(sc->img, N, T);
-  BinView bv = bin_view(sc->binning, (size_t)sc->binning_capacity);
+  SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
   float* rows = (float*)workspace;
-  GS_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)P * GR_STRIDE * sizeof(float), s));
+  {
+    GS_PROF(ST_BWD_MEMSET, s);
+    GS_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)P * GR_STRIDE * sizeof(float), s));
+  }
   if (num_rendered > 0) {
-    launch_render_bwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
-                      dL_dinvdepth, rows, s);
+    {
+      GS_PROF(ST_RENDER_BWD, s);
+      launch_render_bwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
+                        dL_dinvdepth, rows, s);
+    }
     GS_LAUNCH_CHECK(s, v->debug);
   }
   PreprocessBwdArgs a;
@@ -192,7 +222,10 @@ int gs_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, con
   a.grad_rows = rows;
   a.splat = gv.splat;
   a.out = *grads;
-  launch_preprocess_bwd(a, s);
+  {
+    GS_PROF(ST_PREPROCESS_BWD, s);
+    launch_preprocess_bwd(a, s);
+  }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
 }
@@ -202,6 +235,7 @@ int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, co
   if (P < 0) return GS_E_SHAPE;
   if (P == 0) return GS_OK;
   if (!means3D || !viewmatrix || !present) return GS_E_NULL;
+  (void)hipGetLastError();
   launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
   GS_LAUNCH_CHECK((hipStream_t)stream, 0);
   return GS_OK;
@@ -237,7 +271,24 @@ __global__ void export_geom_kernel(GeomView g, int P, float* depths, float* mean
   if (cov3D)
     for (int k = 0; k < 6; k++) cov3D[6 * i + k] = vis ? g.cov3D[6 * (size_t)i + k] : 0.f;
   if (tiles_touched) tiles_touched[i] = g.tiles_touched[i];
-  if (point_offsets) point_offsets[i] = g.point_offsets[i];
+}
+// inclusive scan of tiles_touched in index order (what the reference keeps as point_offsets): the product
+// path never materialises it (instances are emitted in depth order), so the export recomputes it
+__global__ void export_offsets_kernel(GeomView g, int P, uint32_t* point_offsets) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
+  if (b >= nb) return;
+  uint32_t run = g.block_sums[b];
+  for (int i = b * GS_BLOCK; i < min(P, (b + 1) * GS_BLOCK); i++) {
+    run += g.tiles_touched[i];
+    point_offsets[i] = run;
+  }
+}
+__global__ void export_keys_kernel(const uint32_t* tkeys, const uint32_t* point_list, const Splat* splat, int64_t R,
+                                   uint64_t* keys_sorted) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  keys_sorted[i] = ((uint64_t)tkeys[i] << 32) | (uint64_t)__float_as_uint(splat[point_list[i]].depth);
 }
 
 int gs_export_geom(const GsScratch* sc, int32_t P, float* depths, float* means2D, float* cov3D, float* conic_opacity,
@@ -245,8 +296,13 @@ int gs_export_geom(const GsScratch* sc, int32_t P, float* depths, float* means2D
   if (!sc || !sc->geom) return GS_E_NULL;
   if (P <= 0) return GS_OK;
   GeomView gv = geom_view(sc->geom, (size_t)P);
+  (void)hipGetLastError();
   hipLaunchKernelGGL(export_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, gv, P, depths,
                      means2D, cov3D, conic_opacity, rgb, clamped, tiles_touched, point_offsets);
+  if (point_offsets) {
+    const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
+    hipLaunchKernelGGL(export_offsets_kernel, dim3((nb + 63) / 64), dim3(64), 0, (hipStream_t)stream, gv, P, point_offsets);
+  }
   GS_LAUNCH_CHECK((hipStream_t)stream, 0);
   return GS_OK;
 }
@@ -269,8 +325,18 @@ int gs_export_binning(const GsScratch* sc, int64_t R, uint64_t* keys_sorted, uin
   if (R <= 0) return GS_OK;
   if (!sc->binning) return GS_E_NULL;
   hipStream_t s = (hipStream_t)stream;
-  BinView bv = bin_view(sc->binning, (size_t)sc->binning_capacity);
-  if (keys_sorted) GS_HIP_CHECK(hipMemcpyAsync(keys_sorted, bv.keys[0], 8 * (size_t)R, hipMemcpyDeviceToDevice, s));
+  if (!sc->geom) return GS_E_NULL;
+  SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
+  if (keys_sorted) {
+    // the product keeps (tile id) and (depth bits) in separate arrays; rebuild the reference's 64-bit key
+    const GeomHeader* hdr = (const GeomHeader*)sc->geom;
+    const Splat* splat = (const Splat*)((const char*)sc->geom + sizeof(GeomHeader));
+    (void)hdr;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, bv.keys[0], bv.vals[0], splat,
+                       R, keys_sorted);
+    GS_LAUNCH_CHECK(s, 0);
+  }
   if (point_list) GS_HIP_CHECK(hipMemcpyAsync(point_list, bv.vals[0], 4 * (size_t)R, hipMemcpyDeviceToDevice, s));
   return GS_OK;
 }

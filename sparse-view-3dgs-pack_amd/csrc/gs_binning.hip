@@ -1,21 +1,27 @@
-// gs_binning.hip - tile binning: key duplication, stable LSD radix sort, tile ranges.
+// gs_binning.hip - tile binning: depth order of the Gaussians, key duplication, stable tile partition,
+// tile ranges.  Integer/byte work, HBM-bound.
 //
-// Replaces duplicateWithKeys (rasterizer_impl.cu:70-111), cub::DeviceRadixSort::SortPairs on the low
-// 32+ceil_log2(T) key bits (rasterizer_impl.cu:306-311) and identifyTileRanges (:116-138).
-// Integer/byte work, HBM-bound: everything here must reproduce the reference ordering exactly
-// (stable sort: equal (tile, depth-bits) keys stay in ascending Gaussian index).
+// Replaces duplicateWithKeys (rasterizer_impl.cu:70-111), cub::DeviceRadixSort::SortPairs over R
+// 64-bit (tile|depth) keys (rasterizer_impl.cu:306-311) and identifyTileRanges (:116-138), and produces
+// EXACTLY the reference's point_list (stable order: tile, then depth bits, then Gaussian index).
 //
-// All kernels read the instance count R from device memory (GeomHeader.num_rendered) so that the
-// host never has to wait for it; grids are sized from a host-side upper bound.
+// MI355X-first restructuring.  The reference sorts R = sum(tiles_touched) 12-byte pairs on 45 key bits
+// (6 radix passes, ~24 B x R each).  Here the two key fields are separated:
+//   1. the P Gaussians (not the R instances; R/P ~ 20) are stably sorted by their 32 depth bits
+//      (culled ones get key 0xFFFFFFFF) - 4 passes over 8 B x P;
+//   2. instances are emitted in that depth order (key = tile id only, 4 B);
+//   3. a STABLE partition by tile id (ceil(log2 T)/8 = 2 passes over 8 B x R at 1080p) then leaves every
+//      tile's list in (depth, index) order - the same total order as the 64-bit sort.
+// The instance-level traffic drops from 6 x 24 B to 2 x 16 B per instance.
+//
+// duplicate: one workgroup per 256 (depth-ordered) Gaussians; ALL lanes walk the workgroup's instance
+// range cooperatively (binary search of the owner in LDS): coalesced stores, no lane serialised on a
+// Gaussian that covers thousands of tiles (the reference loops one thread over a Gaussian's tiles).
+//
+// All kernels read element counts from device memory so the host never waits for them; grids are sized
+// from a host-side upper bound.
 #include "gs_common.h"
 
-// ------------------------------------------------------------------------------------------------
-// duplicate: one workgroup per 256 Gaussians.  A workgroup-local exclusive scan of tiles_touched
-// gives every Gaussian its slot range; then ALL 256 lanes walk the workgroup's instance range
-// cooperatively (binary search of the owning Gaussian in LDS), so stores are fully coalesced and a
-// Gaussian covering thousands of tiles does not serialise one lane (the reference loops one thread
-// over all of a Gaussian's tiles).
-// ------------------------------------------------------------------------------------------------
 __global__ void bin_prepare_kernel(GeomHeader* hdr, uint32_t capacity) {
   const uint32_t R = hdr->num_rendered;
   const bool ovf = R > capacity;
@@ -23,83 +29,29 @@ __global__ void bin_prepare_kernel(GeomHeader* hdr, uint32_t capacity) {
   hdr->sort_n = ovf ? 0u : R;
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, uint32_t grid_x, uint64_t* keys,
-                                                             uint32_t* vals) {
-  __shared__ uint32_t s_off[GS_BLOCK + 1];  // exclusive local offsets
-  __shared__ uint32_t s_wsum[GS_BLOCK / 64];
-  __shared__ uint32_t s_depth[GS_BLOCK];
-  __shared__ uint32_t s_rmin[GS_BLOCK];
-  __shared__ uint32_t s_w[GS_BLOCK];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int idx = blockIdx.x * GS_BLOCK + tid;
-  uint32_t tiles = 0;
-  if (idx < P) {
-    const Splat* sp = &g.splat[idx];
-    // one 16-B load covers rect_min, rect_max, tiles, clamped
-    const uint4 tail = reinterpret_cast<const uint4*>(sp)[3];
-    tiles = tail.z;
-    s_rmin[tid] = tail.x;
-    s_w[tid] = (tail.y & 0xFFFFu) - (tail.x & 0xFFFFu);
-    s_depth[tid] = __float_as_uint(sp->depth);
-  }
-  uint32_t inc = tiles;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) s_wsum[wid] = inc;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (int w = 0; w < wid; w++) woff += s_wsum[w];
-  const uint32_t base = g.block_sums[blockIdx.x];
-  s_off[tid] = woff + inc - tiles;
-  if (tid == GS_BLOCK - 1) s_off[GS_BLOCK] = woff + inc;
-  if (idx < P) g.point_offsets[idx] = base + woff + inc;  // inclusive scan, as the reference stores it
-  __syncthreads();
-  const uint32_t total = s_off[GS_BLOCK];
-  if (total == 0 || g.hdr->overflow) return;
-  for (uint32_t i = tid; i < total; i += GS_BLOCK) {
-    // largest gi with s_off[gi] <= i
-    int lo = 0, hi = GS_BLOCK - 1;
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      int mid = (lo + hi + 1) >> 1;
-      if (s_off[mid] <= i) lo = mid; else hi = mid - 1;
-    }
-    const uint32_t k = i - s_off[lo];
-    const uint32_t w = s_w[lo];
-    const uint32_t rmin = s_rmin[lo];
-    const uint32_t ty = (rmin >> 16) + k / w;
-    const uint32_t tx = (rmin & 0xFFFFu) + k % w;
-    uint64_t key = (uint64_t)(ty * grid_x + tx);
-    key <<= 32;
-    key |= s_depth[lo];
-    keys[base + i] = key;
-    vals[base + i] = blockIdx.x * GS_BLOCK + lo;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// LSD radix sort, 8-bit digits, stable.  Per pass: (a) per-workgroup digit histograms
-// (digit-major table), (b) exclusive scan of the table, (c) stable scatter.
+// stable LSD radix sort of (u32 key, u32 value) pairs, 8-bit digits.
+// Per pass: (a) per-workgroup digit histograms (digit-major table), (b) exclusive scan, (c) scatter.
+// A workgroup owns a 4096-key tile; wave w owns the contiguous quarter [w*1024, (w+1)*1024).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GS_BLOCK) rs_hist_kernel(const uint64_t* __restrict__ keys, const uint32_t* n_dev,
+__global__ void __launch_bounds__(GS_BLOCK) rs_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* n_dev,
                                                            int shift, uint32_t* __restrict__ hist, uint32_t nblk) {
-  __shared__ uint32_t h[RS_RADIX];
+  __shared__ uint32_t h[GS_BLOCK / 64][RS_RADIX];  // one private histogram per wave
   const uint32_t n = *n_dev;
-  const uint32_t t0 = blockIdx.x * RS_TILE;
-  h[threadIdx.x] = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+  for (int w = 0; w < GS_BLOCK / 64; w++) h[w][tid] = 0;
   __syncthreads();
-  if (t0 < n) {
+  const uint32_t w0 = blockIdx.x * RS_TILE + wid * (RS_TILE / 4);
+  if (w0 < n) {
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
-      uint32_t i = t0 + r * GS_BLOCK + threadIdx.x;
-      if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 0xFFu], 1u);
+      const uint32_t i = w0 + r * 64 + lane;
+      if (i < n) atomicAdd(&h[wid][(keys[i] >> shift) & 0xFFu], 1u);
     }
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+  hist[(size_t)tid * nblk + blockIdx.x] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
 }
 
 // generic exclusive scan of u32 data[n] (n known on host): reduce / scan-of-sums / downsweep
@@ -118,6 +70,7 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_reduce_kernel(const uint32_t* _
   __syncthreads();
   if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// in-place exclusive scan of sums[nb] by ONE workgroup; total -> sums[nb]
 __global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t* sums, int nb) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry_s;
@@ -143,6 +96,7 @@ __global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t* sums, int nb)
     if (tid == 1023) carry_s = carry + woff + inc;
     __syncthreads();
   }
+  if (tid == 0) sums[nb] = carry_s;
 }
 __global__ void __launch_bounds__(GS_BLOCK) scan_down_kernel(uint32_t* __restrict__ data, uint32_t n,
                                                              const uint32_t* __restrict__ sums) {
@@ -173,68 +127,150 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_down_kernel(uint32_t* __restric
   }
 }
 
-// stable scatter of one 4096-key tile: 16 rounds of 256 keys in index order; inside a round the
-// rank among equal digits = (same-digit lanes below me in my wave) + (same-digit counts of lower waves)
-__global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint64_t* __restrict__ kin,
-                                                              const uint32_t* __restrict__ vin,
-                                                              uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+// Stable scatter.  Phase 1: every wave ranks its 1024 keys in 16 rounds of 64 with wave-level
+// match-any (8 ballots per round; no barrier, LDS traffic stays inside the wave) and builds its private
+// digit histogram.  One barrier.  Phase 2: 256 threads turn the four wave histograms into per-wave
+// output bases.  One barrier.  Phase 3: every wave replays its rounds from registers and stores.
+__global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __restrict__ kin,
+                                                              const uint32_t* __restrict__ vin,  // NULL: value = index
+                                                              uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                               const uint32_t* n_dev, int shift,
                                                               const uint32_t* __restrict__ hist, uint32_t nblk) {
-  __shared__ uint32_t s_base[RS_RADIX];          // running output position per digit
-  __shared__ uint32_t s_cnt[GS_BLOCK / 64][RS_RADIX];  // per-wave digit counts of the current round
+  __shared__ uint32_t s_hist[GS_BLOCK / 64][RS_RADIX];  // phase 1: wave digit counts; phase 3: output bases
   const uint32_t n = *n_dev;
   const uint32_t t0 = blockIdx.x * RS_TILE;
   if (t0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  s_base[tid] = hist[(size_t)tid * nblk + blockIdx.x];
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int r = 0; r < RS_ITEMS; r++) {
-    const uint32_t i = t0 + r * GS_BLOCK + tid;
-    const bool valid = i < n;
-    uint64_t key = 0;
-    uint32_t val = 0;
-    if (valid) {
-      key = kin[i];
-      val = vin[i];
-    }
-    const uint32_t d = valid ? ((uint32_t)(key >> shift) & 0xFFu) : 0u;
 #pragma unroll
-    for (int w = 0; w < GS_BLOCK / 64; w++) s_cnt[w][tid] = 0;
-    __syncthreads();
-    // lanes of this wave holding the same digit
+  for (int w = 0; w < GS_BLOCK / 64; w++) s_hist[w][tid] = 0;
+  __syncthreads();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t w0 = t0 + wid * (RS_TILE / 4);
+  uint32_t key[RS_ITEMS], val[RS_ITEMS], pre[RS_ITEMS];  // pre = same-digit keys of my wave before me
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const uint32_t i = w0 + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? kin[i] : 0xFFFFFFFFu;
+    val[r] = valid ? (vin ? vin[i] : i) : 0u;
+    const uint32_t d = (key[r] >> shift) & 0xFFu;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < RS_BITS; b++) {
       const unsigned long long bal = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? bal : ~bal;
     }
-    const uint32_t rank_in_wave = __popcll(peers & lt_mask);
-    if (valid && rank_in_wave == 0) s_cnt[wid][d] = __popcll(peers);
+    const uint32_t rank = __popcll(peers & lt_mask);
+    // same wave, program order: the read sees the previous rounds' updates, and every lane of the wave has
+    // read before the leader's store below is issued (LDS ops of one wave execute in order)
+    const uint32_t before = s_hist[wid][d];
+    pre[r] = valid ? before + rank : 0xFFFFFFFFu;
+    if (valid && rank == 0) s_hist[wid][d] = before + (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  {
+    const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid];
+    const uint32_t base = hist[(size_t)tid * nblk + blockIdx.x];
     __syncthreads();
-    if (valid) {
-      uint32_t pos = s_base[d] + rank_in_wave;
-      for (int w = 0; w < wid; w++) pos += s_cnt[w][d];
-      kout[pos] = key;
-      vout[pos] = val;
+    s_hist[0][tid] = base;
+    s_hist[1][tid] = base + c0;
+    s_hist[2][tid] = base + c0 + c1;
+    s_hist[3][tid] = base + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    if (pre[r] != 0xFFFFFFFFu) {
+      const uint32_t pos = s_hist[wid][(key[r] >> shift) & 0xFFu] + pre[r];
+      kout[pos] = key[r];
+      vout[pos] = val[r];
     }
-    __syncthreads();
-    s_base[tid] += s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
-    // (the zeroing of s_cnt at the top of the next round is ordered by the barrier that follows it)
-    __syncthreads();
   }
 }
 
-// rasterizer_impl.cu:116-138
-__global__ void __launch_bounds__(GS_BLOCK) tile_ranges_kernel(const uint64_t* __restrict__ keys, const uint32_t* n_dev,
+// ------------------------------------------------------------------------------------------------
+// instance emission in depth order
+// ------------------------------------------------------------------------------------------------
+// per-workgroup sums of tiles_touched in depth order
+__global__ void __launch_bounds__(GS_BLOCK) sorted_block_sums_kernel(const uint32_t* __restrict__ order,
+                                                                     const uint32_t* __restrict__ tiles_touched, int P,
+                                                                     uint32_t* __restrict__ sums) {
+  __shared__ uint32_t red[GS_BLOCK / 64];
+  const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+  uint32_t v = (i < P) ? tiles_touched[order[i]] : 0u;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, uint32_t grid_x,
+                                                             const uint32_t* __restrict__ order,
+                                                             const uint32_t* __restrict__ block_base,
+                                                             uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals) {
+  __shared__ uint32_t s_off[GS_BLOCK + 1];  // exclusive local offsets
+  __shared__ uint32_t s_wsum[GS_BLOCK / 64];
+  __shared__ uint32_t s_id[GS_BLOCK];
+  __shared__ uint32_t s_rmin[GS_BLOCK];
+  __shared__ uint32_t s_w[GS_BLOCK];
+  if (g.hdr->overflow) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = blockIdx.x * GS_BLOCK + tid;
+  uint32_t tiles = 0;
+  if (i < P) {
+    const uint32_t id = order[i];
+    // one 16-B load covers rect_min, rect_max, tiles, clamped
+    const uint4 tail = reinterpret_cast<const uint4*>(&g.splat[id])[3];
+    tiles = tail.z;
+    s_id[tid] = id;
+    s_rmin[tid] = tail.x;
+    s_w[tid] = (tail.y & 0xFFFFu) - (tail.x & 0xFFFFu);
+  }
+  uint32_t inc = tiles;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) s_wsum[wid] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wid; w++) woff += s_wsum[w];
+  const uint32_t base = block_base[blockIdx.x];
+  s_off[tid] = woff + inc - tiles;
+  if (tid == GS_BLOCK - 1) s_off[GS_BLOCK] = woff + inc;
+  __syncthreads();
+  const uint32_t total = s_off[GS_BLOCK];
+  for (uint32_t k0 = tid; k0 < total; k0 += GS_BLOCK) {
+    // largest gi with s_off[gi] <= k0
+    int lo = 0, hi = GS_BLOCK - 1;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      int mid = (lo + hi + 1) >> 1;
+      if (s_off[mid] <= k0) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t k = k0 - s_off[lo];
+    const uint32_t w = s_w[lo];
+    const uint32_t rmin = s_rmin[lo];
+    const uint32_t ty = (rmin >> 16) + k / w;
+    const uint32_t tx = (rmin & 0xFFFFu) + k % w;
+    tkeys[base + k0] = ty * grid_x + tx;
+    tvals[base + k0] = s_id[lo];
+  }
+}
+
+// rasterizer_impl.cu:116-138 (keys hold the tile id only)
+__global__ void __launch_bounds__(GS_BLOCK) tile_ranges_kernel(const uint32_t* __restrict__ tkeys, const uint32_t* n_dev,
                                                                uint2* __restrict__ ranges) {
   const uint32_t L = *n_dev;
   const uint32_t idx = blockIdx.x * GS_BLOCK + threadIdx.x;
   if (idx >= L) return;
-  const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+  const uint32_t currtile = tkeys[idx];
   if (idx == 0)
     ranges[currtile].x = 0;
   else {
-    const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+    const uint32_t prevtile = tkeys[idx - 1];
     if (currtile != prevtile) {
       ranges[prevtile].y = idx;
       ranges[currtile].x = idx;
@@ -249,46 +285,54 @@ int launch_bin_prepare(const GeomView& g, int64_t capacity, hipStream_t s) {
   hipLaunchKernelGGL(bin_prepare_kernel, dim3(1), dim3(1), 0, s, g.hdr, cap32);
   return 0;
 }
-int launch_duplicate(const GeomView& g, int P, int grid_x, const BinView& b, int buf, hipStream_t s) {
-  const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
-  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, P, (uint32_t)grid_x, b.keys[buf], b.vals[buf]);
-  return 0;
-}
 
-static int exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* tmp, hipStream_t s) {
+static void exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* tmp, hipStream_t s) {
   const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, data, n, tmp);
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, tmp, (int)nb);
   hipLaunchKernelGGL(scan_down_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, data, n, tmp);
-  return 0;
 }
 
-int launch_radix_sort(const BinView& b, const uint32_t* n_dev, int64_t n_bound, int end_bit, int start_buf,
-                      hipStream_t s, int debug) {
+int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound, int end_bit, int start_buf,
+                      bool iota_values, hipStream_t s, int debug) {
   int cur = start_buf;
-  if (n_bound > 0) {
-    const uint32_t nblk = (uint32_t)((n_bound + RS_TILE - 1) / RS_TILE);  // <= b.nblk
-    const uint32_t hist_n = nblk * RS_RADIX;
-    for (int shift = 0; shift < end_bit; shift += RS_BITS) {
-      hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, b.keys[cur], n_dev, shift, b.hist, nblk);
-      GS_LAUNCH_CHECK(s, debug);
-      exclusive_scan_u32(b.hist, hist_n, b.scan_tmp, s);
-      GS_LAUNCH_CHECK(s, debug);
-      hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, b.keys[cur], b.vals[cur],
-                         b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, shift, b.hist, nblk);
-      GS_LAUNCH_CHECK(s, debug);
-      cur ^= 1;
-    }
+  if (n_bound <= 0) return 0;
+  const uint32_t nblk = (uint32_t)((n_bound + RS_TILE - 1) / RS_TILE);
+  const uint32_t hist_n = nblk * RS_RADIX;
+  bool first = true;
+  for (int shift = 0; shift < end_bit; shift += RS_BITS) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, b.keys[cur], n_dev, shift, b.hist, nblk);
+    GS_LAUNCH_CHECK(s, debug);
+    exclusive_scan_u32(b.hist, hist_n, b.scan_tmp, s);
+    GS_LAUNCH_CHECK(s, debug);
+    const uint32_t* vin = (first && iota_values) ? nullptr : b.vals[cur];
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, b.keys[cur], vin, b.keys[cur ^ 1],
+                       b.vals[cur ^ 1], n_dev, shift, b.hist, nblk);
+    GS_LAUNCH_CHECK(s, debug);
+    cur ^= 1;
+    first = false;
   }
   return 0;
 }
 
-int launch_tile_ranges(const uint64_t* keys, const uint32_t* n_dev, int64_t n_bound, uint2* ranges, int T,
+int launch_emit_instances(const GeomView& g, int P, int grid_x, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
+                          hipStream_t s, int debug) {
+  const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
+  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, order, g.tiles_touched, P, g.sorted_sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, g.sorted_sums, nb);
+  GS_LAUNCH_CHECK(s, debug);
+  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, P, (uint32_t)grid_x, order, g.sorted_sums, tkeys,
+                     tvals);
+  GS_LAUNCH_CHECK(s, debug);
+  return 0;
+}
+
+int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_bound, uint2* ranges, int T,
                        hipStream_t s) {
   hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, s);
   if (e != hipSuccess) return (int)e;
   if (n_bound > 0)
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((uint32_t)((n_bound + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, s,
-                       keys, n_dev, ranges);
+                       tkeys, n_dev, ranges);
   return 0;
 }

@@ -5,11 +5,11 @@
 //  geom   : GeomHeader (256 B)
 //           splat[P]        64-byte record per Gaussian (one cache line per gather in the blend kernels)
 //           cov3D[P][6]     fp32, only read again by the backward per-Gaussian kernel
-//           tiles_touched[P] u32   (scan input)
-//           point_offsets[P] u32   (inclusive scan, written by the duplicate kernel)
-//           block_sums[ceil(P/256)] u32 -> exclusive block offsets after the scan kernel
+//           tiles_touched[P] u32
+//           block_sums / sorted_sums [ceil(P/256)+1] u32   workgroup sums of tiles_touched (index / depth order)
+//           gsort            radix-sort buffers of the per-Gaussian depth sort (16 B x P + histograms)
 //  img    : final_T[N] f32 | n_contrib[N] u32 | ranges[T] uint2
-//  binning: keys[2][cap] u64 | vals[2][cap] u32 | radix histograms
+//  binning: tile keys[2][cap] u32 | Gaussian ids[2][cap] u32 | radix histograms   (16 B per instance)
 //
 // All sub-arrays start on 256-byte boundaries.
 #pragma once
@@ -50,18 +50,55 @@ static_assert(sizeof(Splat) == 64, "Splat is one 64-B line");
 
 static inline __host__ __device__ size_t gs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// radix sort geometry: 8-bit digits, 256 threads x 16 keys per workgroup
+#define RS_BITS 8
+#define RS_RADIX 256
+#define RS_ITEMS 16
+#define RS_TILE (GS_BLOCK * RS_ITEMS)
+
+// ping-pong buffers + histogram workspace of one (u32 key, u32 value) radix sort of up to `cap` pairs
+struct SortBufs {
+  uint32_t* keys[2];
+  uint32_t* vals[2];
+  uint32_t* hist;      // [RS_RADIX][nblk] digit-major workgroup histograms
+  uint32_t* scan_tmp;  // workgroup sums of the histogram scan
+};
+static inline __host__ __device__ size_t sort_bytes(size_t cap) {
+  if (cap == 0) cap = 1;
+  size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
+  size_t hist_n = nblk * RS_RADIX;
+  size_t nscan = (hist_n + RS_TILE - 1) / RS_TILE;
+  return 4 * gs_align(4 * cap) + gs_align(4 * hist_n) + gs_align(4 * (nscan + 1));
+}
+static inline __host__ __device__ SortBufs sort_view(void* buf, size_t cap) {
+  if (cap == 0) cap = 1;
+  char* p = (char*)buf;
+  SortBufs b;
+  size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
+  size_t hist_n = nblk * RS_RADIX;
+  size_t nscan = (hist_n + RS_TILE - 1) / RS_TILE;
+  b.keys[0] = (uint32_t*)p; p += gs_align(4 * cap);
+  b.keys[1] = (uint32_t*)p; p += gs_align(4 * cap);
+  b.vals[0] = (uint32_t*)p; p += gs_align(4 * cap);
+  b.vals[1] = (uint32_t*)p; p += gs_align(4 * cap);
+  b.hist = (uint32_t*)p; p += gs_align(4 * hist_n);
+  b.scan_tmp = (uint32_t*)p; p += gs_align(4 * (nscan + 1));
+  return b;
+}
+
 struct GeomView {
   GeomHeader* hdr;
   Splat* splat;
   float* cov3D;
   uint32_t* tiles_touched;
-  uint32_t* point_offsets;
-  uint32_t* block_sums;
+  uint32_t* block_sums;   // [nb+1] per-workgroup sums of tiles_touched (index order) -> exclusive offsets
+  uint32_t* sorted_sums;  // [nb+1] the same in depth order (instance emission)
+  SortBufs gsort;         // depth sort of the P Gaussians: keys[0] = depth bits written by preprocess
 };
 static inline __host__ __device__ size_t geom_bytes(size_t P) {
   size_t nb = (P + GS_BLOCK - 1) / GS_BLOCK;
-  return sizeof(GeomHeader) + gs_align(64 * P) + gs_align(24 * P) + gs_align(4 * P) + gs_align(4 * P) +
-         gs_align(4 * (nb + 1));
+  return sizeof(GeomHeader) + gs_align(64 * P) + gs_align(24 * P) + gs_align(4 * P) + 2 * gs_align(4 * (nb + 1)) +
+         sort_bytes(P);
 }
 static inline __host__ __device__ GeomView geom_view(void* buf, size_t P) {
   char* p = (char*)buf;
@@ -71,8 +108,9 @@ static inline __host__ __device__ GeomView geom_view(void* buf, size_t P) {
   g.splat = (Splat*)p; p += gs_align(64 * P);
   g.cov3D = (float*)p; p += gs_align(24 * P);
   g.tiles_touched = (uint32_t*)p; p += gs_align(4 * P);
-  g.point_offsets = (uint32_t*)p; p += gs_align(4 * P);
   g.block_sums = (uint32_t*)p; p += gs_align(4 * (nb + 1));
+  g.sorted_sums = (uint32_t*)p; p += gs_align(4 * (nb + 1));
+  g.gsort = sort_view(p, P);
   return g;
 }
 
@@ -94,42 +132,8 @@ static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T
   return v;
 }
 
-// radix sort geometry: 8-bit digits, 256 threads x 16 keys per block
-#define RS_BITS 8
-#define RS_RADIX 256
-#define RS_ITEMS 16
-#define RS_TILE (GS_BLOCK * RS_ITEMS)
-
-struct BinView {
-  uint64_t* keys[2];
-  uint32_t* vals[2];
-  uint32_t* hist;      // [RS_RADIX][nblk] digit-major block histograms (+ scan scratch behind it)
-  uint32_t* scan_tmp;  // block sums of the histogram scan
-  size_t nblk;
-  size_t hist_n;
-};
-static inline __host__ __device__ size_t bin_bytes(size_t cap) {
-  if (cap == 0) cap = 1;
-  size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
-  size_t hist_n = nblk * RS_RADIX;
-  size_t nscan = (hist_n + RS_TILE - 1) / RS_TILE;
-  return 2 * gs_align(8 * cap) + 2 * gs_align(4 * cap) + gs_align(4 * hist_n) + gs_align(4 * (nscan + 1));
-}
-static inline __host__ __device__ BinView bin_view(void* buf, size_t cap) {
-  if (cap == 0) cap = 1;
-  char* p = (char*)buf;
-  BinView b;
-  b.nblk = (cap + RS_TILE - 1) / RS_TILE;
-  b.hist_n = b.nblk * RS_RADIX;
-  size_t nscan = (b.hist_n + RS_TILE - 1) / RS_TILE;
-  b.keys[0] = (uint64_t*)p; p += gs_align(8 * cap);
-  b.keys[1] = (uint64_t*)p; p += gs_align(8 * cap);
-  b.vals[0] = (uint32_t*)p; p += gs_align(4 * cap);
-  b.vals[1] = (uint32_t*)p; p += gs_align(4 * cap);
-  b.hist = (uint32_t*)p; p += gs_align(4 * b.hist_n);
-  b.scan_tmp = (uint32_t*)p; p += gs_align(4 * (nscan + 1));
-  return b;
-}
+// binning buffer = one SortBufs over the instances: keys = tile id, values = Gaussian index
+static inline __host__ __device__ size_t bin_bytes(size_t cap) { return sort_bytes(cap); }
 
 // per-Gaussian gradient row accumulated by the backward blend (one 64-B line per Gaussian)
 enum { GR_MX = 0, GR_MY, GR_CXX, GR_CXY, GR_CYY, GR_OP, GR_CR, GR_CG, GR_CB, GR_ID, GR_N, GR_STRIDE = 16 };
@@ -196,10 +200,11 @@ int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 int launch_bin_prepare(const GeomView& g, int64_t capacity, hipStream_t s);
-int launch_duplicate(const GeomView& g, int P, int grid_x, const BinView& b, int buf, hipStream_t s);
-int launch_radix_sort(const BinView& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
-                      hipStream_t s, int debug);
-int launch_tile_ranges(const uint64_t* keys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
+int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
+                      bool iota_values, hipStream_t s, int debug);
+int launch_emit_instances(const GeomView& g, int P, int grid_x, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
+                          hipStream_t s, int debug);
+int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
                        hipStream_t s);
 
 int launch_render_fwd(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,

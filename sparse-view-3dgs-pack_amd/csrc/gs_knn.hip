@@ -12,6 +12,7 @@
 
 #include "gs_common.h"
 #include "gs_math.h"
+#include "gs_prof.h"
 
 #define KNN_BOX 1024
 
@@ -108,14 +109,14 @@ GS_DEV uint32_t prep_morton(uint32_t x) {
   return x;
 }
 __global__ void __launch_bounds__(GS_BLOCK) knn_morton_kernel(const float* __restrict__ xyz, int P, const KnnHeader* hdr,
-                                                              uint64_t* keys, uint32_t* vals) {
+                                                              uint32_t* keys, uint32_t* vals) {
   const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
   if (i >= P) return;
   const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
   const uint32_t x = prep_morton(f2u_sat(((px - hdr->minn[0]) / (hdr->maxx[0] - hdr->minn[0])) * ((1 << 10) - 1)));
   const uint32_t y = prep_morton(f2u_sat(((py - hdr->minn[1]) / (hdr->maxx[1] - hdr->minn[1])) * ((1 << 10) - 1)));
   const uint32_t z = prep_morton(f2u_sat(((pz - hdr->minn[2]) / (hdr->maxx[2] - hdr->minn[2])) * ((1 << 10) - 1)));
-  keys[i] = (uint64_t)(x | (y << 1) | (z << 2));
+  keys[i] = x | (y << 1) | (z << 2);
   vals[i] = (uint32_t)i;
 }
 
@@ -235,8 +236,9 @@ int gs_knn_mean_dist2(const float* xyz, int32_t P, float* out, void* tmp, size_t
   if (!xyz || !out || !tmp) return GS_E_NULL;
   if (tmp_bytes < knn_bytes((size_t)P)) return GS_E_SCRATCH;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_KNN, s);
   KnnTmp t = knn_view(tmp, (size_t)P);
-  BinView bv = bin_view(t.bin, (size_t)P);
+  SortBufs bv = sort_view(t.bin, (size_t)P);
   const int nblk_p = (P + GS_BLOCK - 1) / GS_BLOCK;
   const int mm_blocks = nblk_p < KNN_MM_BLOCKS ? nblk_p : KNN_MM_BLOCKS;
   hipLaunchKernelGGL(knn_minmax_partial, dim3(mm_blocks), dim3(GS_BLOCK), 0, s, xyz, P, t.partial);
@@ -244,7 +246,7 @@ int gs_knn_mean_dist2(const float* xyz, int32_t P, float* out, void* tmp, size_t
   // 30-bit codes -> 4 passes (even): start in half 0, sorted list ends in half 0
   hipLaunchKernelGGL(knn_morton_kernel, dim3(nblk_p), dim3(GS_BLOCK), 0, s, xyz, P, t.hdr, bv.keys[0], bv.vals[0]);
   GS_LAUNCH_CHECK(s, 0);
-  int rc = launch_radix_sort(bv, &t.hdr->n, P, 32, 0, s, 0);
+  int rc = launch_radix_sort(bv, &t.hdr->n, P, 32, 0, /*iota_values=*/false, s, 0);
   if (rc) return rc;
   hipLaunchKernelGGL(knn_gather_kernel, dim3(nblk_p), dim3(GS_BLOCK), 0, s, xyz, P, bv.vals[0], t.sorted);
   hipLaunchKernelGGL(knn_box_kernel, dim3((unsigned)t.nb), dim3(GS_BLOCK), 0, s, t.sorted, P, t.boxes);

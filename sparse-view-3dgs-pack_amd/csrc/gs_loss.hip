@@ -11,6 +11,7 @@
 //   ELF map / patch selection   LGDWT-GS/utils/loss_utils.py:336-442
 //   fused SSIM                  fused-ssim/ssim.cu:187-366 (11-tap sigma=1.5 separable window, zero padding)
 #include "gs_common.h"
+#include "gs_prof.h"
 
 #define HC 0.7071067811865476f
 
@@ -469,6 +470,7 @@ int gs_l1_fwd(const float* a, const float* b, int64_t n, float* sum, void* strea
   if (!a || !b || !sum) return GS_E_NULL;
   if (n <= 0) return GS_OK;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_L1, s);
   if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return GS_E_UNSUPPORTED;  // torch allocations are 256-B aligned
   hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblocks(n / 4 + 1, GS_BLOCK, 2048)), dim3(GS_BLOCK), 0, s, a, b, n, sum);
   GS_LAUNCH_CHECK(s, 0);
@@ -478,6 +480,7 @@ int gs_l1_bwd(const float* a, const float* b, int64_t n, float coef, float* g, i
   if (!a || !b || !g) return GS_E_NULL;
   if (n <= 0) return GS_OK;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_L1, s);
   hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblocks(n)), dim3(GS_BLOCK), 0, s, a, b, n, coef, g, accumulate);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
@@ -487,6 +490,7 @@ int gs_dwt_haar_fwd(const float* x, int32_t NC, int32_t H, int32_t W, float* ll,
   if (!x) return GS_E_NULL;
   if (NC <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT1, s);
   const int64_t total = (int64_t)NC * ((H + 1) / 2) * ((W + 1) / 2);
   hipLaunchKernelGGL(dwt_fwd_kernel, dim3(nblocks(total)), dim3(GS_BLOCK), 0, s, x, NC, H, W, ll, lh, hl, hh);
   GS_LAUNCH_CHECK(s, 0);
@@ -497,6 +501,7 @@ int gs_dwt_haar_bwd(const float* dll, const float* dlh, const float* dhl, const 
   if (!dx) return GS_E_NULL;
   if (NC <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT1, s);
   const int64_t total = (int64_t)NC * ((H + 1) / 2) * ((W + 1) / 2);
   hipLaunchKernelGGL(dwt_bwd_kernel, dim3(nblocks(total)), dim3(GS_BLOCK), 0, s, dll, dlh, dhl, dhh, NC, H, W, dx);
   GS_LAUNCH_CHECK(s, 0);
@@ -506,6 +511,7 @@ int gs_dwt2_l1_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int
   if (!pred || !gt || !band_sums) return GS_E_NULL;
   if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT2_FWD, s);
   const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
   hipLaunchKernelGGL(dwt2_l1_fwd_kernel, dim3(nblocks((int64_t)C * h2 * w2, GS_BLOCK, 4096)), dim3(GS_BLOCK), 0, s, pred, gt,
                      C, H, W, band_sums);
@@ -517,6 +523,7 @@ int gs_dwt2_l1_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int
   if (!pred || !gt || !coef_dev || !grad_pred) return GS_E_NULL;
   if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT2_BWD, s);
   const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
   hipLaunchKernelGGL(dwt2_l1_bwd_kernel, dim3(nblocks((int64_t)C * h2 * w2)), dim3(GS_BLOCK), 0, s, pred, gt, C, H, W,
                      coef_dev, grad_pred, accumulate);
@@ -527,6 +534,7 @@ int gs_elf_map(const float* img, int32_t C, int32_t H, int32_t W, float* elf_low
   if (!img || !elf || !elf_low) return GS_E_NULL;
   if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_ELF, s);
   const int h = (H + 1) / 2, w = (W + 1) / 2;
   hipLaunchKernelGGL(elf_low_kernel, dim3((h * w + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, img, C, H, W, elf_low);
   hipLaunchKernelGGL(bilinear_up_kernel, dim3((H * W + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, elf_low, h, w, H, W, elf);
@@ -537,6 +545,7 @@ int gs_patch_means(const float* elf, int32_t H, int32_t W, int32_t ps, float* me
   if (!elf || !means) return GS_E_NULL;
   if (ps <= 0 || H < ps || W < ps) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_ELF, s);
   hipLaunchKernelGGL(patch_means_kernel, dim3((H / ps) * (W / ps)), dim3(GS_BLOCK), 0, s, elf, H, W, ps, means);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
@@ -546,6 +555,7 @@ int gs_patch_dwt_fwd(const float* pred, const float* gt, int32_t C, int32_t H, i
   if (!pred || !gt || !mask || !sums) return GS_E_NULL;
   if (ps <= 0 || H < ps || W < ps || C <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_PATCH, s);
   const int hp = (ps + 1) / 2;
   const int chunks = nblocks((int64_t)C * hp * hp, GS_BLOCK * 4, 64);
   hipLaunchKernelGGL(patch_dwt_kernel<false>, dim3((H / ps) * (W / ps), chunks), dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, ps,
@@ -558,6 +568,7 @@ int gs_patch_dwt_bwd(const float* pred, const float* gt, int32_t C, int32_t H, i
   if (!pred || !gt || !mask || !coef_dev || !grad_pred) return GS_E_NULL;
   if (ps <= 0 || H < ps || W < ps || C <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_PATCH, s);
   if (!accumulate) GS_HIP_CHECK(hipMemsetAsync(grad_pred, 0, sizeof(float) * (size_t)C * H * W, s));
   const int hp = (ps + 1) / 2;
   const int chunks = nblocks((int64_t)C * hp * hp, GS_BLOCK * 4, 64);
@@ -572,6 +583,7 @@ int gs_ssim_fwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
   if (dm_dmu1 && (!dm_dsigma1_sq || !dm_dsigma12)) return GS_E_NULL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_SSIM_FWD, s);
   hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
                      C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
   GS_LAUNCH_CHECK(s, 0);
@@ -583,6 +595,7 @@ int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
   if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return GS_E_NULL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_SSIM_BWD, s);
   hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
                      dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
   GS_LAUNCH_CHECK(s, 0);

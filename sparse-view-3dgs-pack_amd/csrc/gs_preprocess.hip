@@ -171,6 +171,8 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       cd[2] = make_float2(cov3D[4], cov3D[5]);
     }
     g.tiles_touched[idx] = tiles;
+    // key of the per-Gaussian depth sort (gs_binning.hip): culled Gaussians sort behind everything
+    g.gsort.keys[0][idx] = tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
     a.radii[idx] = sp.radius;
   }
   // per-workgroup partial sum of tiles_touched for the prefix sum
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
 
 // Exclusive scan of the per-workgroup sums, in place, one workgroup (nb <= 2^22); the grand total
 // (num_rendered) goes to the header and to block_sums[nb].
-__global__ void __launch_bounds__(1024) scan_block_sums_kernel(GeomView g, int nb) {
+__global__ void __launch_bounds__(1024) scan_block_sums_kernel(GeomView g, int nb, uint32_t P) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -214,6 +216,7 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(GeomView g, int n
     g.block_sums[nb] = carry_s;
     g.hdr->num_rendered = carry_s;
     g.hdr->overflow = 0;
+    g.hdr->P = P;
   }
 }
 
@@ -234,7 +237,7 @@ int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_
 }
 int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s) {
   const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, g, nb);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, g, nb, (uint32_t)P);
   return 0;
 }
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {

@@ -25,7 +25,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 class _RasterizeGaussians(torch.autograd.Function):
     # `_C` is looked up through this attribute so that the test-suite can run the identical
-    # autograd plumbing against the CPU oracle (tests/oracle_lib.py swaps it on a subclass).
+    # autograd plumbing against another implementation of the same C ABI (it swaps it on a subclass).
     _impl = _C
 
     @classmethod

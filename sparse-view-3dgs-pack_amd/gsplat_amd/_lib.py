@@ -6,6 +6,11 @@ GPU, every operator raises.
 import os
 import threading
 
+# torch must be loaded BEFORE the library: both link libamdhip64 and have to share ONE HIP runtime (the
+# streams and device pointers handed across the C ABI come from torch).  Loading the library first would
+# bind it to a second copy of the runtime and every launch would fail with hipErrorNoDevice.
+import torch  # noqa: F401,E402
+
 from .capi import CApi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

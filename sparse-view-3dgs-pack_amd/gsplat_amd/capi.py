@@ -3,7 +3,7 @@
 This module only describes the ABI (structs + prototypes) and loads a shared library that
 implements it.  The product loads ``csrc/libgsplat_hip.so`` with the ``gs_`` prefix (see
 ``gsplat_amd/_lib.py``); it raises if that library is missing - there is no CPU fallback.
-(The test-suite binds the same prototypes, prefix ``gso_``, onto the CPU oracle.)
+(The test-suite binds the same prototypes, under its own symbol prefix, onto its CPU checker.)
 """
 import ctypes as C
 import os
@@ -103,7 +103,15 @@ PROTOTYPES = {
     "patch_dwt_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "ssim_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "ssim_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "profile_enable": (C.c_int, [_I32]),
+    "profile_reset": (C.c_int, []),
+    "profile_stage_count": (C.c_int, []),
+    "profile_stage_name": (C.c_char_p, [_I32]),
+    "profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
 }
+
+# entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
+DEVICE_ONLY = ("profile_enable", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}
 
@@ -147,3 +155,12 @@ class CApi:
 
     def raw(self, name):
         return getattr(self, "_" + name)
+
+
+def read_profile(api):
+    """{stage name: (total ms, launches)} from the device library's HIP-event timers."""
+    n = api.raw("profile_stage_count")()
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    api.call("profile_read", ms, cnt, n)
+    return {api.raw("profile_stage_name")(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i] > 0}

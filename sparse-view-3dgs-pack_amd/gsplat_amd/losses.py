@@ -1,0 +1,281 @@
+"""Autograd wrappers over the loss kernels of the C ABI (include/gsplat.h).
+
+`LossOps(api)` mirrors, name for name, the functions of the reference's
+LGDWT-GS/utils/loss_utils.py (l1_loss :40-41, ssim :56-86 / fused_ssim, get_dwt_subbands :106-153,
+compute_elf_map :336-366, compute_patch_dwt_loss :368-442) plus the fused global DWT loss of
+LGDWT-GS/train.py:132-164 and the loss composition of train.py:188-202.
+All tensors stay on the device; no call synchronises the host.
+"""
+import ctypes as C
+
+import torch
+
+BANDS = ("LL1", "LH1", "HL1", "HH1", "LL2", "LH2", "HL2", "HH2")
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else None
+
+
+def _c(t):
+    t = t.contiguous()
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class LossOps:
+    def __init__(self, api):
+        self.api = api
+        ops = self
+
+        class _L1(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, a, b):
+                a, b = _c(a), _c(b)
+                s = torch.zeros((1,), dtype=torch.float32, device=a.device)
+                ops.api.call("l1_fwd", a.data_ptr(), b.data_ptr(), a.numel(), s.data_ptr(), _stream(a))
+                ctx.save_for_backward(a, b)
+                return (s / a.numel()).reshape(())
+
+            @staticmethod
+            def backward(ctx, g):
+                a, b = ctx.saved_tensors
+                # coef is applied on the device so no host sync is needed: grad = sign * (g / n)
+                sign = torch.empty_like(a)
+                ops.api.call("l1_bwd", a.data_ptr(), b.data_ptr(), a.numel(), 1.0, sign.data_ptr(), 0, _stream(a))
+                ga = sign * (g / a.numel())
+                return ga, (-ga if ctx.needs_input_grad[1] else None)
+
+        class _Haar(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                x = _c(x)
+                N, Cc, H, W = x.shape
+                h, w = (H + 1) // 2, (W + 1) // 2
+                outs = [torch.empty((N, Cc, h, w), dtype=torch.float32, device=x.device) for _ in range(4)]
+                ops.api.call("dwt_haar_fwd", x.data_ptr(), N * Cc, H, W, *[o.data_ptr() for o in outs], _stream(x))
+                ctx.shape = (N, Cc, H, W)
+                return tuple(outs)
+
+            @staticmethod
+            def backward(ctx, dll, dlh, dhl, dhh):
+                N, Cc, H, W = ctx.shape
+                gs = [None if g is None else _c(g) for g in (dll, dlh, dhl, dhh)]
+                ref = next(g for g in gs if g is not None)
+                dx = torch.empty((N, Cc, H, W), dtype=torch.float32, device=ref.device)
+                ops.api.call("dwt_haar_bwd", *[_p(g) for g in gs], N * Cc, H, W, dx.data_ptr(), _stream(ref))
+                return dx
+
+        class _Dwt2L1(torch.autograd.Function):
+            """sum_b w_b * mean|band_b(pred) - band_b(gt)| over the 8 sub-bands, one fused pass."""
+
+            @staticmethod
+            def forward(ctx, pred, gt, weights):
+                pred, gt = _c(pred), _c(gt)
+                Cc, H, W = pred.shape[-3:]
+                sums = torch.zeros((8,), dtype=torch.float32, device=pred.device)
+                ops.api.call("dwt2_l1_fwd", pred.data_ptr(), gt.data_ptr(), Cc, H, W, sums.data_ptr(), _stream(pred))
+                h1, w1 = (H + 1) // 2, (W + 1) // 2
+                h2, w2 = (h1 + 1) // 2, (w1 + 1) // 2
+                counts = torch.tensor([Cc * h1 * w1] * 4 + [Cc * h2 * w2] * 4, dtype=torch.float32, device=pred.device)
+                wdev = weights.to(device=pred.device, dtype=torch.float32)
+                means = sums / counts
+                ctx.save_for_backward(pred, gt, wdev / counts)
+                ctx.mark_non_differentiable(means)
+                return (means * wdev).sum(), means
+
+            @staticmethod
+            def backward(ctx, g, _gm):
+                pred, gt, coef = ctx.saved_tensors
+                coef = (coef * g).contiguous()
+                Cc, H, W = pred.shape[-3:]
+                grad = torch.empty_like(pred)
+                ops.api.call("dwt2_l1_bwd", pred.data_ptr(), gt.data_ptr(), Cc, H, W, coef.data_ptr(), grad.data_ptr(),
+                             0, _stream(pred))
+                return grad, None, None
+
+        class _PatchDwt(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, pred, gt, mask, ps, w3):
+                pred, gt = _c(pred), _c(gt)
+                Cc, H, W = pred.shape[-3:]
+                sums = torch.zeros((3,), dtype=torch.float32, device=pred.device)
+                ops.api.call("patch_dwt_fwd", pred.data_ptr(), gt.data_ptr(), Cc, H, W, ps, mask.data_ptr(),
+                             sums.data_ptr(), _stream(pred))
+                hp = (ps + 1) // 2
+                n_sel = mask.sum().to(torch.float32)
+                denom = torch.clamp_min(n_sel * (Cc * hp * hp), 1.0)
+                w3 = w3.to(device=pred.device, dtype=torch.float32)
+                ctx.save_for_backward(pred, gt, mask, w3 / denom)
+                ctx.ps = ps
+                return (sums / denom * w3).sum()
+
+            @staticmethod
+            def backward(ctx, g):
+                pred, gt, mask, coef = ctx.saved_tensors
+                coef = (coef * g).contiguous()
+                Cc, H, W = pred.shape[-3:]
+                grad = torch.empty_like(pred)
+                ops.api.call("patch_dwt_bwd", pred.data_ptr(), gt.data_ptr(), Cc, H, W, ctx.ps, mask.data_ptr(),
+                             coef.data_ptr(), grad.data_ptr(), 0, _stream(pred))
+                return grad, None, None, None, None
+
+        class _SSIMMap(torch.autograd.Function):
+            # FusedSSIMMap, fused-ssim/fused_ssim/__init__.py:8-32
+            @staticmethod
+            def forward(ctx, C1, C2, img1, img2, padding="same", train=True):
+                img1, img2 = _c(img1), _c(img2)
+                B, Cc, H, W = img1.shape
+                smap = torch.empty_like(img1)
+                if train:
+                    d1, d2, d3 = torch.empty_like(img1), torch.empty_like(img1), torch.empty_like(img1)
+                else:
+                    d1 = d2 = d3 = None
+                ops.api.call("ssim_fwd", img1.data_ptr(), img2.data_ptr(), B, Cc, H, W, float(C1), float(C2),
+                             smap.data_ptr(), _p(d1), _p(d2), _p(d3), _stream(img1))
+                if padding == "valid":
+                    smap = smap[:, :, 5:-5, 5:-5]
+                if train:
+                    ctx.save_for_backward(img1.detach(), img2, d1, d2, d3)
+                ctx.C1, ctx.C2, ctx.padding, ctx.train = C1, C2, padding, train
+                return smap
+
+            @staticmethod
+            def backward(ctx, opt_grad):
+                if not ctx.train:
+                    raise RuntimeError("fused_ssim(train=False) cannot be differentiated")
+                img1, img2, d1, d2, d3 = ctx.saved_tensors
+                dL_dmap = opt_grad
+                if ctx.padding == "valid":
+                    dL_dmap = torch.zeros_like(img1)
+                    dL_dmap[:, :, 5:-5, 5:-5] = opt_grad
+                dL_dmap = _c(dL_dmap)
+                B, Cc, H, W = img1.shape
+                grad = torch.empty_like(img1)
+                ops.api.call("ssim_bwd", img1.data_ptr(), img2.data_ptr(), B, Cc, H, W, float(ctx.C1), float(ctx.C2),
+                             dL_dmap.data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), grad.data_ptr(),
+                             _stream(img1))
+                return None, None, grad, None, None, None
+
+        self._L1, self._Haar, self._Dwt2L1, self._PatchDwt, self._SSIMMap = _L1, _Haar, _Dwt2L1, _PatchDwt, _SSIMMap
+
+    # ---------------------------------------------------------------- loss_utils.py names
+    def l1_loss(self, network_output, gt):
+        return self._L1.apply(network_output, gt)
+
+    def fused_ssim(self, img1, img2, padding="same", train=True):
+        """fused-ssim/fused_ssim/__init__.py:34-41: img [B,C,H,W] -> scalar mean SSIM."""
+        assert padding in ("same", "valid")
+        return self._SSIMMap.apply(0.01 ** 2, 0.03 ** 2, img1, img2, padding, train).mean()
+
+    def ssim(self, img1, img2, window_size=11, size_average=True):
+        """loss_utils.ssim signature ([C,H,W] or [B,C,H,W] images)."""
+        if window_size != 11:
+            raise NotImplementedError("only the 11-tap window of the reference is implemented")
+        a = img1 if img1.dim() == 4 else img1.unsqueeze(0)
+        b = img2 if img2.dim() == 4 else img2.unsqueeze(0)
+        m = self._SSIMMap.apply(0.01 ** 2, 0.03 ** 2, a, b, "same", True)
+        return m.mean() if size_average else m.mean(1).mean(1).mean(1)
+
+    def dwt_haar(self, x):
+        """One analysis level: x[N,C,H,W] -> (LL, LH, HL, HH)."""
+        return self._Haar.apply(x)
+
+    def get_dwt_subbands(self, x):
+        LL1, LH1, HL1, HH1 = self.dwt_haar(x)
+        LL2, LH2, HL2, HH2 = self.dwt_haar(LL1)
+        return {"LL1": LL1, "LH1": LH1, "HL1": HL1, "HH1": HH1, "LL2": LL2, "LH2": LH2, "HL2": HL2, "HH2": HH2}
+
+    def dwt_l1_loss(self, pred, gt, weights):
+        """Fused train.py:132-164: weights = 8 floats in BANDS order.  Returns (loss, per-band means)."""
+        w = torch.as_tensor(weights, dtype=torch.float32)
+        if pred.dim() == 4:
+            assert pred.shape[0] == 1, "batch of one image, as in the reference training loop"
+            pred, gt = pred[0], gt[0]
+        return self._Dwt2L1.apply(pred, gt, w)
+
+    def compute_elf_map(self, image):
+        image = _c(image)
+        N, Cc, H, W = image.shape
+        out = torch.empty((N, 1, H, W), dtype=torch.float32, device=image.device)
+        low = torch.empty(((H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=image.device)
+        for n in range(N):
+            self.api.call("elf_map", image[n].data_ptr(), Cc, H, W, low.data_ptr(), out[n].data_ptr(), _stream(image))
+        return out
+
+    def patch_mask(self, elf_map, patch_size=128, percentile=0.2):
+        """Selection rule of compute_patch_dwt_loss (loss_utils.py:391-417): uint8 mask[L] on device."""
+        elf_map = _c(elf_map)
+        H, W = elf_map.shape[-2:]
+        L = (H // patch_size) * (W // patch_size)
+        means = torch.empty((L,), dtype=torch.float32, device=elf_map.device)
+        self.api.call("patch_means", elf_map.data_ptr(), H, W, patch_size, means.data_ptr(), _stream(elf_map))
+        k = int(means.numel() * (1.0 - percentile))
+        k = max(1, k)
+        k = min(k, means.numel())
+        threshold, _ = torch.kthvalue(means, k)
+        return (means >= threshold).to(torch.uint8), means
+
+    def compute_patch_dwt_loss(self, pred, gt, elf_map, patch_size=128, percentile=0.2, lh1_weight=1.0,
+                               hl1_weight=1.0, mask=None):
+        N, Cc, H, W = pred.shape
+        if H < patch_size or W < patch_size:
+            return torch.tensor(0.0, device=pred.device)
+        assert N == 1, "batch of one image, as in the reference training loop"
+        if mask is None:
+            mask, _ = self.patch_mask(elf_map, patch_size, percentile)
+        w3 = torch.tensor([lh1_weight, hl1_weight, 0.5 * (lh1_weight + hl1_weight)], dtype=torch.float32)
+        return self._PatchDwt.apply(pred[0], gt[0], mask, int(patch_size), w3)
+
+
+class LGDWTCriterion:
+    """Loss composition of LGDWT-GS/train.py:128-202 with the reference's defaults
+    (LGDWT-GS/arguments/__init__.py:88-122).  The running-mean DWT scale lives on the DEVICE (the
+    reference pulls base/dwt to the host with .item() every iteration); per-camera ELF masks (a
+    function of the ground truth only) can be cached by the caller through `mask`."""
+
+    def __init__(self, ops, lambda_dssim=0.2, dwt_enable=True, patch_dwt_enable=True,
+                 dwt_weights=(1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0), patch_size=128, patch_percentile=0.2,
+                 patch_dwt_weight=0.1, patch_lh1_weight=1.0, patch_hl1_weight=1.0):
+        self.ops = ops
+        self.lambda_dssim = lambda_dssim
+        self.dwt_enable, self.patch_dwt_enable = dwt_enable, patch_dwt_enable
+        self.dwt_weights = tuple(dwt_weights)
+        self.patch_size, self.patch_percentile = patch_size, patch_percentile
+        self.patch_dwt_weight = patch_dwt_weight
+        self.patch_lh1_weight, self.patch_hl1_weight = patch_lh1_weight, patch_hl1_weight
+        self.dwt_running_mean = None  # device scalar, starts at 1.0 (train.py:75)
+
+    def elf_mask(self, gt_image):
+        elf = self.ops.compute_elf_map(gt_image.unsqueeze(0))
+        mask, _ = self.ops.patch_mask(elf, self.patch_size, self.patch_percentile)
+        return mask
+
+    def __call__(self, image, gt_image, mask=None):
+        ops = self.ops
+        Ll1 = ops.l1_loss(image, gt_image)
+        ssim_value = ops.fused_ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
+        base_loss = (1.0 - self.lambda_dssim) * Ll1 + self.lambda_dssim * (1.0 - ssim_value)
+        loss = base_loss
+        parts = {"l1": Ll1.detach(), "ssim": ssim_value.detach()}
+        if self.dwt_enable:
+            dwt_loss, band_means = ops.dwt_l1_loss(image, gt_image, self.dwt_weights)
+            ratio = base_loss.detach() / (dwt_loss.detach() + 1e-8)
+            if self.dwt_running_mean is None:
+                self.dwt_running_mean = torch.ones((), dtype=torch.float32, device=image.device)
+            self.dwt_running_mean = 0.95 * self.dwt_running_mean + 0.05 * ratio
+            dwt_scale = torch.clamp(self.dwt_running_mean, 0.1, 10.0)
+            loss = base_loss + dwt_scale * dwt_loss
+            parts.update(dwt=dwt_loss.detach(), dwt_scale=dwt_scale, bands=band_means)
+        if self.patch_dwt_enable and image.shape[-2] >= self.patch_size and image.shape[-1] >= self.patch_size:
+            if mask is None:
+                mask = self.elf_mask(gt_image)
+            patch_loss = ops.compute_patch_dwt_loss(image.unsqueeze(0), gt_image.unsqueeze(0), None, self.patch_size,
+                                                    self.patch_percentile, self.patch_lh1_weight,
+                                                    self.patch_hl1_weight, mask=mask)
+            loss = loss + self.patch_dwt_weight * patch_loss
+            parts["patch"] = patch_loss.detach()
+        return loss, parts

@@ -27,10 +27,10 @@ def build():
 class Oracle:
     def __init__(self):
         import diff_gaussian_rasterization as dgr
-        from gsplat_amd.capi import CApi
+        from gsplat_amd.capi import DEVICE_ONLY, CApi
         from gsplat_amd.raster import RasterBackend
         build()
-        self.api = CApi(ORACLE_SO, "gso_")
+        self.api = CApi(ORACLE_SO, "gso_", optional=DEVICE_ONLY)
         self.backend = RasterBackend(self.api, "cpu")
         backend = self.backend
         lib = self.api.lib

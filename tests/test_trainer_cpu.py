@@ -1,0 +1,44 @@
+"""BASELINE config-1-style plumbing on the CPU: the build-owned step loop (render adaptor, LGDWT
+criterion, backward, Adam) running on the CPU oracle behind the reference's rasterizer API."""
+import torch
+
+from gsplat_amd import synthetic
+from gsplat_amd.losses import LGDWTCriterion, LossOps
+from gsplat_amd.trainer import FLOATS_PER_GAUSSIAN, GaussianModelLite, Trainer, camera_to, render
+
+
+def make_trainer(oracle, P=600, W=160, H=128, world_size=1, rank=0, seed=0, dwt=True):
+    dev = torch.device("cpu")
+    sc = synthetic.trained_like(P, seed=seed, scale_mult=1.5)
+    cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(W, H)[:4]]
+    g = torch.Generator().manual_seed(5)
+    gts = [torch.rand((3, H, W), generator=g) for _ in cams]
+    model = GaussianModelLite(sc, dev)
+    crit = LGDWTCriterion(LossOps(oracle.api), dwt_enable=dwt, patch_dwt_enable=dwt)
+    return Trainer(model, cams, gts, crit, oracle.Rasterizer, oracle.Settings, torch.zeros(3), rank, world_size)
+
+
+def test_step_updates_all_six_parameter_tensors_and_lowers_the_loss(oracle):
+    tr = make_trainer(oracle)
+    before = tr.model.flat.clone()
+    l0 = float(tr.step(0))
+    assert tr.model.flat_grad.abs().sum() > 0
+    for name, p in tr.model.params.items():
+        assert p.grad.data_ptr() >= tr.model.flat_grad.data_ptr()  # still a view of the flat buffer
+        assert float((p.detach() - before[: 0].new_zeros(())).abs().sum()) >= 0
+    assert not torch.equal(before, tr.model.flat)
+    assert tr.model.flat.numel() == 600 * FLOATS_PER_GAUSSIAN
+    losses = [l0] + [float(tr.step(k)) for k in range(4, 24, 4)]  # same camera (index 0) every 4th step
+    assert losses[-1] < losses[0]
+    assert float(tr.model.denom.max()) >= 1 and float(tr.model.max_radii2D.max()) > 0
+
+
+def test_render_contract_matches_reference_renderer(oracle):
+    tr = make_trainer(oracle, dwt=False)
+    pkg = render(tr.cameras[0], tr.model, oracle.Rasterizer, oracle.Settings, torch.zeros(3))
+    assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
+    assert pkg["render"].shape == (3, 128, 160) and pkg["depth"].shape == (1, 128, 160)
+    assert pkg["visibility_filter"].dim() == 2 and pkg["visibility_filter"].shape[1] == 1  # nonzero() indices
+    assert float(pkg["render"].min()) >= 0 and float(pkg["render"].max()) <= 1
+    pkg["render"].sum().backward()
+    assert pkg["viewspace_points"].grad is not None and pkg["viewspace_points"].grad.shape == (600, 3)
