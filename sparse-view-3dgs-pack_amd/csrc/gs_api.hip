@@ -129,9 +129,10 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
   launch_bin_prepare(gv, cap, s);
   GS_LAUNCH_CHECK(s, v->debug);
   if (cap > 0) {
-    {  // 1. depth order of the P Gaussians: 4 passes, starts in half 0 (keys written by preprocess), ends in half 0
+    {  // 1. depth order of the P Gaussians: 4 passes; pass 0 reads the keys preprocess wrote (kept intact, so the
+       //    phase can be re-run), then half 1 -> 0 -> 1 -> 0: the order ends in gsort.vals[0]
       GS_PROF(ST_SORT_DEPTH, s);
-      rc = launch_radix_sort(gv.gsort, &gv.hdr->P, P, 32, 0, /*iota_values=*/true, s, v->debug);
+      rc = launch_radix_sort(gv.gsort, &gv.hdr->P, P, 32, 0, gv.depth_keys, s, v->debug);
       if (rc) return rc;
     }
     // 2. instances in depth order; 3. stable partition by tile id.  The unsorted list goes into the ping-pong
@@ -146,7 +147,7 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
     }
     {
       GS_PROF(ST_SORT, s);
-      rc = launch_radix_sort(bv, &gv.hdr->sort_n, cap, bit, start, /*iota_values=*/false, s, v->debug);
+      rc = launch_radix_sort(bv, &gv.hdr->sort_n, cap, bit, start, nullptr, s, v->debug);
       if (rc) return rc;
     }
   }

@@ -294,19 +294,21 @@ static void exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* tmp, hipStr
 }
 
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound, int end_bit, int start_buf,
-                      bool iota_values, hipStream_t s, int debug) {
+                      const uint32_t* first_keys, hipStream_t s, int debug) {
   int cur = start_buf;
   if (n_bound <= 0) return 0;
   const uint32_t nblk = (uint32_t)((n_bound + RS_TILE - 1) / RS_TILE);
   const uint32_t hist_n = nblk * RS_RADIX;
   bool first = true;
   for (int shift = 0; shift < end_bit; shift += RS_BITS) {
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, b.keys[cur], n_dev, shift, b.hist, nblk);
+    const bool ext = first && first_keys != nullptr;
+    const uint32_t* kin = ext ? first_keys : b.keys[cur];
+    const uint32_t* vin = ext ? nullptr : b.vals[cur];
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, n_dev, shift, b.hist, nblk);
     GS_LAUNCH_CHECK(s, debug);
     exclusive_scan_u32(b.hist, hist_n, b.scan_tmp, s);
     GS_LAUNCH_CHECK(s, debug);
-    const uint32_t* vin = (first && iota_values) ? nullptr : b.vals[cur];
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, b.keys[cur], vin, b.keys[cur ^ 1],
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, vin, b.keys[cur ^ 1],
                        b.vals[cur ^ 1], n_dev, shift, b.hist, nblk);
     GS_LAUNCH_CHECK(s, debug);
     cur ^= 1;

@@ -93,11 +93,12 @@ struct GeomView {
   uint32_t* tiles_touched;
   uint32_t* block_sums;   // [nb+1] per-workgroup sums of tiles_touched (index order) -> exclusive offsets
   uint32_t* sorted_sums;  // [nb+1] the same in depth order (instance emission)
-  SortBufs gsort;         // depth sort of the P Gaussians: keys[0] = depth bits written by preprocess
+  uint32_t* depth_keys;   // [P] depth bits (0xFFFFFFFF when culled): read-only input of the depth sort
+  SortBufs gsort;         // ping-pong buffers of the depth sort of the P Gaussians
 };
 static inline __host__ __device__ size_t geom_bytes(size_t P) {
   size_t nb = (P + GS_BLOCK - 1) / GS_BLOCK;
-  return sizeof(GeomHeader) + gs_align(64 * P) + gs_align(24 * P) + gs_align(4 * P) + 2 * gs_align(4 * (nb + 1)) +
+  return sizeof(GeomHeader) + gs_align(64 * P) + gs_align(24 * P) + 2 * gs_align(4 * P) + 2 * gs_align(4 * (nb + 1)) +
          sort_bytes(P);
 }
 static inline __host__ __device__ GeomView geom_view(void* buf, size_t P) {
@@ -110,6 +111,7 @@ static inline __host__ __device__ GeomView geom_view(void* buf, size_t P) {
   g.tiles_touched = (uint32_t*)p; p += gs_align(4 * P);
   g.block_sums = (uint32_t*)p; p += gs_align(4 * (nb + 1));
   g.sorted_sums = (uint32_t*)p; p += gs_align(4 * (nb + 1));
+  g.depth_keys = (uint32_t*)p; p += gs_align(4 * P);
   g.gsort = sort_view(p, P);
   return g;
 }
@@ -200,8 +202,9 @@ int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 int launch_bin_prepare(const GeomView& g, int64_t capacity, hipStream_t s);
+// first_keys != NULL: the first pass reads its keys from there (left untouched) and takes value = index
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
-                      bool iota_values, hipStream_t s, int debug);
+                      const uint32_t* first_keys, hipStream_t s, int debug);
 int launch_emit_instances(const GeomView& g, int P, int grid_x, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
                           hipStream_t s, int debug);
 int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,

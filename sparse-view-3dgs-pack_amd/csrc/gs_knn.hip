@@ -246,7 +246,7 @@ int gs_knn_mean_dist2(const float* xyz, int32_t P, float* out, void* tmp, size_t
   // 30-bit codes -> 4 passes (even): start in half 0, sorted list ends in half 0
   hipLaunchKernelGGL(knn_morton_kernel, dim3(nblk_p), dim3(GS_BLOCK), 0, s, xyz, P, t.hdr, bv.keys[0], bv.vals[0]);
   GS_LAUNCH_CHECK(s, 0);
-  int rc = launch_radix_sort(bv, &t.hdr->n, P, 32, 0, /*iota_values=*/false, s, 0);
+  int rc = launch_radix_sort(bv, &t.hdr->n, P, 32, 0, nullptr, s, 0);
   if (rc) return rc;
   hipLaunchKernelGGL(knn_gather_kernel, dim3(nblk_p), dim3(GS_BLOCK), 0, s, xyz, P, bv.vals[0], t.sorted);
   hipLaunchKernelGGL(knn_box_kernel, dim3((unsigned)t.nb), dim3(GS_BLOCK), 0, s, t.sorted, P, t.boxes);

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
     }
     g.tiles_touched[idx] = tiles;
     // key of the per-Gaussian depth sort (gs_binning.hip): culled Gaussians sort behind everything
-    g.gsort.keys[0][idx] = tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
+    g.depth_keys[idx] = tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
     a.radii[idx] = sp.radius;
   }
   // per-workgroup partial sum of tiles_touched for the prefix sum

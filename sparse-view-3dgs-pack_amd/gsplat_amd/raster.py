@@ -7,6 +7,7 @@ arguments and return tuples, on top of the two-phase C ABI.  Tensors stay torch-
 addresses and the current HIP stream cross the boundary.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -43,6 +44,8 @@ class RasterBackend:
         # optimistic binning capacity (instances): skips the forward's host sync when the previous
         # call's num_rendered is a good predictor; see rasterize_gaussians().
         self._capacity_hint = 0
+        self.optimistic = os.environ.get("GS_SYNC_FORWARD", "0") != "1"
+        self._cap_memo = {}
 
     # ------------------------------------------------------------------ helpers
     def _stream(self, device):
@@ -79,6 +82,32 @@ class RasterBackend:
         g.means3D, g.shs, g.colors_precomp, g.opacities = _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacities)
         g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D)
         return g
+
+    def _update_hint(self, num_rendered):
+        # 25 % head-room over the largest recent instance count; decays slowly so one huge view does not pin
+        # the capacity (and the 16 B/instance buffer) forever
+        want = int(num_rendered * 1.25) + 4096
+        self._capacity_hint = max(want, int(self._capacity_hint * 0.98))
+
+    def _capacity_of(self, P, W, H, nbytes, at_least):
+        """Instances the binning buffer of `nbytes` bytes was sized for (largest cap with bytes(cap) <= nbytes)."""
+        key = (P, W, H, nbytes)
+        cap = self._cap_memo.get(key)
+        if cap is None:
+            lo, hi = int(at_least), max(int(at_least), 1)
+            while self.scratch_bytes(P, W, H, hi)[2] <= nbytes:
+                lo, hi = hi, hi * 2
+            while lo < hi - 1:
+                mid = (lo + hi) // 2
+                if self.scratch_bytes(P, W, H, mid)[2] <= nbytes:
+                    lo = mid
+                else:
+                    hi = mid
+            cap = lo
+            if len(self._cap_memo) > 64:
+                self._cap_memo.clear()
+            self._cap_memo[key] = cap
+        return cap
 
     def scratch_bytes(self, P, W, H, R):
         out = (C.c_size_t * 3)()
@@ -133,10 +162,34 @@ class RasterBackend:
             if self._pinned is None:
                 self._pinned = torch.empty((1,), dtype=torch.int32).pin_memory()
             nr_host = self._pinned
+            cur = torch.cuda.current_stream(device)
             self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(),
                           nr_host.data_ptr(), stream)
-            torch.cuda.current_stream(device).synchronize()  # the reference's blocking D2H (rasterizer_impl.cu:284)
-            num_rendered = int(nr_host[0])
+            cap = self._capacity_hint if self.optimistic else 0
+            if cap > 0:
+                # Optimistic path: the reference blocks the host on a D2H copy of num_rendered before it can
+                # size the binning buffer (rasterizer_impl.cu:284-288) and the GPU idles meanwhile.  Here the
+                # binning/blend phase is enqueued at once with a capacity predicted from the previous calls
+                # (the kernels read num_rendered on the device); the host then waits only for the geometry
+                # phase - the GPU is already sorting and blending - and re-runs the phase in the rare case
+                # the prediction was too small.
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
+                binning = torch.empty((bb,), **u8)
+                s2 = self._scratch(geom, img, binning, cap)
+                self.api.call("forward_render", C.byref(view), C.byref(g), C.byref(s2), out_color.data_ptr(),
+                              out_invdepth.data_ptr(), stream)
+                ev.synchronize()
+                num_rendered = int(nr_host[0])
+                self._update_hint(num_rendered)
+                if num_rendered <= cap:
+                    return num_rendered, out_color, radii, geom, binning, img, out_invdepth
+                del binning
+            else:
+                cur.synchronize()  # the reference's blocking D2H (rasterizer_impl.cu:284)
+                num_rendered = int(nr_host[0])
+                self._update_hint(num_rendered)
         else:
             nr = (C.c_int32 * 1)()
             self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(),
@@ -188,7 +241,8 @@ class RasterBackend:
         radii = radii.contiguous()
         _, _, _, wsb = self.scratch_bytes(P, W, H, R)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
-        s = self._scratch(geomBuffer, imgBuffer, binningBuffer, R)
+        cap = R if binningBuffer.numel() == 0 else self._capacity_of(P, W, H, binningBuffer.numel(), R)
+        s = self._scratch(geomBuffer, imgBuffer, binningBuffer, cap)
         grads = GsGrads()
         grads.dL_dmeans3D, grads.dL_dmeans2D = dL_dmeans3D.data_ptr(), dL_dmeans2D.data_ptr()
         grads.dL_dsh = _ptr(dL_dsh)
@@ -219,7 +273,8 @@ class RasterBackend:
     def export_state(self, P, W, H, R, geom, binning, img):
         """Plain-array copies of the forward's internal state (tests / debugging only)."""
         device = geom.device
-        s = self._scratch(geom, img, binning, R)
+        cap = R if binning.numel() == 0 else self._capacity_of(P, W, H, binning.numel(), R)
+        s = self._scratch(geom, img, binning, cap)
         f32 = dict(dtype=torch.float32, device=device)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         out = dict(

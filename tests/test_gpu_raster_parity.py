@@ -169,3 +169,35 @@ def test_knn_bit_exact_vs_oracle(hip, oracle, P, seed):
     ref = dist2(oracle.api, pts)
     out = distCUDA2(pts.cuda()).cpu()
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+
+
+def test_optimistic_capacity_path_equals_synchronous_path(hip):
+    """The no-host-bubble forward (binning capacity predicted from earlier calls) must give the same
+    bytes as the synchronous path, including when the prediction overflows and the phase is re-run."""
+    sc = synthetic.trained_like(20000, seed=3)
+    cam = synthetic.orbit_cameras(640, 360)[5]
+    dev = torch.device("cuda")
+    bg = torch.zeros(3)
+    old = (hip.optimistic, hip._capacity_hint)
+    try:
+        hip.optimistic = False
+        ref = forward_state(hip, sc, cam, dev, bg, False)
+        hip.optimistic = True
+        for hint in (64, ref["num_rendered"] - 1, ref["num_rendered"], 10 * ref["num_rendered"]):
+            hip._capacity_hint = hint
+            got = forward_state(hip, sc, cam, dev, bg, False)
+            assert got["num_rendered"] == ref["num_rendered"]
+            for k in ("point_list", "keys_sorted", "ranges", "n_contrib"):
+                assert torch.equal(got[k], ref[k]), (hint, k)
+            assert torch.equal(got["color"], ref["color"]), hint
+        g = torch.Generator().manual_seed(0)
+        dL = torch.randn((3, 360, 640), generator=g)
+        hip._capacity_hint = 3 * ref["num_rendered"]
+        a = run_scene(dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, sc, cam, dev, bg=bg, dL_dcolor=dL)
+        hip.optimistic = False
+        b = run_scene(dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, sc, cam, dev, bg=bg, dL_dcolor=dL)
+        for k in b["grads"]:
+            scale = max(float(b["grads"][k].abs().max()), 1e-12)
+            assert float((a["grads"][k] - b["grads"][k]).abs().max()) / scale < 1e-4, k
+    finally:
+        hip.optimistic, hip._capacity_hint = old
