@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): kernel trace + stats, then HBM traffic counters in their own passes
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC has 4 slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# usage: bash profiles/collect.sh <tag>      -> gpurun_out/prof_<tag>/{trace,fetch,write}
+set -e
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > $OUT/bench_write.json 2> $OUT/bench_write.err
+find $OUT -name "*.csv" | head -20

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_<tag> directory (made by profiles/collect.sh) into the small files that are
+committed under profiles/:  <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, our kernels and
+the largest torch kernels), <tag>_step_timeline.txt (one steady-state step), <tag>_pmc_traffic.csv and
+pmc_traffic.json (HBM bytes per launch of each kernel from FETCH_SIZE / WRITE_SIZE, corrected as
+MI355X_MICROARCH.md 'HBM' prescribes: both counters are in KiB... FETCH_SIZE under-reports wide coalesced
+reads by 2x on gfx950, WRITE_SIZE is exact for 16-B stores and float atomics).
+usage: python profiles/summarize.py gpurun_out/prof_r01b r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs_scatter_kernel", "scan_reduce_kernel",
+        "scan_sums_kernel", "scan_down_kernel", "sorted_block_sums_kernel", "duplicate_kernel", "tile_ranges_kernel",
+        "bin_prepare_kernel", "render_fwd_kernel", "render_bwd_kernel", "preprocess_bwd_kernel", "l1_fwd_kernel",
+        "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
+        "patch_dwt_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel")
+
+
+def short(name):
+    for o in OURS:
+        if o in name:
+            return o
+    return name.split("(")[0][-60:]
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(here, "%s_kernel_stats.csv" % tag), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows[:40]:
+        w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
+tr = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(tr) if "render_bwd_kernel" in r["Kernel_Name"]]
+a, b = idx[-3], idx[-2]
+seg = tr[a:b]
+wall = (int(tr[b]["Start_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6
+busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e6
+agg = collections.OrderedDict()
+for r in seg:
+    n = short(r["Kernel_Name"])
+    agg.setdefault(n, [0.0, 0])
+    agg[n][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    agg[n][1] += 1
+with open(os.path.join(here, "%s_step_timeline.txt" % tag), "w") as f:
+    f.write("one steady-state train step (render_bwd to render_bwd), rocprofv3 --kernel-trace\n")
+    f.write("wall %.3f ms, GPU busy %.3f ms, %d kernel launches\n" % (wall, busy, len(seg)))
+    for n, (d, c) in sorted(agg.items(), key=lambda x: -x[1][0]):
+        f.write("%10.1f us %4d  %s\n" % (d, c, n))
+
+traffic = {}
+table = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
+for kind in ("fetch", "write"):
+    files = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    for r in csv.DictReader(open(files[0])):
+        table[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(os.path.join(here, "%s_pmc_traffic.csv" % tag), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "launches", "FETCH_SIZE_KiB_mean", "WRITE_SIZE_KiB_mean", "hbm_read_bytes_corrected(x2)",
+                "hbm_write_bytes", "hbm_total_bytes_per_launch"])
+    for k, v in sorted(table.items()):
+        if k not in OURS or not v["FETCH_SIZE"]:
+            continue
+        # steady-state launches only: drop the setup launches (GT renders etc.) by taking the last third
+        fs = v["FETCH_SIZE"][-max(1, len(v["FETCH_SIZE"]) // 3):]
+        ws = v["WRITE_SIZE"][-max(1, len(v["WRITE_SIZE"]) // 3):] if v["WRITE_SIZE"] else [0.0]
+        fm, wm = sum(fs) / len(fs), sum(ws) / len(ws)
+        rd, wr = 2.0 * fm * 1024.0, wm * 1024.0
+        w.writerow([k, len(v["FETCH_SIZE"]), "%.1f" % fm, "%.1f" % wm, "%.0f" % rd, "%.0f" % wr, "%.0f" % (rd + wr)])
+        traffic[k] = rd + wr
+stage_of = {"render_bwd": "render_bwd_kernel", "render_fwd": "render_fwd_kernel", "preprocess_fwd": "preprocess_fwd_kernel",
+            "preprocess_bwd": "preprocess_bwd_kernel", "duplicate": "duplicate_kernel", "tile_ranges": "tile_ranges_kernel"}
+out = {st: traffic[k] for st, k in stage_of.items() if k in traffic}
+if "rs_scatter_kernel" in traffic:  # the sort stage = all passes of hist + scatter (launch counts per step: 6 each)
+    out["sort"] = 6 * (traffic.get("rs_scatter_kernel", 0) + traffic.get("rs_hist_kernel", 0))
+json.dump(out, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(here, "%s_step_timeline.txt" % tag)).read())
+print(open(os.path.join(here, "%s_pmc_traffic.csv" % tag)).read())
