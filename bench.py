@@ -146,11 +146,18 @@ def main():
             sys.exit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal knobs (control-flow check of the N>1 path on a ONE-GPU box): all ranks on device 0 over gloo
+    one_dev = os.environ.get("GS_BENCH_SINGLE_DEVICE", "0") == "1"
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def log(*a):
         if rank == 0:
@@ -224,7 +231,7 @@ def main():
                                     (902 * P + 172 * R_last + 84 * N) / 1e9,
                                     (902 * P + 172 * R_last + 84 * N) / 1e9 * value / world)}
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tf):
+            if os.path.exists(tf) and args.config == "c3":  # counters were collected on the C3 workload
                 try:
                     roofline["traffic"] = json.load(open(tf)).get(dom)
                 except Exception:

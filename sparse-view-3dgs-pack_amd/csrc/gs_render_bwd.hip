@@ -13,6 +13,8 @@
 //      per (tile, Gaussian) instead of 2560), skipping rows nobody touched.
 // Entries behind every pixel's last contributor are never visited: the loop starts at the first
 // entry some pixel of the wave (batch: of the tile) actually blended in the forward pass.
+#include <stdlib.h>
+
 #include "gs_common.h"
 
 template <int CTRL, int ROW_MASK, bool BOUND>
@@ -38,7 +40,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 #define ACC_STRIDE 11  // 10 values + touched flag per entry; rows [j][11]: odd stride -> conflict-free flush reads
 
-template <bool HAS_INVDEPTH>
+// VARIANT: 0 = product; 1/2 = timing experiments only (wrong results): 1 drops the cross-lane reduction and the
+// accumulator traffic, 2 additionally drops the per-pair gradient math (alpha test only)
+template <bool HAS_INVDEPTH, int VARIANT>
 __global__ void __launch_bounds__(GS_BLOCK) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const Splat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
@@ -126,6 +130,7 @@ __global__ void __launch_bounds__(GS_BLOCK) render_bwd_kernel(
       const float alpha = fminf(0.99f, co.w * G);
       const bool valid = (contributor < last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
       if (!__any(valid)) continue;
+      if (VARIANT == 2) { T += G; continue; }
 
       float v_mx = 0.f, v_my = 0.f, v_cxx = 0.f, v_cxy = 0.f, v_cyy = 0.f, v_op = 0.f;
       float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_id = 0.f;
@@ -173,6 +178,24 @@ __global__ void __launch_bounds__(GS_BLOCK) render_bwd_kernel(
         v_cyy = -0.5f * gdy * dy * dL_dG;
         v_op = G * dL_dalpha;
       }
+      if (VARIANT == 4) {  // every touched lane adds straight into the LDS accumulator (no cross-lane reduction)
+        if (valid) {
+          float* row = &s_acc[j * ACC_STRIDE];
+          atomicAdd(&row[GR_MX], v_mx);
+          atomicAdd(&row[GR_MY], v_my);
+          atomicAdd(&row[GR_CXX], v_cxx);
+          atomicAdd(&row[GR_CXY], v_cxy);
+          atomicAdd(&row[GR_CYY], v_cyy);
+          atomicAdd(&row[GR_OP], v_op);
+          atomicAdd(&row[GR_CR], v_c0);
+          atomicAdd(&row[GR_CG], v_c1);
+          atomicAdd(&row[GR_CB], v_c2);
+          if (HAS_INVDEPTH) atomicAdd(&row[GR_ID], v_id);
+          row[GR_N] = 1.0f;
+        }
+        continue;
+      }
+      if (VARIANT == 1) { T += (v_mx + v_my + v_cxx + v_cxy + v_cyy + v_op + v_c0 + v_c1 + v_c2 + v_id) * 1e-30f; continue; }
       v_mx = wave_sum_to_lane63(v_mx);
       v_my = wave_sum_to_lane63(v_my);
       v_cxx = wave_sum_to_lane63(v_cxx);
@@ -183,6 +206,7 @@ __global__ void __launch_bounds__(GS_BLOCK) render_bwd_kernel(
       v_c1 = wave_sum_to_lane63(v_c1);
       v_c2 = wave_sum_to_lane63(v_c2);
       if (HAS_INVDEPTH) v_id = wave_sum_to_lane63(v_id);
+      if (VARIANT == 3) { T += (v_mx + v_my + v_cxx + v_cxy + v_cyy + v_op + v_c0 + v_c1 + v_c2 + v_id) * 1e-30f; continue; }
       if (lane == 63) {
         atomicAdd(&s_acc[j * ACC_STRIDE + GR_MX], v_mx);
         atomicAdd(&s_acc[j * ACC_STRIDE + GR_MY], v_my);
@@ -207,16 +231,22 @@ __global__ void __launch_bounds__(GS_BLOCK) render_bwd_kernel(
       }
     }
   }
+  if (VARIANT != 0 && T == 123.456f) atomicAdd(&grad_rows[0], T + acc0 + acc1 + acc2 + accD);
 }
 
 int launch_render_bwd(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                       const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                       const float* dL_dpix, const float* dL_dinvdepth, float* grad_rows, hipStream_t s) {
-  if (dL_dinvdepth)
-    hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(grid_x * grid_y), dim3(GS_BLOCK), 0, s, ranges, point_list, W, H,
-                       grid_x, splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, grad_rows);
-  else
-    hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(grid_x * grid_y), dim3(GS_BLOCK), 0, s, ranges, point_list, W, H,
-                       grid_x, splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, grad_rows);
+  static const int variant = getenv("GS_BWD_VARIANT") ? atoi(getenv("GS_BWD_VARIANT")) : 0;
+#define GS_LAUNCH_BWD(INV, VAR)                                                                                          \
+  hipLaunchKernelGGL((render_bwd_kernel<INV, VAR>), dim3(grid_x * grid_y), dim3(GS_BLOCK), 0, s, ranges, point_list, W, H, \
+                     grid_x, splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, grad_rows)
+  if (variant == 1) GS_LAUNCH_BWD(true, 1);
+  else if (variant == 2) GS_LAUNCH_BWD(true, 2);
+  else if (variant == 3) GS_LAUNCH_BWD(true, 3);
+  else if (variant == 4) GS_LAUNCH_BWD(true, 4);
+  else if (dL_dinvdepth) GS_LAUNCH_BWD(true, 0);
+  else GS_LAUNCH_BWD(false, 0);
+#undef GS_LAUNCH_BWD
   return 0;
 }
