@@ -1,6 +1,7 @@
 // gs_api.hip - extern "C" entry points of libgsplat_hip.so for the rasterizer (include/gsplat.h).
 // Argument checking, scratch carving and launch orchestration only; kernels live in the other files.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gs_common.h"
@@ -193,8 +194,14 @@ int gs_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, con
   if (num_rendered > 0) {
     {
       GS_PROF(ST_RENDER_BWD, s);
-      launch_render_bwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
-                        dL_dinvdepth, rows, s);
+      // GS_BWD_KERNEL=quad selects the first-generation kernel (one pixel per lane, four waves per tile)
+      static const bool quad = getenv("GS_BWD_KERNEL") && !strcmp(getenv("GS_BWD_KERNEL"), "quad");
+      if (quad)
+        launch_render_bwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
+                          dL_dinvdepth, rows, s);
+      else
+        launch_render_bwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
+                               dL_dinvdepth, rows, s);
     }
     GS_LAUNCH_CHECK(s, v->debug);
   }

@@ -217,6 +217,10 @@ int launch_render_bwd(const uint2* ranges, const uint32_t* point_list, int W, in
                       const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                       const float* dL_dpix, const float* dL_dinvdepth, float* grad_rows, hipStream_t s);
 
+int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
+                           const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                           const float* dL_dpix, const float* dL_dinvdepth, float* grad_rows, hipStream_t s);
+
 struct PreprocessBwdArgs {
   int P, D, M;
   const float* means3D;

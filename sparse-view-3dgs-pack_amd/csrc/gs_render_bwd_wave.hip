@@ -1,0 +1,237 @@
+// gs_render_bwd_wave.hip - backward blend, "one wave64 per tile, four pixels per lane".
+//
+// Measured on the first backward kernel (gs_render_bwd.hip, one pixel per lane, four waves per tile): of
+// 1.40 ms, the per-pair alpha test costs 0.31 ms, the gradient math 0.30 ms and the cross-lane reduction of
+// the ten per-Gaussian sums 0.61 ms (+0.18 ms LDS accumulate / flush).  The reduction is paid once per
+// (wave, Gaussian) pair with a touched lane, i.e. up to four times per (tile, Gaussian).
+// Here ONE wave owns the whole 16x16 tile: lane l holds the pixel at the same position of each of the four
+// 8x8 quadrants.  A Gaussian's contributions to up to four pixels are summed in registers for free, the
+// wave reduces once per (tile, Gaussian), and - because the wave total IS the tile total - the ten sums go
+// straight to memory as global atomics into one Gaussian's 64-byte gradient row (3 instructions, 10 lanes): no
+// LDS accumulator, no zeroing, no flush pass, no workgroup barrier (a 64-thread workgroup is one wave).
+// Replaces renderCUDA<3> backward (backward.cu:452-638); per-pixel recurrences are unchanged.
+#include "gs_common.h"
+
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dppw(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
+}
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+// v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b; the sum then holds a's lane-pair sums in lanes
+// 0..31 and b's in lanes 32..63: TWO values halve their lane count for one swap + one add
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  const uint2v r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  // NB: element access as r[0]/r[1] + __uint_as_float; `bit_cast(float, r.x) + bit_cast(float, r.y)` is miscompiled
+  // by hipcc 7.2 into x + x (checked in the ISA)
+  const unsigned x = r[0], y = r[1];
+  return __uint_as_float(x) + __uint_as_float(y);
+}
+// v_permlane16_swap: odd rows of a <-> even rows of b; with a = (u | w), b = (x | y) as produced by swap32_add the
+// sum holds u, x, w, y in rows 0..3 (16 lanes each)
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  const uint2v r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  // NB: element access as r[0]/r[1] + __uint_as_float; `bit_cast(float, r.x) + bit_cast(float, r.y)` is miscompiled
+  // by hipcc 7.2 into x + x (checked in the ISA)
+  const unsigned x = r[0], y = r[1];
+  return __uint_as_float(x) + __uint_as_float(y);
+}
+// inclusive scan inside each row of 16 lanes: lane 15 of every row ends with the row total
+__device__ __forceinline__ float row_total_in_lane15(float v) {
+  v += dppw<0x111, 0xf, true>(v);  // row_shr:1
+  v += dppw<0x112, 0xf, true>(v);  // row_shr:2
+  v += dppw<0x114, 0xf, true>(v);  // row_shr:4
+  v += dppw<0x118, 0xf, true>(v);  // row_shr:8
+  return v;
+}
+
+#define WB 64  // batch = one list entry per lane
+
+template <bool HAS_INVDEPTH>
+__global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
+    const Splat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    const float* __restrict__ dL_invdepths, float* __restrict__ grad_rows) {
+  __shared__ float4 s_a[WB];  // x, y, invdepth, -
+  __shared__ float4 s_c[WB];  // conic, opacity
+  __shared__ float4 s_k[WB];  // rgb
+  __shared__ uint32_t s_id[WB];
+
+  const int tile = blockIdx.x;
+  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+  const int lane = threadIdx.x;
+  const uint2 range = ranges[tile];
+  const int n = (int)(range.y - range.x);
+  if (n == 0) return;
+
+  // slot s = quadrant (s&1, s>>1); this lane's pixel inside every quadrant is (lane&7, lane>>3)
+  const int px0 = tile_x * TILE_X + (lane & 7), py0 = tile_y * TILE_Y + (lane >> 3);
+  const float pixfx0 = (float)px0, pixfy0 = (float)py0;
+  const size_t HW = (size_t)H * W;
+
+  float T[4], Tbg[4], dLp0[4], dLp1[4], dLp2[4], dLinv[4];  // Tbg = T_final * (bg . dL_dpixel)
+  float acc0[4], acc1[4], acc2[4], accD[4], lastc0[4], lastc1[4], lastc2[4], lastD[4], last_alpha[4];
+  uint32_t lastc[4];
+  uint32_t lmax = 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int px = px0 + (s & 1) * 8, py = py0 + (s >> 1) * 8;
+    const bool inside = px < W && py < H;
+    const int pix_id = W * py + px;
+    T[s] = inside ? final_Ts[pix_id] : 0.f;
+    lastc[s] = inside ? n_contrib[pix_id] : 0u;
+    lmax = max(lmax, lastc[s]);
+    dLp0[s] = inside ? dL_dpixels[pix_id] : 0.f;
+    dLp1[s] = inside ? dL_dpixels[HW + pix_id] : 0.f;
+    dLp2[s] = inside ? dL_dpixels[2 * HW + pix_id] : 0.f;
+    dLinv[s] = (HAS_INVDEPTH && inside) ? dL_invdepths[pix_id] : 0.f;
+    float b = 0;
+    b += bg[0] * dLp0[s];
+    b += bg[1] * dLp1[s];
+    b += bg[2] * dLp2[s];
+    Tbg[s] = T[s] * b;
+    acc0[s] = acc1[s] = acc2[s] = accD[s] = 0.f;
+    lastc0[s] = lastc1[s] = lastc2[s] = lastD[s] = last_alpha[s] = 0.f;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, off, 64));
+  lmax = __builtin_amdgcn_readfirstlane(lmax);
+  if (lmax == 0) return;
+
+  const float ddelx_dx = 0.5f * W;
+  const float ddely_dy = 0.5f * H;
+  const int q0 = n - (int)lmax;  // entries q < q0 (counted from the back) are behind every pixel's last contributor
+  const int rounds = (n + WB - 1) / WB;
+
+  // prefetch the first needed batch
+  float4 ra, rc, rk;
+  uint32_t rid = 0;
+  ra = rc = rk = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int q = (q0 / WB) * WB + lane;
+    if (q < n) {
+      rid = point_list[range.y - q - 1];
+      const float4* rec = reinterpret_cast<const float4*>(&splat[rid]);
+      ra = rec[0]; rc = rec[1]; rk = rec[2];
+    }
+  }
+  for (int i = q0 / WB; i < rounds; i++) {
+    __syncthreads();  // (single wave) previous batch fully consumed
+    s_id[lane] = rid;
+    s_a[lane] = make_float4(ra.x, ra.y, ra.w, 0.f);
+    s_c[lane] = rc;
+    s_k[lane] = rk;
+    __syncthreads();
+    {
+      const int q = (i + 1) * WB + lane;
+      if (q < n) {
+        rid = point_list[range.y - q - 1];
+        const float4* rec = reinterpret_cast<const float4*>(&splat[rid]);
+        ra = rec[0]; rc = rec[1]; rk = rec[2];
+      }
+    }
+    const int cnt = min(WB, n - i * WB);
+    const int jbeg = max(0, q0 - i * WB);
+    for (int j = jbeg; j < cnt; j++) {
+      const uint32_t contributor = (uint32_t)(n - 1 - (i * WB + j));
+      const float4 a = s_a[j];
+      const float4 co = s_c[j];
+      // alpha test for the four pixels of this lane
+      float G[4], alpha[4];
+      bool valid[4];
+      bool any_valid = false;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
+        const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));
+        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        G[s] = __expf(power);
+        alpha[s] = fminf(0.99f, co.w * G[s]);
+        valid[s] = (contributor < lastc[s]) && (power <= 0.0f) && (alpha[s] >= 1.0f / 255.0f);
+        any_valid |= valid[s];
+      }
+      if (!__any(any_valid)) continue;
+
+      float v_mx = 0.f, v_my = 0.f, v_cxx = 0.f, v_cxy = 0.f, v_cyy = 0.f, v_op = 0.f;
+      float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_id = 0.f;
+      const float4 k = s_k[j];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        if (!__any(valid[s])) continue;  // wave-uniform: quadrant not touched by this Gaussian
+        if (valid[s]) {
+          const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
+          const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));
+          const float om = 1.f - alpha[s];
+          float rinv = __builtin_amdgcn_rcpf(om);
+          rinv = fmaf(rinv, fmaf(-om, rinv, 1.0f), rinv);
+          T[s] = T[s] * rinv;
+          const float dchannel_dcolor = alpha[s] * T[s];
+          float dL_dalpha = 0.0f;
+          const float oma = 1.f - last_alpha[s];
+          acc0[s] = last_alpha[s] * lastc0[s] + oma * acc0[s];
+          lastc0[s] = k.x;
+          dL_dalpha += (k.x - acc0[s]) * dLp0[s];
+          v_c0 += dchannel_dcolor * dLp0[s];
+          acc1[s] = last_alpha[s] * lastc1[s] + oma * acc1[s];
+          lastc1[s] = k.y;
+          dL_dalpha += (k.y - acc1[s]) * dLp1[s];
+          v_c1 += dchannel_dcolor * dLp1[s];
+          acc2[s] = last_alpha[s] * lastc2[s] + oma * acc2[s];
+          lastc2[s] = k.z;
+          dL_dalpha += (k.z - acc2[s]) * dLp2[s];
+          v_c2 += dchannel_dcolor * dLp2[s];
+          if (HAS_INVDEPTH) {
+            const float invd = a.z;
+            accD[s] = last_alpha[s] * lastD[s] + oma * accD[s];
+            lastD[s] = invd;
+            dL_dalpha += (invd - accD[s]) * dLinv[s];
+            v_id += dchannel_dcolor * dLinv[s];
+          }
+          dL_dalpha *= T[s];
+          last_alpha[s] = alpha[s];
+          dL_dalpha += -Tbg[s] * rinv;  // (-T_final / (1 - alpha)) * bg_dot_dpixel, backward.cu:613
+          const float dL_dG = co.w * dL_dalpha;
+          const float gdx = G[s] * dx;
+          const float gdy = G[s] * dy;
+          const float dG_ddelx = -gdx * co.x - gdy * co.y;
+          const float dG_ddely = -gdy * co.z - gdx * co.y;
+          v_mx += dL_dG * dG_ddelx * ddelx_dx;
+          v_my += dL_dG * dG_ddely * ddely_dy;
+          v_cxx += -0.5f * gdx * dx * dL_dG;
+          v_cxy += -0.5f * gdx * dy * dL_dG;
+          v_cyy += -0.5f * gdy * dy * dL_dG;
+          v_op += G[s] * dL_dalpha;
+        }
+      }
+      // One reduction per (tile, Gaussian): 5 + 3 swap-adds pack the ten sums into three registers holding one
+      // value per row of 16 lanes, 3 x 4 row shifts finish them (28 VALU ops instead of 10 x 6 DPP adds), and
+      // lane 15 of every row adds its total to the Gaussian's 64-byte gradient row.
+      const float s0 = swap32_add(v_mx, v_cxx), s1 = swap32_add(v_my, v_cxy);   // (0|2) (1|3)
+      const float s2 = swap32_add(v_cyy, v_c0), s3 = swap32_add(v_op, v_c1);    // (4|6) (5|7)
+      const float s4 = swap32_add(v_c2, v_id);                                  // (8|9)
+      const float t0 = row_total_in_lane15(swap16_add(s0, s1));                 // rows: 0 1 2 3
+      const float t1 = row_total_in_lane15(swap16_add(s2, s3));                 // rows: 4 5 6 7
+      const float t2 = row_total_in_lane15(swap16_add(s4, 0.f));                // rows: 8 - 9 -
+      if ((lane & 15) == 15) {
+        float* row = grad_rows + (size_t)s_id[j] * GR_STRIDE;
+        const int q = lane >> 4;
+        if (t0 != 0.0f) atomicAdd(row + q, t0);
+        if (t1 != 0.0f) atomicAdd(row + 4 + q, t1);
+        if (!(q & 1) && (HAS_INVDEPTH || q == 0) && t2 != 0.0f) atomicAdd(row + 8 + (q >> 1), t2);
+      }
+    }
+  }
+}
+
+int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
+                           const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                           const float* dL_dpix, const float* dL_dinvdepth, float* grad_rows, hipStream_t s) {
+  if (dL_dinvdepth)
+    hipLaunchKernelGGL(render_bwd_wave_kernel<true>, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x,
+                       splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, grad_rows);
+  else
+    hipLaunchKernelGGL(render_bwd_wave_kernel<false>, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x,
+                       splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, grad_rows);
+  return 0;
+}
