@@ -160,8 +160,14 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
   GS_LAUNCH_CHECK(s, v->debug);
   {
     GS_PROF(ST_RENDER_FWD, s);
-    launch_render_fwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
-                      out_invdepth, s);
+    // GS_FWD_KERNEL=quad selects the first-generation kernel (one pixel per lane, four waves per tile)
+    static const bool quad = getenv("GS_FWD_KERNEL") && !strcmp(getenv("GS_FWD_KERNEL"), "quad");
+    if (quad)
+      launch_render_fwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
+                        out_invdepth, s);
+    else
+      launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
+                             out_invdepth, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;

@@ -1,0 +1,130 @@
+// gs_render_fwd_wave.hip - forward blend, "one wave64 per tile, four pixels per lane".
+//
+// Same decomposition as gs_render_bwd_wave.hip: a 64-thread workgroup (one wave) owns a 16x16 tile, lane l
+// blends the pixel at the same position of each 8x8 quadrant.  Compared with the four-waves-per-tile kernel
+// (gs_render_fwd.hip) the per-Gaussian LDS broadcast reads and loop overhead are paid once per tile instead
+// of once per quadrant, batches are 64 entries (a tile stops within 64 entries of its last live pixel, not
+// 256) and there is no workgroup barrier on which three waves wait for the slowest one.
+// Replaces renderCUDA<3> forward (forward.cu:274-397); per-pixel arithmetic and stopping rules unchanged.
+#include "gs_common.h"
+
+#define WB 64
+
+__global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __restrict__ ranges,
+                                                             const uint32_t* __restrict__ point_list, int W, int H,
+                                                             int grid_x, const Splat* __restrict__ splat,
+                                                             const float* __restrict__ bg, float* __restrict__ final_T,
+                                                             uint32_t* __restrict__ n_contrib,
+                                                             float* __restrict__ out_color,
+                                                             float* __restrict__ out_invdepth) {
+  __shared__ float4 s_a[WB];  // x, y, invdepth, -
+  __shared__ float4 s_c[WB];  // conic, opacity
+  __shared__ float4 s_k[WB];  // rgb
+
+  const int tile = blockIdx.x;
+  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+  const int lane = threadIdx.x;
+  const int px0 = tile_x * TILE_X + (lane & 7), py0 = tile_y * TILE_Y + (lane >> 3);
+  const float pixfx0 = (float)px0, pixfy0 = (float)py0;
+
+  const uint2 range = ranges[tile];
+  const int n = (int)(range.y - range.x);
+  const int rounds = (n + WB - 1) / WB;
+
+  float T[4], C0[4], C1[4], C2[4], D[4];
+  uint32_t last_contributor[4];
+  bool done[4], inside[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int px = px0 + (s & 1) * 8, py = py0 + (s >> 1) * 8;
+    inside[s] = px < W && py < H;
+    done[s] = !inside[s];
+    T[s] = 1.0f;
+    C0[s] = C1[s] = C2[s] = D[s] = 0.f;
+    last_contributor[s] = 0;
+  }
+
+  float4 ra, rc, rk;
+  ra = rc = rk = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < n) {
+    const float4* rec = reinterpret_cast<const float4*>(&splat[point_list[range.x + lane]]);
+    ra = rec[0]; rc = rec[1]; rk = rec[2];
+  }
+  for (int i = 0; i < rounds; i++) {
+    // the whole tile is done (forward.cu:326-328)
+    if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
+    __syncthreads();  // single wave: previous batch fully consumed
+    s_a[lane] = make_float4(ra.x, ra.y, ra.w, 0.f);
+    s_c[lane] = rc;
+    s_k[lane] = rk;
+    __syncthreads();
+    {
+      const int nxt = (i + 1) * WB + lane;
+      if (nxt < n) {
+        const float4* rec = reinterpret_cast<const float4*>(&splat[point_list[range.x + nxt]]);
+        ra = rec[0]; rc = rec[1]; rk = rec[2];
+      }
+    }
+    const int cnt = min(WB, n - i * WB);
+    for (int j = 0; j < cnt; j++) {
+      const uint32_t contributor = (uint32_t)(i * WB + j + 1);
+      const float4 a = s_a[j];
+      const float4 co = s_c[j];
+      float alpha[4];
+      bool hit[4];
+      bool any_hit = false;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
+        const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));
+        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        alpha[s] = fminf(0.99f, co.w * __expf(power));
+        hit[s] = !done[s] && (power <= 0.0f) && (alpha[s] >= 1.0f / 255.0f);
+        any_hit |= hit[s];
+      }
+      if (!__any(any_hit)) continue;
+      const float4 k = s_k[j];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        if (hit[s]) {
+          const float test_T = T[s] * (1 - alpha[s]);
+          if (test_T < 0.0001f) {
+            done[s] = true;
+          } else {
+            const float w = alpha[s] * T[s];
+            C0[s] += k.x * w;
+            C1[s] += k.y * w;
+            C2[s] += k.z * w;
+            D[s] += a.z * w;
+            T[s] = test_T;
+            last_contributor[s] = contributor;
+          }
+        }
+      }
+      if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
+    }
+  }
+  const size_t HW = (size_t)H * W;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    if (inside[s]) {
+      const int px = px0 + (s & 1) * 8, py = py0 + (s >> 1) * 8;
+      const int pix_id = W * py + px;
+      final_T[pix_id] = T[s];
+      n_contrib[pix_id] = last_contributor[s];
+      out_color[pix_id] = C0[s] + T[s] * bg0;
+      out_color[HW + pix_id] = C1[s] + T[s] * bg1;
+      out_color[2 * HW + pix_id] = C2[s] + T[s] * bg2;
+      if (out_invdepth) out_invdepth[pix_id] = D[s];
+    }
+  }
+}
+
+int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
+                           const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
+                           float* out_invdepth, hipStream_t s) {
+  hipLaunchKernelGGL(render_fwd_wave_kernel, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x, splat,
+                     bg, final_T, n_contrib, out_color, out_invdepth);
+  return 0;
+}
