@@ -54,6 +54,7 @@ def build_workload(cfg, device, rank, world, seed=0):
     import lgdwt_loss
     from gsplat_amd import synthetic
     from gsplat_amd.trainer import GaussianModelLite, Trainer, camera_to, render
+    from gsplat_amd._lib import hip_api as hip_api_
     from simple_knn._C import distCUDA2
 
     P, W, H, dwt, patch, _ = CONFIGS[cfg]
@@ -63,7 +64,7 @@ def build_workload(cfg, device, rank, world, seed=0):
     bg = torch.zeros(3, device=device)
     # ground truth: renders of a differently seeded scene, quantised to 8 bit like PILtoTorch
     gt_scene = synthetic.trained_like(P, seed=seed + 1, knn=knn)
-    gt_model = GaussianModelLite(gt_scene, device)
+    gt_model = GaussianModelLite(gt_scene, device, api=hip_api_())
     # every rank only ever touches cameras rank, rank+world, ...: render just those
     needed = sorted({(k * world + rank) % len(cams) for k in range(len(cams))})
     gts = [None] * len(cams)
@@ -72,7 +73,7 @@ def build_workload(cfg, device, rank, world, seed=0):
             img = render(cams[ci], gt_model, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg)["render"]
             gts[ci] = (torch.round(img * 255.0) / 255.0).contiguous()
     del gt_model
-    model = GaussianModelLite(scene, device)
+    model = GaussianModelLite(scene, device, api=hip_api_())
     crit = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch)
     masks = None
     if patch:  # ELF / patch selection depends on the ground truth only: cached per camera
@@ -109,7 +110,7 @@ def cpu_baseline(cfg, scene, cam, gt, log):
     P, W, H, dwt, patch, _ = CONFIGS[cfg]
     orc = oracle_lib.get()
     cpu = torch.device("cpu")
-    model = GaussianModelLite({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in scene.items()}, cpu)
+    model = GaussianModelLite({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in scene.items()}, cpu, api=orc.api)
     crit = LGDWTCriterion(LossOps(orc.api), dwt_enable=dwt, patch_dwt_enable=patch)
     cam = camera_to(cam, cpu)
     gt = gt.cpu()
@@ -245,7 +246,7 @@ def main():
             "config": {"workload": desc, "gaussians": P, "image": "%dx%d" % (W, H), "sh_degree": 3,
                        "scene": "trained-like (SURVEY 8d), seed 0", "cameras_per_step": world,
                        "num_rendered_last_view": R_last, "loss": "L1+SSIM" + ("+DWT2" if dwt else "") +
-                       ("+patchDWT" if patch else ""), "optimizer": "Adam (torch, eps 1e-15)",
+                       ("+patchDWT" if patch else ""), "optimizer": "Adam eps 1e-15, fused HIP kernel over the flat buffer",
                        "parallelism": "camera-sharded dp%d, one all-reduce of 59 f32/Gaussian" % world},
             "roofline": roofline,
             "stages": stages,

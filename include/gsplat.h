@@ -227,6 +227,20 @@ int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
                 const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                 void* stream);
 
+/* ---- optimiser (caller side of the path): fused Adam over ONE flat fp32 parameter buffer.
+ * Replaces torch.optim.Adam(lr=0, eps=1e-15) with per-group learning rates,
+ * LGDWT-GS/scene/gaussian_model.py:183-193 + train.py:279-288.  Segment k covers elements [begin, end);
+ * element i uses lr_a, or lr_b when period > 0 and (i - begin) % period >= split (interleaved SH DC / rest). */
+typedef struct GsAdamSeg {
+  int64_t begin, end;
+  float lr_a, lr_b;
+  int32_t period, split;
+} GsAdamSeg;
+/* segs is a HOST array (<= 8 entries, copied into the launch); step = 1-based iteration for the bias correction. */
+int gs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
+                 void* stream);
+
 /* ---- optional per-stage timing (HIP events recorded on the caller's stream around every kernel
  * group).  Off by default.  bench.py enables it over the timed region to get each kernel's average
  * launch duration on the stream it is launched on.  (No reference counterpart: the reference only

@@ -385,4 +385,26 @@ int gso_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int
   }
   return GS_OK;
 }
+
+/* torch.optim.Adam arithmetic (no amsgrad / weight decay) over a flat buffer with a learning-rate segment table;
+ * restates the update of LGDWT-GS/scene/gaussian_model.py:183-193 + train.py:279-288 (pinned against
+ * torch.optim.Adam itself in tests/test_adam.py) */
+int gso_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const GsAdamSeg* segs, int32_t nseg,
+                  float b1, float b2, float eps, int32_t step, void*) {
+  if (!p || !g || !m || !v) return GS_E_NULL;
+  if (step < 1 || nseg < 0 || nseg > 8) return GS_E_SHAPE;
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  const float inv_bc1 = (float)(1.0 / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  for (int64_t i = 0; i < n; i++) {
+    float lr = 0.f;
+    for (int k = 0; k < nseg; k++)
+      if (i >= segs[k].begin && i < segs[k].end)
+        lr = (segs[k].period > 0 && (int)((i - segs[k].begin) % segs[k].period) >= segs[k].split) ? segs[k].lr_b : segs[k].lr_a;
+    m[i] = b1 * m[i] + (1.f - b1) * g[i];
+    v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
+    const float denom = sqrtf(v[i]) * inv_sqrt_bc2 + eps;
+    p[i] = p[i] - (lr * inv_bc1) * (m[i] / denom);
+  }
+  return GS_OK;
+}
 }

@@ -24,6 +24,7 @@ enum GsStage {
   ST_PATCH,
   ST_ELF,
   ST_DWT1,
+  ST_ADAM,
   ST_COUNT
 };
 

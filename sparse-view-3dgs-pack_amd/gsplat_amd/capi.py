@@ -69,6 +69,11 @@ class GsGrads(C.Structure):
     ]
 
 
+class GsAdamSeg(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr_a", C.c_float), ("lr_b", C.c_float),
+                ("period", C.c_int32), ("split", C.c_int32)]
+
+
 _P = C.c_void_p
 _I32 = C.c_int32
 _I64 = C.c_int64
@@ -103,6 +108,7 @@ PROTOTYPES = {
     "patch_dwt_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "ssim_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "ssim_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "adam_step": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P]),
     "profile_enable": (C.c_int, [_I32]),
     "profile_reset": (C.c_int, []),
     "profile_stage_count": (C.c_int, []),

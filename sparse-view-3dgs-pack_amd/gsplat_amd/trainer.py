@@ -19,27 +19,85 @@ import math
 import torch
 import torch.distributed as dist
 
-FIELDS = (("xyz", 3), ("f_dc", 3), ("f_rest", 45), ("opacity", 1), ("scaling", 3), ("rotation", 4))
+# flat layout: one segment per field; the SH block keeps DC and rest interleaved [P,16,3] exactly as the
+# rasterizer reads it, so get_features is a view (the reference concatenates _features_dc/_features_rest
+# every step: gaussian_model.py:119-123).  The two learning rates of that block alternate with period 48.
+FIELDS = (("xyz", 3), ("features", 48), ("opacity", 1), ("scaling", 3), ("rotation", 4))
 FLOATS_PER_GAUSSIAN = sum(n for _, n in FIELDS)  # 59
+# LGDWT-GS/arguments/__init__.py:79-86 (position_lr_init, feature_lr, opacity_lr, scaling_lr, rotation_lr)
+LRS = {"xyz": 0.00016, "f_dc": 0.0025, "f_rest": 0.0025 / 20.0, "opacity": 0.025, "scaling": 0.005, "rotation": 0.001}
+
+
+def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """get_expon_lr_func of LGDWT-GS/utils/general_utils.py:29-62 (pinned by tests/golden/schedule.npz)."""
+    import numpy as np
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    if lr_delay_steps > 0:
+        delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+    else:
+        delay_rate = 1.0
+    t = np.clip(step / max_steps, 0, 1)
+    log_lerp = np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+    return float(delay_rate * log_lerp)
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr=0.0, eps=1e-15) with the reference's per-group learning rates
+    (gaussian_model.py:183-193), as ONE fused pass over the flat buffers through gs_adam_step."""
+
+    def __init__(self, api, model, betas=(0.9, 0.999), eps=1e-15):
+        from .capi import GsAdamSeg
+        self.api, self.model, self.betas, self.eps = api, model, betas, eps
+        self.exp_avg = torch.zeros_like(model.flat)
+        self.exp_avg_sq = torch.zeros_like(model.flat)
+        self.t = 0
+        self.lr = dict(LRS)
+        self.lr["xyz"] = LRS["xyz"] * model.spatial_lr_scale
+        self._Seg = GsAdamSeg
+
+    def segments(self):
+        P = self.model.P
+        segs = (self._Seg * len(FIELDS))()
+        off = 0
+        for k, (name, n) in enumerate(FIELDS):
+            segs[k].begin, segs[k].end = off, off + P * n
+            if name == "features":
+                segs[k].lr_a, segs[k].lr_b, segs[k].period, segs[k].split = self.lr["f_dc"], self.lr["f_rest"], 48, 3
+            else:
+                segs[k].lr_a, segs[k].lr_b, segs[k].period, segs[k].split = self.lr[name], 0.0, 0, 0
+            off += P * n
+        return segs
+
+    def step(self):
+        import ctypes as C
+        m = self.model
+        self.t += 1
+        segs = self.segments()
+        stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
+        self.api.call("adam_step", m.flat.data_ptr(), m.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                      self.exp_avg_sq.data_ptr(), m.flat.numel(), segs, len(FIELDS), self.betas[0], self.betas[1],
+                      self.eps, self.t, stream)
 
 
 class GaussianModelLite:
     """Raw (pre-activation) parameters of P Gaussians at max SH degree 3."""
 
-    def __init__(self, scene, device, spatial_lr_scale=1.0):
+    def __init__(self, scene, device, spatial_lr_scale=1.0, api=None):
         """scene: dict of ACTIVATED tensors as produced by gsplat_amd.synthetic (means3D, scales,
-        rotations, opacities, shs[P,16,3]) - converted back to raw form as create_from_pcd would hold them."""
+        rotations, opacities, shs[P,16,3]) - converted back to raw form as create_from_pcd would hold them.
+        api: C-ABI implementation that provides adam_step (None: torch.optim.Adam on the same flat buffers)."""
         P = scene["means3D"].shape[0]
         self.P = P
         self.device = device
+        self.spatial_lr_scale = spatial_lr_scale
         self.max_sh_degree = 3
         self.active_sh_degree = scene.get("sh_degree", 3)
         self.flat = torch.zeros((P * FLOATS_PER_GAUSSIAN,), dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros_like(self.flat)
         self.params = {}
         off = 0
-        shapes = {"xyz": (P, 3), "f_dc": (P, 1, 3), "f_rest": (P, 15, 3), "opacity": (P, 1), "scaling": (P, 3),
-                  "rotation": (P, 4)}
+        shapes = {"xyz": (P, 3), "features": (P, 16, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
         for name, n in FIELDS:
             view = self.flat[off:off + P * n].view(shapes[name])
             p = torch.nn.Parameter(view, requires_grad=True)
@@ -48,20 +106,34 @@ class GaussianModelLite:
             off += P * n
         with torch.no_grad():
             self.params["xyz"].copy_(scene["means3D"])
-            self.params["f_dc"].copy_(scene["shs"][:, 0:1, :])
-            self.params["f_rest"].copy_(scene["shs"][:, 1:, :])
+            self.params["features"].copy_(scene["shs"])
             op = scene["opacities"].clamp(1e-6, 1 - 1e-6)
             self.params["opacity"].copy_(torch.log(op / (1 - op)))
             self.params["scaling"].copy_(torch.log(scene["scales"]))
             self.params["rotation"].copy_(scene["rotations"])
-        lrs = {"xyz": 0.00016 * spatial_lr_scale, "f_dc": 0.0025, "f_rest": 0.0025 / 20.0, "opacity": 0.025,
-               "scaling": 0.005, "rotation": 0.001}
-        groups = [{"params": [self.params[n]], "lr": lrs[n], "name": n} for n, _ in FIELDS]
-        # fused=True: one multi-tensor kernel per step instead of ~10 foreach passes over the 59 floats/Gaussian
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=(device.type == "cuda"))
+        if api is not None:
+            self.optimizer = FlatAdam(api, self)
+        else:
+            # plain torch Adam on the same storage (used to pin FlatAdam): f_dc / f_rest as strided views
+            f = self.params["features"]
+            groups = [{"params": [self.params["xyz"]], "lr": LRS["xyz"] * spatial_lr_scale, "name": "xyz"},
+                      {"params": [self.params["opacity"]], "lr": LRS["opacity"], "name": "opacity"},
+                      {"params": [self.params["scaling"]], "lr": LRS["scaling"], "name": "scaling"},
+                      {"params": [self.params["rotation"]], "lr": LRS["rotation"], "name": "rotation"}]
+            self.optimizer = _TorchAdamWithFeatureSplit(groups, f, LRS["f_dc"], LRS["f_rest"])
         self.xyz_gradient_accum = torch.zeros((P, 1), device=device)
         self.denom = torch.zeros((P, 1), device=device)
         self.max_radii2D = torch.zeros((P,), device=device)
+
+    def update_learning_rate(self, iteration, position_lr_final=0.0000016, delay_mult=0.01, max_steps=30000):
+        """gaussian_model.py:213-223: exponential decay of the xyz learning rate."""
+        lr = expon_lr(iteration, LRS["xyz"] * self.spatial_lr_scale, position_lr_final * self.spatial_lr_scale,
+                      lr_delay_mult=delay_mult, max_steps=max_steps)
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.lr["xyz"] = lr
+        else:
+            self.optimizer.set_xyz_lr(lr)
+        return lr
 
     # activations, gaussian_model.py:102-135
     @property
@@ -82,7 +154,7 @@ class GaussianModelLite:
 
     @property
     def get_features(self):
-        return torch.cat((self.params["f_dc"], self.params["f_rest"]), dim=1)
+        return self.params["features"]
 
     def zero_grad(self):
         # gradients live in one persistent flat buffer (views), so "set_to_none" is replaced by a memset
@@ -94,6 +166,32 @@ class GaussianModelLite:
         vm = visible_mask.to(torch.float32).unsqueeze(-1)
         self.xyz_gradient_accum += torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * vm
         self.denom += vm
+
+
+class _TorchAdamWithFeatureSplit:
+    """Reference optimiser on the flat storage: torch.optim.Adam for the four plain groups and for f_dc / f_rest
+    as separate contiguous copies that are written back (the fused torch kernels need dense tensors)."""
+
+    def __init__(self, groups, features, lr_dc, lr_rest):
+        self.features = features
+        self.f_dc = features.detach()[:, :1, :].clone().requires_grad_(True)
+        self.f_rest = features.detach()[:, 1:, :].clone().requires_grad_(True)
+        groups = groups + [{"params": [self.f_dc], "lr": lr_dc, "name": "f_dc"},
+                           {"params": [self.f_rest], "lr": lr_rest, "name": "f_rest"}]
+        self.opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    def set_xyz_lr(self, lr):
+        for g in self.opt.param_groups:
+            if g["name"] == "xyz":
+                g["lr"] = lr
+
+    def step(self):
+        self.f_dc.grad = self.features.grad[:, :1, :].contiguous()
+        self.f_rest.grad = self.features.grad[:, 1:, :].contiguous()
+        self.opt.step()
+        with torch.no_grad():
+            self.features[:, :1, :] = self.f_dc
+            self.features[:, 1:, :] = self.f_rest
 
 
 def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifier=1.0, antialiasing=False,

@@ -18,7 +18,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 P, W, H = int(os.environ.get("GS_P", 1000000)), 1920, 1080
 dev = torch.device("cuda")
 sc = synthetic.trained_like(P, seed=0, knn=lambda x: distCUDA2(x.to(dev)).cpu())
-model = GaussianModelLite(sc, dev)
+model = GaussianModelLite(sc, dev, api=hip_api())
 cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(W, H)]
 api = hip_api()
 g = torch.Generator().manual_seed(0)

@@ -20,7 +20,7 @@ def psnr(a, b):
     return 20 * math.log10(1.0 / math.sqrt(float(mse)))
 
 
-def run(device, Rasterizer, Settings, ops, iters, P=10000, W=400, H=400):
+def run(device, Rasterizer, Settings, ops, iters, P=10000, W=400, H=400, api=None):
     target = synthetic.trained_like(P, seed=1, scale_mult=1.0)
     g = torch.Generator().manual_seed(2)
     start = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in target.items()}
@@ -30,10 +30,10 @@ def run(device, Rasterizer, Settings, ops, iters, P=10000, W=400, H=400):
     cams_all = [camera_to(c, device) for c in synthetic.orbit_cameras(W, H)]
     train_idx, test_idx = [0, 8, 16], [4, 13, 21]          # "3-view" sparse setting + 3 held-out views
     bg = torch.zeros(3, device=device)
-    tm = GaussianModelLite(target, device)
+    tm = GaussianModelLite(target, device, api=api)
     with torch.no_grad():
         gt = {i: render(cams_all[i], tm, Rasterizer, Settings, bg)["render"].clone() for i in train_idx + test_idx}
-    model = GaussianModelLite(start, device)
+    model = GaussianModelLite(start, device, api=api)
     crit = LGDWTCriterion(ops, dwt_enable=True, patch_dwt_enable=True)
     tr = Trainer(model, [cams_all[i] for i in train_idx], [gt[i] for i in train_idx], crit, Rasterizer, Settings, bg)
 
@@ -47,8 +47,8 @@ def run(device, Rasterizer, Settings, ops, iters, P=10000, W=400, H=400):
 
 def test_training_psnr_parity_hip_vs_oracle(hip, oracle):
     iters = 60
-    h = run(torch.device("cuda"), dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, LossOps(hip.api), iters)
-    o = run(torch.device("cpu"), oracle.Rasterizer, oracle.Settings, LossOps(oracle.api), iters)
+    h = run(torch.device("cuda"), dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, LossOps(hip.api), iters, api=hip.api)
+    o = run(torch.device("cpu"), oracle.Rasterizer, oracle.Settings, LossOps(oracle.api), iters, api=oracle.api)
     print("PSNR before", h["p0"], o["p0"])
     print("PSNR after ", h["p1"], o["p1"])
     print("loss first/last", h["losses"][0], h["losses"][-1], o["losses"][0], o["losses"][-1])

@@ -13,7 +13,7 @@ def make_trainer(oracle, P=600, W=160, H=128, world_size=1, rank=0, seed=0, dwt=
     cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(W, H)[:4]]
     g = torch.Generator().manual_seed(5)
     gts = [torch.rand((3, H, W), generator=g) for _ in cams]
-    model = GaussianModelLite(sc, dev)
+    model = GaussianModelLite(sc, dev, api=oracle.api)
     crit = LGDWTCriterion(LossOps(oracle.api), dwt_enable=dwt, patch_dwt_enable=dwt)
     return Trainer(model, cams, gts, crit, oracle.Rasterizer, oracle.Settings, torch.zeros(3), rank, world_size)
 
