@@ -129,8 +129,8 @@ __global__ void __launch_bounds__(GS_BLOCK) scan_down_kernel(uint32_t* __restric
 
 // Stable scatter.  Phase 1: every wave ranks its 1024 keys in 16 rounds of 64 with wave-level
 // match-any (8 ballots per round; no barrier, LDS traffic stays inside the wave) and builds its private
-// digit histogram.  One barrier.  Phase 2: 256 threads turn the four wave histograms into per-wave
-// output bases.  One barrier.  Phase 3: every wave replays its rounds from registers and stores.
+// digit histogram.  Phase 2: 256 threads turn the four wave histograms into per-wave offsets inside the tile.
+// Phase 3: keys/values are exchanged through LDS into digit order and stored as contiguous runs.
 __global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __restrict__ kin,
                                                               const uint32_t* __restrict__ vin,  // NULL: value = index
                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
@@ -168,22 +168,55 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __
     if (valid && rank == 0) s_hist[wid][d] = before + (uint32_t)__popcll(peers);
   }
   __syncthreads();
+  // Phase 2: digit `tid`: wave prefixes, workgroup-local exclusive digit offset (scan over the 256 digit totals)
+  // and the distance from the local to the global position of that digit's run.
+  __shared__ uint32_t s_loc[RS_RADIX];    // local start of each digit's run inside the 4096-key tile
+  __shared__ uint32_t s_delta[RS_RADIX];  // global start - local start
+  __shared__ uint32_t s_wtot[GS_BLOCK / 64];
   {
-    const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid];
-    const uint32_t base = hist[(size_t)tid * nblk + blockIdx.x];
+    const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid], c3 = s_hist[3][tid];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    uint32_t inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wtot[wid] = inc;
     __syncthreads();
-    s_hist[0][tid] = base;
-    s_hist[1][tid] = base + c0;
-    s_hist[2][tid] = base + c0 + c1;
-    s_hist[3][tid] = base + c0 + c1 + c2;
+    uint32_t loc = inc - tot;
+    for (int w = 0; w < wid; w++) loc += s_wtot[w];
+    s_loc[tid] = loc;
+    s_delta[tid] = hist[(size_t)tid * nblk + blockIdx.x] - loc;
+    s_hist[0][tid] = loc;
+    s_hist[1][tid] = loc + c0;
+    s_hist[2][tid] = loc + c0 + c1;
+    s_hist[3][tid] = loc + c0 + c1 + c2;
   }
   __syncthreads();
+  // Phase 3: exchange through LDS so that every digit's keys are contiguous, then store: consecutive lanes write
+  // consecutive global addresses inside a digit run (a direct scatter writes 64 isolated 4-byte words per
+  // wave instruction).
+  __shared__ uint32_t s_key[RS_TILE];
+  __shared__ uint32_t s_val[RS_TILE];
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     if (pre[r] != 0xFFFFFFFFu) {
-      const uint32_t pos = s_hist[wid][(key[r] >> shift) & 0xFFu] + pre[r];
-      kout[pos] = key[r];
-      vout[pos] = val[r];
+      const uint32_t lp = s_hist[wid][(key[r] >> shift) & 0xFFu] + pre[r];
+      s_key[lp] = key[r];
+      s_val[lp] = val[r];
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = min((uint32_t)RS_TILE, n - t0);
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const uint32_t i = r * GS_BLOCK + tid;
+    if (i < cnt) {
+      const uint32_t k = s_key[i];
+      const uint32_t pos = i + s_delta[(k >> shift) & 0xFFu];
+      kout[pos] = k;
+      vout[pos] = s_val[i];
     }
   }
 }
@@ -286,7 +319,48 @@ int launch_bin_prepare(const GeomView& g, int64_t capacity, hipStream_t s) {
   return 0;
 }
 
+// exclusive scan of a small table by ONE workgroup (1024 threads x 16 items per round): one launch instead of three
+__global__ void __launch_bounds__(1024) scan_small_kernel(uint32_t* __restrict__ data, uint32_t n) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024 * 16) {
+    const uint32_t i0 = base + tid * 16;
+    uint32_t v[16];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      v[r] = (i0 + r < n) ? data[i0 + r] : 0u;
+      tsum += v[r];
+    }
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t run = carry_s + inc - tsum;
+    for (int w = 0; w < wid; w++) run += wsum[w];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      if (i0 + r < n) data[i0 + r] = run;
+      run += v[r];
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = run;
+    __syncthreads();
+  }
+}
+
 static void exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* tmp, hipStream_t s) {
+  if (n <= 1024 * 16) {  // one round of one workgroup (measured: at 4 rounds the three-kernel scan is already faster)
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, s, data, n);
+    return;
+  }
   const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, data, n, tmp);
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, tmp, (int)nb);

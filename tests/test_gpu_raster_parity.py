@@ -201,3 +201,33 @@ def test_optimistic_capacity_path_equals_synchronous_path(hip):
             assert float((a["grads"][k] - b["grads"][k]).abs().max()) / scale < 1e-4, k
     finally:
         hip.optimistic, hip._capacity_hint = old
+
+
+def test_two_contexts_alive_rgb_plus_nir_pass(hip, oracle):
+    """train_nir.py renders RGB and then a second pass with precomputed (NIR) colours before any backward runs
+    (mult-dwtgs/gaussian_renderer/__init__.py:151-258): two forward contexts coexist and their gradients add."""
+    sc = small_scene(600, 21, big=True)
+    cam = synthetic.look_at_camera((3.0, 0.4, 0.8), 96, 64, FoVx=0.9)
+    outs = {}
+    for name, dev, Rast, Settings in (("hip", torch.device("cuda"), dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings),
+                                      ("oracle", torch.device("cpu"), oracle.Rasterizer, oracle.Settings)):
+        from helpers import settings_for
+        p = {k: sc[k].to(dev).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        nir_albedo = torch.linspace(-1, 1, 600).reshape(600, 1).to(dev).requires_grad_(True)
+        rs = settings_for(Settings, cam, torch.zeros(3), 3, dev)
+        rast = Rast(rs)
+        m2d = torch.zeros_like(p["means3D"], requires_grad=True)
+        rgb, _, _ = rast(means3D=p["means3D"], means2D=m2d, opacities=p["opacities"], shs=p["shs"], scales=p["scales"],
+                         rotations=p["rotations"])
+        nir_col = torch.sigmoid(nir_albedo).repeat(1, 3)
+        nir, _, _ = rast(means3D=p["means3D"], means2D=m2d, opacities=p["opacities"], colors_precomp=nir_col,
+                         scales=p["scales"], rotations=p["rotations"])
+        g = torch.Generator().manual_seed(8)
+        w1, w2 = torch.randn((3, 64, 96), generator=g).to(dev), torch.randn((64, 96), generator=g).to(dev)
+        ((rgb * w1).sum() + (nir[0] * w2).sum()).backward()
+        outs[name] = {k: v.grad.cpu() for k, v in p.items()}
+        outs[name]["nir"] = nir_albedo.grad.cpu()
+        outs[name]["img"] = nir.detach().cpu()
+    assert float((outs["hip"]["img"] - outs["oracle"]["img"]).abs().max()) < 1e-5
+    grads_close({k: v for k, v in outs["hip"].items() if k != "img"}, {k: v for k, v in outs["oracle"].items() if k != "img"},
+                "rgb+nir")
