@@ -17,7 +17,7 @@ src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
 OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs_scatter_kernel", "scan_reduce_kernel",
         "scan_sums_kernel", "scan_down_kernel", "sorted_block_sums_kernel", "duplicate_kernel", "tile_ranges_kernel",
-        "bin_prepare_kernel", "render_fwd_kernel", "render_bwd_kernel", "preprocess_bwd_kernel", "l1_fwd_kernel",
+        "bin_prepare_kernel", "render_fwd_wave_kernel", "render_bwd_wave_kernel", "render_fwd_kernel", "render_bwd_kernel", "adam_kernel", "scan_small_kernel", "preprocess_bwd_kernel", "l1_fwd_kernel",
         "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
         "patch_dwt_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel")
 
@@ -39,7 +39,7 @@ with open(os.path.join(here, "%s_kernel_stats.csv" % tag), "w") as f:
 
 trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
 tr = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(tr) if "render_bwd_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(tr) if "render_bwd_wave_kernel" in r["Kernel_Name"] or "render_bwd_kernel" in r["Kernel_Name"]]
 a, b = idx[-3], idx[-2]
 seg = tr[a:b]
 wall = (int(tr[b]["Start_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6
@@ -78,7 +78,7 @@ with open(os.path.join(here, "%s_pmc_traffic.csv" % tag), "w") as f:
         rd, wr = 2.0 * fm * 1024.0, wm * 1024.0
         w.writerow([k, len(v["FETCH_SIZE"]), "%.1f" % fm, "%.1f" % wm, "%.0f" % rd, "%.0f" % wr, "%.0f" % (rd + wr)])
         traffic[k] = rd + wr
-stage_of = {"render_bwd": "render_bwd_kernel", "render_fwd": "render_fwd_kernel", "preprocess_fwd": "preprocess_fwd_kernel",
+stage_of = {"render_bwd": "render_bwd_wave_kernel", "render_fwd": "render_fwd_wave_kernel", "preprocess_fwd": "preprocess_fwd_kernel",
             "preprocess_bwd": "preprocess_bwd_kernel", "duplicate": "duplicate_kernel", "tile_ranges": "tile_ranges_kernel"}
 out = {st: traffic[k] for st, k in stage_of.items() if k in traffic}
 if "rs_scatter_kernel" in traffic:  # the sort stage = all passes of hist + scatter (launch counts per step: 6 each)

@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
   const int lane = threadIdx.x;
   const int px0 = tile_x * TILE_X + (lane & 7), py0 = tile_y * TILE_Y + (lane >> 3);
   const float pixfx0 = (float)px0, pixfy0 = (float)py0;
+  const float tile_fx0 = (float)(tile_x * TILE_X), tile_fy0 = (float)(tile_y * TILE_Y);
 
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
@@ -56,7 +57,20 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     __syncthreads();  // single wave: previous batch fully consumed
     s_a[lane] = make_float4(ra.x, ra.y, ra.w, 0.f);
     s_c[lane] = rc;
-    s_k[lane] = rk;
+    {
+      // Exact-safe tile cull: alpha >= 1/255 needs power >= -L with L = ln(255 * opacity); the set
+      // {d : d^T Q d <= 2L} is an ellipse whose half-extent along x is sqrt(2 L Sigma_xx), Sigma = Q^-1
+      // (Sigma_xx = Q_yy / det Q).  A tile whose pixel range lies beyond that extent (+2 % and one pixel of
+      // slack, far above the rounding of the per-pixel test) cannot receive a contribution, so the whole
+      // iteration is skipped.  The list itself is untouched (the reference's bounding square stays the binning rule).
+      const float det = rc.x * rc.z - rc.y * rc.y;
+      const float L2 = 2.0f * __logf(255.0f * 1.0001f * fmaxf(rc.w, 1e-20f));  // < 0: opacity below 1/255, never blends
+      const bool ok = det > 0.f && L2 >= 0.f;
+      const float ex = ok ? sqrtf(L2 * rc.z / det) * 1.02f + 1.0f : (L2 >= 0.f ? 3.0e38f : -1.0f);
+      const float ey = ok ? sqrtf(L2 * rc.x / det) * 1.02f + 1.0f : (L2 >= 0.f ? 3.0e38f : -1.0f);
+      s_k[lane] = make_float4(rk.x, rk.y, rk.z, ex);
+      s_a[lane].w = ey;
+    }
     __syncthreads();
     {
       const int nxt = (i + 1) * WB + lane;
@@ -69,6 +83,12 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     for (int j = 0; j < cnt; j++) {
       const uint32_t contributor = (uint32_t)(i * WB + j + 1);
       const float4 a = s_a[j];
+      const float4 k = s_k[j];
+      {  // wave-uniform: distance from the centre to the tile's pixel range, per axis
+        const float ddx = fmaxf(fmaxf(tile_fx0 - a.x, a.x - (tile_fx0 + 15.0f)), 0.f);
+        const float ddy = fmaxf(fmaxf(tile_fy0 - a.y, a.y - (tile_fy0 + 15.0f)), 0.f);
+        if (ddx > k.w || ddy > a.w) continue;
+      }
       const float4 co = s_c[j];
       float alpha[4];
       bool hit[4];
@@ -83,7 +103,6 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
         any_hit |= hit[s];
       }
       if (!__any(any_hit)) continue;
-      const float4 k = s_k[j];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         if (hit[s]) {
