@@ -8,6 +8,19 @@ probes for them in a try/except; the fused SSIM lives in the separate `fused_ssi
 from gsplat_amd import hip_backend
 
 
+class _Backend:
+    """`_C.backend` -> the process-wide RasterBackend (lazy: loading the library needs torch + the .so)."""
+
+    def __getattr__(self, name):
+        return getattr(hip_backend(), name)
+
+    def __setattr__(self, name, value):
+        setattr(hip_backend(), name, value)
+
+
+backend = _Backend()
+
+
 def rasterize_gaussians(*args):
     return hip_backend().rasterize_gaussians(*args)
 

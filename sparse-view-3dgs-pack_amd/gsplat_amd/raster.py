@@ -46,6 +46,9 @@ class RasterBackend:
         self._capacity_hint = 0
         self.optimistic = os.environ.get("GS_SYNC_FORWARD", "0") != "1"
         self._cap_memo = {}
+        # one-shot output arena for the next backward: {"means3D": [P,3], "sh": [P,M,3]} fp32 tensors to write
+        # dL_dmeans3D / dL_dsh INTO (e.g. views of a flat gradient buffer) instead of fresh allocations
+        self.grad_arena = None
 
     # ------------------------------------------------------------------ helpers
     def _stream(self, device):
@@ -220,12 +223,20 @@ class RasterBackend:
         f32 = dict(dtype=torch.float32, device=device)
         # every row is written by gs_backward (culled rows become 0): empty, not zeros
         alloc = torch.empty if P != 0 else torch.zeros
-        dL_dmeans3D = alloc((P, 3), **f32)
+        arena, self.grad_arena = self.grad_arena, None
+
+        def out(name, shape):
+            t = None if arena is None else arena.get(name)
+            if t is not None and tuple(t.shape) == tuple(shape) and t.is_contiguous() and t.device == device \
+                    and t.dtype == torch.float32:
+                return t
+            return alloc(shape, **f32)
+        dL_dmeans3D = out("means3D", (P, 3))
         dL_dmeans2D = alloc((P, 3), **f32)
         dL_dcolors = alloc((P, NUM_CHANNELS), **f32)
         dL_dopacity = alloc((P, 1), **f32)
         dL_dcov3D = alloc((P, 6), **f32)
-        dL_dsh = alloc((P, M, 3), **f32)
+        dL_dsh = out("sh", (P, M, 3))
         dL_dscales = alloc((P, 3), **f32)
         dL_drotations = alloc((P, 4), **f32)
         ret = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)

@@ -157,8 +157,37 @@ class GaussianModelLite:
         return self.params["features"]
 
     def zero_grad(self):
-        # gradients live in one persistent flat buffer (views), so "set_to_none" is replaced by a memset
-        self.flat_grad.zero_()
+        """set_to_none, as the reference does (train.py:283-288): autograd then ASSIGNS the new gradients
+        instead of adding them to a zeroed buffer (no 236 B/Gaussian memset, no read-modify-write)."""
+        for p in self.params.values():
+            p.grad = None
+
+    def grad_views(self):
+        P, off, out = self.P, 0, {}
+        shapes = {"xyz": (P, 3), "features": (P, 16, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+        for name, n in FIELDS:
+            out[name] = self.flat_grad[off:off + P * n].view(shapes[name])
+            off += P * n
+        return out
+
+    def arm_grad_arena(self, backend):
+        """Ask the rasterizer backward to write dL_dmeans3D / dL_dsh (51 of the 59 floats per Gaussian) straight
+        into the flat gradient buffer: those two parameters reach the rasterizer without an activation in
+        between, so autograd hands the very same tensors to the leaves and nothing is copied."""
+        v = self.grad_views()
+        backend.grad_arena = {"means3D": v["xyz"], "sh": v["features"]}
+
+    def collect_grads(self):
+        """After backward: make every .grad a view of the flat buffer (copy only what autograd produced elsewhere:
+        the 8 floats per Gaussian behind exp / sigmoid / normalize, or everything when no arena was armed)."""
+        for name, view in self.grad_views().items():
+            p = self.params[name]
+            g = p.grad
+            if g is None:
+                view.zero_()
+            elif g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+            p.grad = view
 
     def add_densification_stats(self, viewspace_grad, visible_mask):
         # gaussian_model.py:471-473, written without boolean indexing (no host sync); rows of culled
@@ -246,12 +275,17 @@ class Trainer:
         m = self.model
         ci = self.camera_index(k)
         m.zero_grad()
+        backend = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
+        backend = getattr(backend, "backend", None)
+        if backend is not None:
+            m.arm_grad_arena(backend)
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=False)
         mask = None if self.masks is None else self.masks[ci]
         loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
         loss.backward()
         radii = pkg["radii"]
         with torch.no_grad():
+            m.collect_grads()
             # train.py:268 (radii are 0 for culled Gaussians, so a plain maximum equals the masked update)
             torch.maximum(m.max_radii2D, radii.to(torch.float32), out=m.max_radii2D)
             m.add_densification_stats(pkg["viewspace_points"].grad, pkg["visibility_filter"])

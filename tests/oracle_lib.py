@@ -37,6 +37,7 @@ class Oracle:
         self.lib = lib
 
         class _Impl:
+            backend = self.backend
             rasterize_gaussians = staticmethod(backend.rasterize_gaussians)
             rasterize_gaussians_backward = staticmethod(backend.rasterize_gaussians_backward)
             mark_visible = staticmethod(backend.mark_visible)
