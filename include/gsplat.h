@@ -227,6 +227,38 @@ int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
                 const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                 void* stream);
 
+/* ---- fused form of the LGDWT-GS criterion (LGDWT-GS/train.py:128-202): the per-term kernels above with
+ * device-resident coefficients, one shared image-gradient buffer, SSIM's mean and the clamp(0,1) backward folded
+ * in, and the loss composition itself (running-mean DWT scale included) done by one tiny kernel instead of
+ * host arithmetic on .item() values. ---- */
+int gs_l1_bwd_dev(const float* a, const float* b, int64_t n, const float* coef_dev /*[1]*/, float* grad_a,
+                  int32_t accumulate, void* stream);
+/* like gs_ssim_fwd but returns sum(ssim_map) (+=, zero it first) instead of the map */
+int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1,
+                    float C2, float* sum_out, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                    void* stream);
+/* like gs_ssim_bwd with dL_dmap == coef_dev[0] everywhere; optionally adds to dL_dimg1 and then zeroes the
+ * result where clamp_src (the un-clamped render) lies outside [0,1] */
+int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W,
+                        const float* coef_dev, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                        const float* dm_dsigma12, float* dL_dimg1, int32_t accumulate, const float* clamp_src,
+                        void* stream);
+typedef struct GsLgdwtParams {
+  float lambda_dssim;        /* 0.2 */
+  float n_pix;               /* C*H*W */
+  float n_band1, n_band2;    /* elements per level-1 / level-2 band */
+  float dwt_w[8];            /* LL1 LH1 HL1 HH1 LL2 LH2 HL2 HH2 */
+  float patch_w[3];          /* w_lh, w_hl, (w_lh+w_hl)/2 */
+  float patch_weight;        /* beta = 0.1 */
+  float patch_elems_per_sel; /* C * (patch/2)^2 */
+  int32_t dwt_enable, patch_enable;
+} GsLgdwtParams;
+/* sums[16]: 0 l1 | 1 ssim | 2..9 bands | 10..12 patch | 13 selected patches.  running_mean: device scalar,
+ * updated in place (train.py:193-195).  out[24]: 0 loss 1 base 2 dwt 3 patch 4 dwt_scale 5 l1 6 ssim;
+ * 8 c_l1, 9 c_ssim, 10..17 c_band, 18..20 c_patch = dLoss/d(term sum). */
+int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* params /*host*/, float* out,
+                     void* stream);
+
 /* ---- optimiser (caller side of the path): fused Adam over ONE flat fp32 parameter buffer.
  * Replaces torch.optim.Adam(lr=0, eps=1e-15) with per-group learning rates,
  * LGDWT-GS/scene/gaussian_model.py:183-193 + train.py:279-288.  Segment k covers elements [begin, end);

@@ -407,4 +407,68 @@ int gso_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
   }
   return GS_OK;
 }
+
+/* ---- fused-criterion entry points (same arithmetic as the per-term functions above) ---- */
+int gso_l1_bwd_dev(const float* a, const float* b, int64_t n, const float* coef, float* g, int32_t accumulate, void*) {
+  if (!a || !b || !g || !coef) return GS_E_NULL;
+  return gso_l1_bwd(a, b, n, 1.0f * coef[0], g, accumulate, nullptr);
+}
+int gso_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1, float C2,
+                     float* sum_out, float* d1, float* d2, float* d3, void*) {
+  if (!sum_out) return GS_E_NULL;
+  std::vector<float> map((size_t)B * C * H * W);
+  int rc = gso_ssim_fwd(img1, img2, B, C, H, W, C1, C2, map.data(), d1, d2, d3, nullptr);
+  if (rc) return rc;
+  double s = 0;
+  for (float v : map) s += (double)v;
+  *sum_out += (float)s;
+  return GS_OK;
+}
+int gso_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, const float* coef,
+                         const float* d1, const float* d2, const float* d3, float* dL_dimg1, int32_t accumulate,
+                         const float* clamp_src, void*) {
+  if (!coef || !dL_dimg1) return GS_E_NULL;
+  const size_t n = (size_t)B * C * H * W;
+  std::vector<float> g(n, coef[0]), out(n);
+  int rc = gso_ssim_bwd(img1, img2, B, C, H, W, 0.f, 0.f, g.data(), d1, d2, d3, out.data(), nullptr);
+  if (rc) return rc;
+  for (size_t i = 0; i < n; i++) {
+    float v = out[i];
+    if (accumulate) v += dL_dimg1[i];
+    if (clamp_src && (clamp_src[i] < 0.f || clamp_src[i] > 1.f)) v = 0.f;
+    dL_dimg1[i] = v;
+  }
+  return GS_OK;
+}
+/* LGDWT-GS/train.py:188-202 */
+int gso_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* pp, float* out, void*) {
+  if (!sums || !running_mean || !pp || !out) return GS_E_NULL;
+  const GsLgdwtParams& p = *pp;
+  const float l1 = sums[0] / p.n_pix;
+  const float ssim = sums[1] / p.n_pix;
+  const float base = (1.0f - p.lambda_dssim) * l1 + p.lambda_dssim * (1.0f - ssim);
+  float loss = base, dwt = 0.f, scale = 0.f, patch = 0.f;
+  for (int k = 0; k < 24; k++) out[k] = 0.f;
+  if (p.dwt_enable) {
+    for (int k = 0; k < 8; k++) dwt += p.dwt_w[k] * (sums[2 + k] / (k < 4 ? p.n_band1 : p.n_band2));
+    const float ratio = base / (dwt + 1e-8f);
+    const float m = 0.95f * running_mean[0] + 0.05f * ratio;
+    running_mean[0] = m;
+    scale = fminf(fmaxf(m, 0.1f), 10.0f);
+    loss = base + scale * dwt;
+    for (int k = 0; k < 8; k++) out[10 + k] = scale * p.dwt_w[k] / (k < 4 ? p.n_band1 : p.n_band2);
+  }
+  if (p.patch_enable) {
+    const float denom = fmaxf(sums[13] * p.patch_elems_per_sel, 1.0f);
+    for (int k = 0; k < 3; k++) {
+      patch += p.patch_w[k] * (sums[10 + k] / denom);
+      out[18 + k] = p.patch_weight * p.patch_w[k] / denom;
+    }
+    loss = loss + p.patch_weight * patch;
+  }
+  out[0] = loss; out[1] = base; out[2] = dwt; out[3] = patch; out[4] = scale; out[5] = l1; out[6] = ssim;
+  out[8] = (1.0f - p.lambda_dssim) / p.n_pix;
+  out[9] = -p.lambda_dssim / p.n_pix;
+  return GS_OK;
+}
 }

@@ -73,7 +73,9 @@ __global__ void __launch_bounds__(GS_BLOCK) l1_fwd_kernel(const float* __restric
   block_sum_atomic<1>(acc, sum);
 }
 __global__ void __launch_bounds__(GS_BLOCK) l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          int64_t n, float coef, float* __restrict__ g, int accumulate) {
+                                                          int64_t n, float coef, const float* __restrict__ coef_dev,
+                                                          float* __restrict__ g, int accumulate) {
+  if (coef_dev) coef *= coef_dev[0];
   for (int64_t i = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GS_BLOCK) {
     const float v = coef * sgnf(a[i] - b[i]);
     g[i] = accumulate ? g[i] + v : v;
@@ -369,7 +371,7 @@ __device__ __forceinline__ void ssim_conv_tile(float (*tile)[SH][SH + 1], float 
 __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                             int H, int W, float C1, float C2, float* __restrict__ ssim_map,
                                                             float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
-                                                            float* __restrict__ dm_dsigma12) {
+                                                            float* __restrict__ dm_dsigma12, float* sum_out) {
   __shared__ float tile[5][SH][SH + 1];
   __shared__ float hor[5][SH][ST + 1];
   const size_t plane = (size_t)blockIdx.z * H * W;
@@ -392,6 +394,7 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
   float out[4][5];
   ssim_conv_tile<5>(tile, hor, out);
   const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
+  float msum = 0.f;
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     const int x = bx + lx, y = by + ly0 + 8 * m;
@@ -406,13 +409,20 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
     const float A = (mu1_sq + mu2_sq + C1);
     const float B = (sigma1_sq + sigma2_sq + C2);
     const size_t o = plane + (size_t)y * W + x;
-    ssim_map[o] = (Cc * D) / (A * B);
+    const float mval = (Cc * D) / (A * B);
+    msum += mval;
+    if (ssim_map) ssim_map[o] = mval;
     if (dm_dmu1) {
       dm_dmu1[o] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * Cc) / (A * B) - (mu1 * 2.0f * Cc * D) / (A * A * B) +
                     (mu1 * 2.0f * Cc * D) / (A * B * B));
       dm_dsigma1_sq[o] = ((-Cc * D) / (A * B * B));
       dm_dsigma12[o] = ((2 * Cc) / (A * B));
     }
+  }
+  if (sum_out) {  // uniform branch: mean SSIM without a second pass over the map
+    float acc[1] = {msum};
+    __syncthreads();
+    block_sum_atomic<1>(acc, sum_out);
   }
 }
 
@@ -421,8 +431,10 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dm_dmu1,
                                                             const float* __restrict__ dm_dsigma1_sq,
                                                             const float* __restrict__ dm_dsigma12,
-                                                            float* __restrict__ dL_dimg1) {
+                                                            float* __restrict__ dL_dimg1, const float* __restrict__ coef_dev,
+                                                            int accumulate, const float* __restrict__ clamp_src) {
   __shared__ float tile[3][SH][SH + 1];
+  const float gu = coef_dev ? coef_dev[0] : 0.f;  // uniform dL/dssim_map (mean reduction upstream)
   __shared__ float hor[3][SH][ST + 1];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
@@ -432,7 +444,7 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
     float g = 0.f, a = 0.f, b = 0.f, d = 0.f;
     if (x >= 0 && x < W && y >= 0 && y < H) {
       const size_t o = plane + (size_t)y * W + x;
-      g = dL_dmap[o];
+      g = dL_dmap ? dL_dmap[o] : gu;
       a = dm_dmu1[o];
       b = dm_dsigma1_sq[o];
       d = dm_dsigma12[o];
@@ -454,6 +466,11 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
     dL += out[m][0];
     dL += img1[o] * 2.0f * out[m][1];
     dL += img2[o] * out[m][2];
+    if (accumulate) dL += dL_dimg1[o];
+    if (clamp_src) {  // gradient of clamp(x, 0, 1) folded in: zero where the un-clamped source was outside [0, 1]
+      const float r = clamp_src[o];
+      if (r < 0.f || r > 1.f) dL = 0.f;
+    }
     dL_dimg1[o] = dL;
   }
 }
@@ -481,7 +498,7 @@ int gs_l1_bwd(const float* a, const float* b, int64_t n, float coef, float* g, i
   if (n <= 0) return GS_OK;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_L1, s);
-  hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblocks(n)), dim3(GS_BLOCK), 0, s, a, b, n, coef, g, accumulate);
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblocks(n)), dim3(GS_BLOCK), 0, s, a, b, n, coef, (const float*)nullptr, g, accumulate);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -585,7 +602,7 @@ int gs_ssim_fwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_FWD, s);
   hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+                     C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -597,7 +614,99 @@ int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_BWD, s);
   hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+                     dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, (const float*)nullptr, 0, (const float*)nullptr);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fused criterion
+// Entry points used by the one-Function form of the LGDWT-GS loss (gsplat_amd/losses.py::FusedLGDWTLoss): the
+// per-term kernels above, but (1) coefficients come from DEVICE memory (no host sync on the running-mean DWT
+// scale), (2) every term accumulates into ONE image-gradient buffer, (3) SSIM's mean and the clamp(0,1) backward
+// are folded in, so no torch elementwise pass touches an image.
+
+int gs_l1_bwd_dev(const float* a, const float* b, int64_t n, const float* coef_dev, float* grad_a, int32_t accumulate,
+                  void* stream) {
+  if (!a || !b || !grad_a || !coef_dev) return GS_E_NULL;
+  if (n <= 0) return GS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_L1, s);
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblocks(n)), dim3(GS_BLOCK), 0, s, a, b, n, 1.0f, coef_dev, grad_a, accumulate);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+
+int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1, float C2,
+                    float* sum_out, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream) {
+  if (!img1 || !img2 || !sum_out) return GS_E_NULL;
+  if (dm_dmu1 && (!dm_dsigma1_sq || !dm_dsigma12)) return GS_E_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_SSIM_FWD, s);
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, sum_out);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+
+int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W,
+                        const float* coef_dev, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                        float* dL_dimg1, int32_t accumulate, const float* clamp_src, void* stream) {
+  if (!img1 || !img2 || !coef_dev || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return GS_E_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_SSIM_BWD, s);
+  hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, coef_dev, accumulate, clamp_src);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+
+// loss composition of LGDWT-GS/train.py:188-202 on the device (one thread): the reference pulls base/dwt to the
+// host with .item() every iteration; here the running mean lives in device memory and the coefficient vector of
+// the backward kernels is produced in the same launch.
+//   sums[16] : 0 l1_sum | 1 ssim_sum | 2..9 band_sums | 10..12 patch_sums | 13 n_selected_patches
+//   out[24]  : 0 loss | 1 base | 2 dwt | 3 patch | 4 dwt_scale | 5 l1 | 6 ssim |
+//              8 c_l1 | 9 c_ssim | 10..17 c_band[8] | 18..20 c_patch[3]      (dL/d term-sum, for upstream grad 1)
+__global__ void lgdwt_combine_kernel(const float* __restrict__ sums, float* running_mean, GsLgdwtParams p,
+                                     float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float l1 = sums[0] / p.n_pix;
+  const float ssim = sums[1] / p.n_pix;
+  const float base = (1.0f - p.lambda_dssim) * l1 + p.lambda_dssim * (1.0f - ssim);
+  float loss = base;
+  float dwt = 0.f, scale = 0.f, patch = 0.f;
+  for (int k = 0; k < 24; k++) out[k] = 0.f;
+  if (p.dwt_enable) {
+    for (int k = 0; k < 8; k++) {
+      const float cnt = k < 4 ? p.n_band1 : p.n_band2;
+      dwt += p.dwt_w[k] * (sums[2 + k] / cnt);
+    }
+    const float ratio = base / (dwt + 1e-8f);
+    const float m = 0.95f * running_mean[0] + 0.05f * ratio;
+    running_mean[0] = m;
+    scale = fminf(fmaxf(m, 0.1f), 10.0f);
+    loss = base + scale * dwt;
+    for (int k = 0; k < 8; k++) out[10 + k] = scale * p.dwt_w[k] / (k < 4 ? p.n_band1 : p.n_band2);
+  }
+  if (p.patch_enable) {
+    const float denom = fmaxf(sums[13] * p.patch_elems_per_sel, 1.0f);
+    for (int k = 0; k < 3; k++) {
+      patch += p.patch_w[k] * (sums[10 + k] / denom);
+      out[18 + k] = p.patch_weight * p.patch_w[k] / denom;
+    }
+    loss = loss + p.patch_weight * patch;
+  }
+  out[0] = loss; out[1] = base; out[2] = dwt; out[3] = patch; out[4] = scale; out[5] = l1; out[6] = ssim;
+  out[8] = (1.0f - p.lambda_dssim) / p.n_pix;
+  out[9] = -p.lambda_dssim / p.n_pix;
+}
+
+int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* p, float* out, void* stream) {
+  if (!sums || !running_mean || !p || !out) return GS_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(lgdwt_combine_kernel, dim3(1), dim3(64), 0, s, sums, running_mean, *p, out);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }

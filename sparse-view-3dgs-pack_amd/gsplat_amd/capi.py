@@ -69,6 +69,12 @@ class GsGrads(C.Structure):
     ]
 
 
+class GsLgdwtParams(C.Structure):
+    _fields_ = [("lambda_dssim", C.c_float), ("n_pix", C.c_float), ("n_band1", C.c_float), ("n_band2", C.c_float),
+                ("dwt_w", C.c_float * 8), ("patch_w", C.c_float * 3), ("patch_weight", C.c_float),
+                ("patch_elems_per_sel", C.c_float), ("dwt_enable", C.c_int32), ("patch_enable", C.c_int32)]
+
+
 class GsAdamSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr_a", C.c_float), ("lr_b", C.c_float),
                 ("period", C.c_int32), ("split", C.c_int32)]
@@ -108,6 +114,10 @@ PROTOTYPES = {
     "patch_dwt_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "ssim_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "ssim_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "l1_bwd_dev": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P]),
+    "ssim_fwd_sum": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
+    "ssim_bwd_uniform": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P]),
+    "lgdwt_combine": (C.c_int, [_P, _P, C.POINTER(GsLgdwtParams), _P, _P]),
     "adam_step": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P]),
     "profile_enable": (C.c_int, [_I32]),
     "profile_reset": (C.c_int, []),

@@ -231,6 +231,87 @@ class LossOps:
         return self._PatchDwt.apply(pred[0], gt[0], mask, int(patch_size), w3)
 
 
+class FusedLGDWTLoss(torch.autograd.Function):
+    """The whole criterion of LGDWT-GS/train.py:128-202 as ONE autograd node on the un-clamped render.
+
+    forward : clamp(0,1) -> L1 sum, SSIM sum (+ the three derivative maps), eight DWT band sums, three patch sums
+              -> gs_lgdwt_combine (loss, running-mean DWT scale and the backward coefficients, all on the device)
+    backward: four kernels accumulate into ONE image-gradient buffer; the last one folds in the clamp mask.
+    No torch elementwise pass over an image, no host synchronisation."""
+
+    @staticmethod
+    def forward(ctx, ops, raw, gt, mask, n_sel, running_mean, params):
+        api = ops.api
+        raw, gt = _c(raw), _c(gt)
+        Cc, H, W = raw.shape
+        img = raw.clamp(0, 1)
+        st = _stream(raw)
+        sums = torch.zeros((16,), dtype=torch.float32, device=raw.device)
+        d1, d2, d3 = torch.empty_like(raw), torch.empty_like(raw), torch.empty_like(raw)
+        api.call("l1_fwd", img.data_ptr(), gt.data_ptr(), img.numel(), sums.data_ptr(), st)
+        api.call("ssim_fwd_sum", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, 0.01 ** 2, 0.03 ** 2,
+                 sums[1:].data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), st)
+        if params.dwt_enable:
+            api.call("dwt2_l1_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, sums[2:].data_ptr(), st)
+        if params.patch_enable:
+            api.call("patch_dwt_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
+                     sums[10:].data_ptr(), st)
+            sums[13:14].copy_(n_sel)
+        out = torch.empty((24,), dtype=torch.float32, device=raw.device)
+        api.call("lgdwt_combine", sums.data_ptr(), running_mean.data_ptr(), C.byref(params.c), out.data_ptr(), st)
+        ctx.ops, ctx.params = ops, params
+        ctx.save_for_backward(raw, img, gt, mask, d1, d2, d3, out)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g, _gout):
+        raw, img, gt, mask, d1, d2, d3, out = ctx.saved_tensors
+        api, params = ctx.ops.api, ctx.params
+        Cc, H, W = raw.shape
+        st = _stream(raw)
+        coef = (out[8:24] * g).contiguous()   # [c_l1, c_ssim, c_band x8, c_patch x3, ...] x upstream
+        grad = torch.empty_like(raw)
+        api.call("l1_bwd_dev", img.data_ptr(), gt.data_ptr(), img.numel(), coef.data_ptr(), grad.data_ptr(), 0, st)
+        if params.dwt_enable:
+            api.call("dwt2_l1_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, coef[2:].data_ptr(), grad.data_ptr(), 1, st)
+        if params.patch_enable:
+            api.call("patch_dwt_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
+                     coef[10:].data_ptr(), grad.data_ptr(), 1, st)
+        api.call("ssim_bwd_uniform", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, coef[1:].data_ptr(), d1.data_ptr(),
+                 d2.data_ptr(), d3.data_ptr(), grad.data_ptr(), 1, raw.data_ptr(), st)
+        return None, grad, None, None, None, None, None
+
+
+def ctx_ps(params):
+    return int(params.patch_size)
+
+
+class _FusedParams:
+    """Host-side constants of one image size (the C struct + the patch size)."""
+
+    def __init__(self, crit, Cc, H, W):
+        from .capi import GsLgdwtParams
+        h1, w1 = (H + 1) // 2, (W + 1) // 2
+        h2, w2 = (h1 + 1) // 2, (w1 + 1) // 2
+        c = GsLgdwtParams()
+        c.lambda_dssim = crit.lambda_dssim
+        c.n_pix = float(Cc * H * W)
+        c.n_band1, c.n_band2 = float(Cc * h1 * w1), float(Cc * h2 * w2)
+        for k in range(8):
+            c.dwt_w[k] = crit.dwt_weights[k]
+        c.patch_w[0], c.patch_w[1] = crit.patch_lh1_weight, crit.patch_hl1_weight
+        c.patch_w[2] = 0.5 * (crit.patch_lh1_weight + crit.patch_hl1_weight)
+        c.patch_weight = crit.patch_dwt_weight
+        hp = (crit.patch_size + 1) // 2
+        c.patch_elems_per_sel = float(Cc * hp * hp)
+        self.patch_enable = bool(crit.patch_dwt_enable and H >= crit.patch_size and W >= crit.patch_size)
+        self.dwt_enable = bool(crit.dwt_enable)
+        c.dwt_enable, c.patch_enable = int(self.dwt_enable), int(self.patch_enable)
+        self.c = c
+        self.patch_size = crit.patch_size
+
+
 class LGDWTCriterion:
     """Loss composition of LGDWT-GS/train.py:128-202 with the reference's defaults
     (LGDWT-GS/arguments/__init__.py:88-122).  The running-mean DWT scale lives on the DEVICE (the
@@ -239,8 +320,10 @@ class LGDWTCriterion:
 
     def __init__(self, ops, lambda_dssim=0.2, dwt_enable=True, patch_dwt_enable=True,
                  dwt_weights=(1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0), patch_size=128, patch_percentile=0.2,
-                 patch_dwt_weight=0.1, patch_lh1_weight=1.0, patch_hl1_weight=1.0):
+                 patch_dwt_weight=0.1, patch_lh1_weight=1.0, patch_hl1_weight=1.0, fused=True):
         self.ops = ops
+        self.fused = fused        # one autograd node on the UN-clamped render (see FusedLGDWTLoss)
+        self._fp = {}
         self.lambda_dssim = lambda_dssim
         self.dwt_enable, self.patch_dwt_enable = dwt_enable, patch_dwt_enable
         self.dwt_weights = tuple(dwt_weights)
@@ -254,6 +337,33 @@ class LGDWTCriterion:
         mask, _ = self.ops.patch_mask(elf, self.patch_size, self.patch_percentile)
         return mask
 
+    def fused_call(self, raw_image, gt_image, mask=None):
+        """Criterion on the rasterizer's raw output (the clamp of gaussian_renderer/__init__.py:119 is applied -
+        and differentiated - inside).  Returns (loss, parts) like __call__."""
+        key = tuple(raw_image.shape)
+        fp = self._fp.get(key)
+        if fp is None:
+            fp = self._fp[key] = _FusedParams(self, *key)
+        dev = raw_image.device
+        if self.dwt_running_mean is None:
+            self.dwt_running_mean = torch.ones((1,), dtype=torch.float32, device=dev)
+        if fp.patch_enable:
+            if mask is None:
+                mask = self.elf_mask(gt_image)
+            n_sel = getattr(mask, "_gs_n_sel", None)
+            if n_sel is None:
+                n_sel = mask.sum().to(torch.float32).reshape(1)
+                try:
+                    mask._gs_n_sel = n_sel       # cached with the per-camera mask
+                except Exception:
+                    pass
+        else:
+            mask = torch.zeros((1,), dtype=torch.uint8, device=dev)
+            n_sel = torch.zeros((1,), dtype=torch.float32, device=dev)
+        loss, out = FusedLGDWTLoss.apply(self.ops, raw_image, gt_image, mask, n_sel, self.dwt_running_mean, fp)
+        parts = {"l1": out[5], "ssim": out[6], "dwt": out[2], "dwt_scale": out[4], "patch": out[3], "base": out[1]}
+        return loss, parts
+
     def __call__(self, image, gt_image, mask=None):
         ops = self.ops
         Ll1 = ops.l1_loss(image, gt_image)
@@ -265,9 +375,9 @@ class LGDWTCriterion:
             dwt_loss, band_means = ops.dwt_l1_loss(image, gt_image, self.dwt_weights)
             ratio = base_loss.detach() / (dwt_loss.detach() + 1e-8)
             if self.dwt_running_mean is None:
-                self.dwt_running_mean = torch.ones((), dtype=torch.float32, device=image.device)
+                self.dwt_running_mean = torch.ones((1,), dtype=torch.float32, device=image.device)
             self.dwt_running_mean = 0.95 * self.dwt_running_mean + 0.05 * ratio
-            dwt_scale = torch.clamp(self.dwt_running_mean, 0.1, 10.0)
+            dwt_scale = torch.clamp(self.dwt_running_mean, 0.1, 10.0).reshape(())
             loss = base_loss + dwt_scale * dwt_loss
             parts.update(dwt=dwt_loss.detach(), dwt_scale=dwt_scale, bands=band_means)
         if self.patch_dwt_enable and image.shape[-2] >= self.patch_size and image.shape[-1] >= self.patch_size:

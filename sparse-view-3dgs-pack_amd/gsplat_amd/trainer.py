@@ -224,7 +224,7 @@ class _TorchAdamWithFeatureSplit:
 
 
 def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifier=1.0, antialiasing=False,
-           debug=False, filter_as_indices=True):
+           debug=False, filter_as_indices=True, clamp=True):
     """= render() of LGDWT-GS/gaussian_renderer/__init__.py:18-128 (SH evaluated by the rasterizer, scale +
     rotation given, no exposure): returns {render, viewspace_points, visibility_filter, radii, depth}."""
     screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
@@ -242,7 +242,8 @@ def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifie
     rendered_image, radii, depth_image = rasterizer(
         means3D=pc.get_xyz, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None,
         opacities=pc.get_opacity, scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
-    rendered_image = rendered_image.clamp(0, 1)
+    if clamp:  # gaussian_renderer/__init__.py:119; the fused criterion applies (and differentiates) it itself
+        rendered_image = rendered_image.clamp(0, 1)
     return {"render": rendered_image, "viewspace_points": screenspace_points,
             # the reference returns indices ((radii > 0).nonzero(): a host sync); the step loop asks for the
             # equivalent boolean mask instead and stays asynchronous
@@ -279,9 +280,14 @@ class Trainer:
         backend = getattr(backend, "backend", None)
         if backend is not None:
             m.arm_grad_arena(backend)
-        pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=False)
+        fused = getattr(self.criterion, "fused", False)
+        pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=False,
+                     clamp=not fused)
         mask = None if self.masks is None else self.masks[ci]
-        loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
+        if fused:
+            loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
+        else:
+            loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
         loss.backward()
         radii = pkg["radii"]
         with torch.no_grad():

@@ -95,3 +95,22 @@ def test_reference_named_packages_run_on_gpu():
     assert Yl.shape == (1, 3, 17, 13) and Yh[0].shape == (1, 3, 3, 33, 25) and Yh[1].shape == (1, 3, 3, 17, 13)
     b = lgdwt_loss.get_dwt_subbands(x)
     assert torch.equal(b["LL2"], Yl) and torch.equal(b["HH1"], Yh[0][:, :, 2])
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (131, 260)])
+def test_fused_criterion_hip_vs_oracle(ops_pair, H, W):
+    hop, oop = ops_pair
+    g = torch.Generator().manual_seed(H)
+    gt = torch.rand((3, H, W), generator=g)
+    raw = gt + 0.2 * torch.randn((3, H, W), generator=g)
+    ch, co = LGDWTCriterion(hop), LGDWTCriterion(oop)
+    for it in range(2):
+        rh = raw.cuda().requires_grad_(True)
+        ro = raw.clone().requires_grad_(True)
+        lh, ph = ch.fused_call(rh, gt.cuda())
+        lo, po = co.fused_call(ro, gt)
+        lh.backward()
+        lo.backward()
+        close(lh, lo, 1e-5, "fused loss")
+        close(ph["dwt_scale"], po["dwt_scale"], 1e-5, "dwt scale")
+        close(rh.grad, ro.grad, 5e-5, "fused dL/draw")

@@ -147,3 +147,30 @@ def test_criterion_composition_matches_reference_formula(ops):
     loss2, parts2 = crit(pred, gt)
     m2 = 0.95 * m + 0.05 * ratio
     assert abs(float(parts2["dwt_scale"]) - max(0.1, min(10.0, m2))) < 1e-6
+
+
+def test_fused_criterion_equals_the_term_by_term_composition(ops):
+    """FusedLGDWTLoss (one autograd node on the un-clamped render, device-side loss composition) against the
+    modular path (clamp + l1_loss + fused_ssim + dwt_l1_loss + compute_patch_dwt_loss + torch arithmetic)."""
+    g = torch.Generator().manual_seed(9)
+    gt = torch.rand((3, 160, 256), generator=g)
+    raw = gt + 0.25 * torch.randn((3, 160, 256), generator=g)        # leaves [0,1] in places: exercises the clamp
+    ca, cb = LGDWTCriterion(ops, fused=True), LGDWTCriterion(ops, fused=False)
+    for it in range(3):
+        ra = raw.clone().requires_grad_(True)
+        rb = raw.clone().requires_grad_(True)
+        la, pa = ca.fused_call(ra, gt)
+        lb, pb = cb(rb.clamp(0, 1), gt)
+        (la * 1.5).backward()
+        (lb * 1.5).backward()
+        assert abs(float(la) - float(lb)) < 2e-6, it
+        assert abs(float(pa["dwt_scale"]) - float(pb["dwt_scale"])) < 1e-6
+        gref = rb.grad
+        assert float((ra.grad - gref).abs().max()) < 1e-6 * max(1.0, float(gref.abs().max())) + 1e-9
+        assert float(ra.grad[(raw < 0) | (raw > 1)].abs().max()) == 0.0
+    # DWT / patch switched off, small image (no patches)
+    ca, cb = LGDWTCriterion(ops, dwt_enable=False, patch_dwt_enable=False), LGDWTCriterion(ops, dwt_enable=False, patch_dwt_enable=False, fused=False)
+    r = raw[:, :40, :56].clone().contiguous()
+    la, _ = ca.fused_call(r, gt[:, :40, :56].contiguous())
+    lb, _ = cb(r.clamp(0, 1), gt[:, :40, :56].contiguous())
+    assert abs(float(la) - float(lb)) < 2e-6
