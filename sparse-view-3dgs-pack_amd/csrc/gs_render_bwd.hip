@@ -15,6 +15,7 @@
 // entry some pixel of the wave (batch: of the tile) actually blended in the forward pass.
 #include <stdlib.h>
 
+#include "gs_blend.h"
 #include "gs_common.h"
 
 template <int CTRL, int ROW_MASK, bool BOUND>
@@ -125,8 +126,8 @@ __global__ void __launch_bounds__(GS_BLOCK) render_bwd_kernel(
       const float4 a = s_a[j];
       const float4 co = s_c[j];
       const float dx = a.x - pixfx, dy = a.y - pixfy;
-      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-      const float G = __expf(power);
+      const float power = blend_power2(blend_stage_conic(co), dx, dy);  // same decision arithmetic as every blend kernel
+      const float G = blend_exp2(power);
       const float alpha = fminf(0.99f, co.w * G);
       const bool valid = (contributor < last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
       if (!__any(valid)) continue;

@@ -10,6 +10,7 @@
 // straight to memory as global atomics into one Gaussian's 64-byte gradient row (3 instructions, 10 lanes): no
 // LDS accumulator, no zeroing, no flush pass, no workgroup barrier (a 64-thread workgroup is one wave).
 // Replaces renderCUDA<3> backward (backward.cu:452-638); per-pixel recurrences are unchanged.
+#include "gs_blend.h"
 #include "gs_common.h"
 
 template <int CTRL, int ROW_MASK, bool BOUND>
@@ -99,8 +100,10 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
   lmax = __builtin_amdgcn_readfirstlane(lmax);
   if (lmax == 0) return;
 
-  const float ddelx_dx = 0.5f * W;
-  const float ddely_dy = 0.5f * H;
+  // per-row factors applied after the reduction (lane 15 of row q carries value q of t0 / 4+q of t1)
+  const int rq = lane >> 4;
+  const float rowscale0 = rq == 0 ? (0.5f * W) / GS_LOG2E : (rq == 1 ? (0.5f * H) / GS_LOG2E : -0.5f);
+  const float rowscale1 = rq == 0 ? -0.5f : 1.0f;
   const int q0 = n - (int)lmax;  // entries q < q0 (counted from the back) are behind every pixel's last contributor
   const int rounds = (n + WB - 1) / WB;
 
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
     __syncthreads();  // (single wave) previous batch fully consumed
     s_id[lane] = rid;
     s_a[lane] = make_float4(ra.x, ra.y, ra.w, 0.f);
-    s_c[lane] = rc;
+    s_c[lane] = blend_stage_conic(rc);  // (qa, qb, qc, opacity), see gs_blend.h
     s_k[lane] = rk;
     __syncthreads();
     {
@@ -145,17 +148,21 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
       for (int s = 0; s < 4; s++) {
         const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
         const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));
-        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-        G[s] = __expf(power);
+        const float p2 = blend_power2(co, dx, dy);
+        G[s] = blend_exp2(p2);
         alpha[s] = fminf(0.99f, co.w * G[s]);
-        valid[s] = (contributor < lastc[s]) && (power <= 0.0f) && (alpha[s] >= 1.0f / 255.0f);
+        valid[s] = (contributor < lastc[s]) && (p2 <= 0.0f) && (alpha[s] >= 1.0f / 255.0f);
         any_valid |= valid[s];
       }
       if (!__any(any_valid)) continue;
 
+      // Raw sums; the constant factors of backward.cu:617-635 are applied once per (tile, Gaussian) after the
+      // reduction:  mean2D.x = (0.5 W / log2e) * sum h (2 qa dx + qb dy),  conic.xx = -0.5 * sum h dx^2, ...
+      // with h = opacity * G * dL_dalpha.
       float v_mx = 0.f, v_my = 0.f, v_cxx = 0.f, v_cxy = 0.f, v_cyy = 0.f, v_op = 0.f;
       float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_id = 0.f;
       const float4 k = s_k[j];
+      const float q2a = co.x + co.x, q2c = co.z + co.z;
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         if (!__any(valid[s])) continue;  // wave-uniform: quadrant not touched by this Gaussian
@@ -166,42 +173,36 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
           float rinv = __builtin_amdgcn_rcpf(om);
           rinv = fmaf(rinv, fmaf(-om, rinv, 1.0f), rinv);
           T[s] = T[s] * rinv;
-          const float dchannel_dcolor = alpha[s] * T[s];
-          float dL_dalpha = 0.0f;
-          const float oma = 1.f - last_alpha[s];
-          acc0[s] = last_alpha[s] * lastc0[s] + oma * acc0[s];
+          const float w = alpha[s] * T[s];  // dchannel_dcolor
+          const float la = last_alpha[s];
+          acc0[s] = fmaf(la, lastc0[s] - acc0[s], acc0[s]);
+          acc1[s] = fmaf(la, lastc1[s] - acc1[s], acc1[s]);
+          acc2[s] = fmaf(la, lastc2[s] - acc2[s], acc2[s]);
           lastc0[s] = k.x;
-          dL_dalpha += (k.x - acc0[s]) * dLp0[s];
-          v_c0 += dchannel_dcolor * dLp0[s];
-          acc1[s] = last_alpha[s] * lastc1[s] + oma * acc1[s];
           lastc1[s] = k.y;
-          dL_dalpha += (k.y - acc1[s]) * dLp1[s];
-          v_c1 += dchannel_dcolor * dLp1[s];
-          acc2[s] = last_alpha[s] * lastc2[s] + oma * acc2[s];
           lastc2[s] = k.z;
-          dL_dalpha += (k.z - acc2[s]) * dLp2[s];
-          v_c2 += dchannel_dcolor * dLp2[s];
+          float dL_dalpha = (k.x - acc0[s]) * dLp0[s];
+          dL_dalpha = fmaf(k.y - acc1[s], dLp1[s], dL_dalpha);
+          dL_dalpha = fmaf(k.z - acc2[s], dLp2[s], dL_dalpha);
+          v_c0 = fmaf(w, dLp0[s], v_c0);
+          v_c1 = fmaf(w, dLp1[s], v_c1);
+          v_c2 = fmaf(w, dLp2[s], v_c2);
           if (HAS_INVDEPTH) {
-            const float invd = a.z;
-            accD[s] = last_alpha[s] * lastD[s] + oma * accD[s];
-            lastD[s] = invd;
-            dL_dalpha += (invd - accD[s]) * dLinv[s];
-            v_id += dchannel_dcolor * dLinv[s];
+            accD[s] = fmaf(la, lastD[s] - accD[s], accD[s]);
+            lastD[s] = a.z;
+            dL_dalpha = fmaf(a.z - accD[s], dLinv[s], dL_dalpha);
+            v_id = fmaf(w, dLinv[s], v_id);
           }
-          dL_dalpha *= T[s];
+          dL_dalpha = fmaf(dL_dalpha, T[s], -Tbg[s] * rinv);  // *T, then + (-T_final/(1-alpha)) * bg_dot_dpixel
           last_alpha[s] = alpha[s];
-          dL_dalpha += -Tbg[s] * rinv;  // (-T_final / (1 - alpha)) * bg_dot_dpixel, backward.cu:613
-          const float dL_dG = co.w * dL_dalpha;
-          const float gdx = G[s] * dx;
-          const float gdy = G[s] * dy;
-          const float dG_ddelx = -gdx * co.x - gdy * co.y;
-          const float dG_ddely = -gdy * co.z - gdx * co.y;
-          v_mx += dL_dG * dG_ddelx * ddelx_dx;
-          v_my += dL_dG * dG_ddely * ddely_dy;
-          v_cxx += -0.5f * gdx * dx * dL_dG;
-          v_cxy += -0.5f * gdx * dy * dL_dG;
-          v_cyy += -0.5f * gdy * dy * dL_dG;
-          v_op += G[s] * dL_dalpha;
+          v_op = fmaf(G[s], dL_dalpha, v_op);
+          const float h = co.w * G[s] * dL_dalpha;
+          const float hx = h * dx, hy = h * dy;
+          v_cxx = fmaf(hx, dx, v_cxx);
+          v_cxy = fmaf(hx, dy, v_cxy);
+          v_cyy = fmaf(hy, dy, v_cyy);
+          v_mx = fmaf(q2a, hx, fmaf(co.y, hy, v_mx));
+          v_my = fmaf(q2c, hy, fmaf(co.y, hx, v_my));
         }
       }
       // One reduction per (tile, Gaussian): 5 + 3 swap-adds pack the ten sums into three registers holding one
@@ -216,8 +217,8 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
       if ((lane & 15) == 15) {
         float* row = grad_rows + (size_t)s_id[j] * GR_STRIDE;
         const int q = lane >> 4;
-        if (t0 != 0.0f) atomicAdd(row + q, t0);
-        if (t1 != 0.0f) atomicAdd(row + 4 + q, t1);
+        if (t0 != 0.0f) atomicAdd(row + q, t0 * rowscale0);      // mean2D.x, mean2D.y, conic.xx, conic.xy
+        if (t1 != 0.0f) atomicAdd(row + 4 + q, t1 * rowscale1);  // conic.yy, opacity, colour r, g
         if (!(q & 1) && (HAS_INVDEPTH || q == 0) && t2 != 0.0f) atomicAdd(row + 8 + (q >> 1), t2);
       }
     }

@@ -11,6 +11,7 @@
 //
 // Bound: VALU (~22 issue slots + one v_exp_f32 per pixel x Gaussian pair); compulsory HBM traffic
 // is 4 B (id) + <=64 B (record) per instance and 24 B per pixel.
+#include "gs_blend.h"
 #include "gs_common.h"
 
 struct __attribute__((aligned(16))) StageRec {
@@ -76,9 +77,9 @@ __global__ void __launch_bounds__(GS_BLOCK) render_fwd_kernel(const uint2* __res
         const float4 a = s_a[j];
         const float4 co = s_c[j];
         const float dx = a.x - pixfx, dy = a.y - pixfy;
-        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        const float power = blend_power2(blend_stage_conic(co), dx, dy);  // same decision arithmetic as every blend kernel
         if (power > 0.0f) continue;
-        const float alpha = fminf(0.99f, co.w * __expf(power));
+        const float alpha = fminf(0.99f, co.w * blend_exp2(power));
         if (alpha < 1.0f / 255.0f) continue;
         const float test_T = T * (1 - alpha);
         if (test_T < 0.0001f) {

@@ -6,6 +6,7 @@
 // of once per quadrant, batches are 64 entries (a tile stops within 64 entries of its last live pixel, not
 // 256) and there is no workgroup barrier on which three waves wait for the slowest one.
 // Replaces renderCUDA<3> forward (forward.cu:274-397); per-pixel arithmetic and stopping rules unchanged.
+#include "gs_blend.h"
 #include "gs_common.h"
 
 #define WB 64
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
     __syncthreads();  // single wave: previous batch fully consumed
     s_a[lane] = make_float4(ra.x, ra.y, ra.w, 0.f);
-    s_c[lane] = rc;
+    s_c[lane] = blend_stage_conic(rc);  // (qa, qb, qc, opacity), see gs_blend.h
     {
       // Exact-safe tile cull: alpha >= 1/255 needs power >= -L with L = ln(255 * opacity); the set
       // {d : d^T Q d <= 2L} is an ellipse whose half-extent along x is sqrt(2 L Sigma_xx), Sigma = Q^-1
@@ -97,9 +98,9 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       for (int s = 0; s < 4; s++) {
         const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
         const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));
-        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-        alpha[s] = fminf(0.99f, co.w * __expf(power));
-        hit[s] = !done[s] && (power <= 0.0f) && (alpha[s] >= 1.0f / 255.0f);
+        const float p2 = blend_power2(co, dx, dy);
+        alpha[s] = fminf(0.99f, co.w * blend_exp2(p2));
+        hit[s] = !done[s] && (p2 <= 0.0f) && (alpha[s] >= 1.0f / 255.0f);
         any_hit |= hit[s];
       }
       if (!__any(any_hit)) continue;

@@ -7,6 +7,12 @@ Tolerance 1e-4 (relative to the tensor's max magnitude, fp32): rendered colour /
 final_T and all gradients - the blend kernels use FMA + v_exp_f32 and sum in a different order.
 A pixel whose alpha or transmittance sits within rounding distance of a hard threshold
 (alpha < 1/255, T < 1e-4) may legitimately flip; such pixels are counted and bounded separately.
+The same holds for gradients: one flipped decision changes that pixel's transmittance chain by a whole
+alpha quantum (1/255), i.e. ~4e-3 of everything the pixel back-propagates.  (Measured on the CPU side alone:
+the oracle compiled with and without FMA contraction - the freedom nvcc has with the reference - differs by
+4e-4 of max|dL_dscales| on the init-10k/400x400 scene because of ONE such pixel.)  The gradient tests
+therefore find the flipped pixels from the two forward states (`flip_mask`), bound their number, zero the
+image cotangent there for BOTH implementations and compare everything else at the tight tolerance.
 """
 import math
 
@@ -70,6 +76,16 @@ def compare_forward(h, o, name, skip=()):
     return dict(bad=int(bad.sum()), nflip=nflip, maxerr=float(dc.max()))
 
 
+def flip_mask(h, o):
+    """[H, W] bool: pixels whose forward state shows a threshold decision that went the other way."""
+    scale = max(1.0, float(o["color"].abs().max()))
+    m = (h["color"] - o["color"]).abs().amax(dim=0) > 0.2 * TOL * scale
+    m |= (h["final_T"] - o["final_T"]).abs().reshape(m.shape) > 0.2 * TOL
+    m |= (h["n_contrib"] != o["n_contrib"]).reshape(m.shape)
+    assert int(m.sum()) <= max(2, m.numel() // 2000), "%d flipped pixels" % int(m.sum())
+    return m
+
+
 SMALL = [
     dict(P=120, seed=1, W=48, H=40, aa=False, bg=(0.0, 0.0, 0.0), eye=(3.2, 1.0, 1.5)),
     dict(P=160, seed=2, W=37, H=53, aa=True, bg=(1.0, 0.5, 0.25), eye=(-2.5, 2.8, -0.7)),
@@ -103,6 +119,8 @@ def test_small_scenes_forward_state_and_gradients(hip, oracle, case):
     g = torch.Generator().manual_seed(100 + case["seed"])
     dL_dcolor = torch.randn((3, case["H"], case["W"]), generator=g)
     dL_dinv = torch.randn((1, case["H"], case["W"]), generator=g) * 0.3
+    keep = (~flip_mask(h, o)).float()
+    dL_dcolor, dL_dinv = dL_dcolor * keep, dL_dinv * keep
     ho = run_scene(dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, sc, cam, torch.device("cuda"), bg=bg,
                    antialiasing=case["aa"], dL_dcolor=dL_dcolor, dL_dinvdepth=dL_dinv)
     oo = run_scene(oracle.Rasterizer, oracle.Settings, sc, cam, torch.device("cpu"), bg=bg, antialiasing=case["aa"],
@@ -125,7 +143,7 @@ def test_config_sized_scenes(hip, oracle, kind, P, W, H, deg):
     info = compare_forward(h, o, name)
     print(name, "R=%d" % h["num_rendered"], info)
     g = torch.Generator().manual_seed(5)
-    dL_dcolor = torch.randn((3, H, W), generator=g)
+    dL_dcolor = torch.randn((3, H, W), generator=g) * (~flip_mask(h, o)).float()
     ho = run_scene(dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, sc, cam, torch.device("cuda"), bg=bg,
                    dL_dcolor=dL_dcolor)
     oo = run_scene(oracle.Rasterizer, oracle.Settings, sc, cam, torch.device("cpu"), bg=bg, dL_dcolor=dL_dcolor)
