@@ -67,7 +67,9 @@ typedef struct GsView {
   int32_t prefiltered; /* bool */
   int32_t antialiasing; /* bool */
   int32_t debug;       /* bool: synchronise + check after every launch (auxiliary.h:178-185) */
-  int32_t _pad;
+  int32_t tile_cull;   /* 0: instance lists = the reference's bounding-square rule (rasterizer_impl.cu:70-111), bit-identical
+                          point_list / ranges / num_rendered; 1: additionally drop (tile, Gaussian) pairs on which alpha <
+                          1/255 for every pixel (csrc/gs_tilecull.h) - same images and gradients, ~2.6x fewer instances */
   const float* bg;         /* [3] */
   const float* viewmatrix; /* [16] */
   const float* projmatrix; /* [16] */

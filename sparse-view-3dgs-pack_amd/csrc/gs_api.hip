@@ -87,6 +87,7 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   a.radii = radii;
   tile_grid(v, a.grid_x, a.grid_y);
   a.antialiasing = v->antialiasing;
+  a.tile_cull = v->tile_cull;
   {
     GS_PROF(ST_PREPROCESS_FWD, s);
     launch_preprocess_fwd(a, gv, s);
@@ -143,7 +144,7 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
     const int start = passes & 1;
     {
       GS_PROF(ST_DUPLICATE, s);
-      rc = launch_emit_instances(gv, P, gx, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
+      rc = launch_emit_instances(gv, P, gx, v->tile_cull, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
       if (rc) return rc;
     }
     {

@@ -21,6 +21,7 @@
 // All kernels read element counts from device memory so the host never waits for them; grids are sized
 // from a host-side upper bound.
 #include "gs_common.h"
+#include "gs_tilecull.h"
 
 __global__ void bin_prepare_kernel(GeomHeader* hdr, uint32_t capacity) {
   const uint32_t R = hdr->num_rendered;
@@ -238,58 +239,134 @@ __global__ void __launch_bounds__(GS_BLOCK) sorted_block_sums_kernel(const uint3
   if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, uint32_t grid_x,
-                                                             const uint32_t* __restrict__ order,
-                                                             const uint32_t* __restrict__ block_base,
-                                                             uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals) {
-  __shared__ uint32_t s_off[GS_BLOCK + 1];  // exclusive local offsets
-  __shared__ uint32_t s_wsum[GS_BLOCK / 64];
-  __shared__ uint32_t s_id[GS_BLOCK];
-  __shared__ uint32_t s_rmin[GS_BLOCK];
-  __shared__ uint32_t s_w[GS_BLOCK];
-  if (g.hdr->overflow) return;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int i = blockIdx.x * GS_BLOCK + tid;
-  uint32_t tiles = 0;
-  if (i < P) {
-    const uint32_t id = order[i];
-    // one 16-B load covers rect_min, rect_max, tiles, clamped
-    const uint4 tail = reinterpret_cast<const uint4*>(&g.splat[id])[3];
-    tiles = tail.z;
-    s_id[tid] = id;
-    s_rmin[tid] = tail.x;
-    s_w[tid] = (tail.y & 0xFFFFu) - (tail.x & 0xFFFFu);
-  }
-  uint32_t inc = tiles;
+// Instance emission (duplicateWithKeys, rasterizer_impl.cu:70-111) in depth order.  The unit of work is one
+// TILE ROW of one Gaussian: a workgroup takes 256 consecutive Gaussians of the depth order, expands them into
+// their rectangle rows (binary search over the row-count prefix in LDS), evaluates each row's column span once
+// (whole row, or the ellipse span of gs_tilecull.h), scans the span lengths and then writes the instances with
+// one binary search per instance - coalesced stores, no lane serialised on a Gaussian covering thousands of
+// tiles, and no per-instance re-evaluation of the spans.  Rows are processed DUP_RC at a time to bound LDS.
+#define DUP_RC 1024
+__device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t* s_wsum, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t inc = v;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     uint32_t t = __shfl_up(inc, off, 64);
     if (lane >= off) inc += t;
   }
+  __syncthreads();  // s_wsum may still be read from a previous call
   if (lane == 63) s_wsum[wid] = inc;
   __syncthreads();
   uint32_t woff = 0;
   for (int w = 0; w < wid; w++) woff += s_wsum[w];
-  const uint32_t base = block_base[blockIdx.x];
-  s_off[tid] = woff + inc - tiles;
-  if (tid == GS_BLOCK - 1) s_off[GS_BLOCK] = woff + inc;
-  __syncthreads();
-  const uint32_t total = s_off[GS_BLOCK];
-  for (uint32_t k0 = tid; k0 < total; k0 += GS_BLOCK) {
-    // largest gi with s_off[gi] <= k0
-    int lo = 0, hi = GS_BLOCK - 1;
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      int mid = (lo + hi + 1) >> 1;
-      if (s_off[mid] <= k0) lo = mid; else hi = mid - 1;
+  total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  return woff + inc - v;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, uint32_t grid_x, int tile_cull,
+                                                             const uint32_t* __restrict__ order,
+                                                             const uint32_t* __restrict__ block_base,
+                                                             uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals) {
+  __shared__ uint32_t s_wsum[GS_BLOCK / 64];
+  __shared__ uint32_t s_rowoff[GS_BLOCK + 1];  // exclusive prefix of rows per Gaussian
+  __shared__ uint32_t s_id[GS_BLOCK];
+  __shared__ uint32_t s_rmin[GS_BLOCK];
+  __shared__ uint32_t s_rmax[GS_BLOCK];
+  __shared__ TileCull s_cull[GS_BLOCK];
+  __shared__ uint32_t s_span_off[DUP_RC + 1];  // exclusive prefix of span lengths within the row chunk
+  __shared__ uint32_t s_span_key[DUP_RC];      // first tile id of the span
+  __shared__ uint32_t s_span_own[DUP_RC];      // owner (index into s_id)
+  if (g.hdr->overflow) return;
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * GS_BLOCK + tid;
+  uint32_t tiles = 0, rows = 0;
+  if (i < P) {
+    const uint32_t id = order[i];
+    const float4* rec = reinterpret_cast<const float4*>(&g.splat[id]);
+    const uint4 tail = reinterpret_cast<const uint4*>(rec)[3];  // rect_min, rect_max, tiles, clamped
+    tiles = tail.z;
+    s_id[tid] = id;
+    s_rmin[tid] = tail.x;
+    s_rmax[tid] = tail.y;
+    if (tiles) {
+      rows = (tail.y >> 16) - (tail.x >> 16);
+      if (tile_cull) {
+        const float4 ra = rec[0], rc = rec[1];
+        s_cull[tid] = tilecull_setup(1, ra.x, ra.y, rc.x, rc.y, rc.z, rc.w);
+      } else {
+        s_cull[tid].mode = 0;
+      }
     }
-    const uint32_t k = k0 - s_off[lo];
-    const uint32_t w = s_w[lo];
-    const uint32_t rmin = s_rmin[lo];
-    const uint32_t ty = (rmin >> 16) + k / w;
-    const uint32_t tx = (rmin & 0xFFFFu) + k % w;
-    tkeys[base + k0] = ty * grid_x + tx;
-    tvals[base + k0] = s_id[lo];
+  }
+  uint32_t total_rows, expected;
+  const uint32_t my_rowoff = block_exclusive_scan256(rows, s_wsum, total_rows);
+  s_rowoff[tid] = my_rowoff;
+  if (tid == 0) s_rowoff[GS_BLOCK] = total_rows;
+  (void)block_exclusive_scan256(tiles, s_wsum, expected);  // what the prefix sum reserved for this workgroup
+  uint32_t written = 0;                                    // instances emitted so far (uniform)
+  const uint32_t base = block_base[blockIdx.x];
+  uint32_t last_key = 0, last_own = 0;
+  for (uint32_t rbase = 0; rbase < total_rows; rbase += DUP_RC) {
+    const uint32_t nrow = min((uint32_t)DUP_RC, total_rows - rbase);
+    // each thread evaluates DUP_RC / 256 consecutive rows
+    uint32_t n4[DUP_RC / GS_BLOCK], local = 0;
+#pragma unroll
+    for (int j = 0; j < DUP_RC / GS_BLOCK; j++) {
+      const uint32_t r = tid * (DUP_RC / GS_BLOCK) + j;
+      uint32_t n = 0;
+      if (r < nrow) {
+        const uint32_t rs = rbase + r;
+        int lo = 0, hi = GS_BLOCK - 1;  // largest owner with s_rowoff[owner] <= rs
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (s_rowoff[mid] <= rs) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t rmin = s_rmin[lo], rmax = s_rmax[lo];
+        const uint32_t ty = (rmin >> 16) + (rs - s_rowoff[lo]);
+        uint32_t tx0;
+        n = tilecull_row_span(s_cull[lo], ty, rmin & 0xFFFFu, rmax & 0xFFFFu, tx0);
+        s_span_key[r] = ty * grid_x + tx0;
+        s_span_own[r] = (uint32_t)lo;
+      }
+      n4[j] = n;
+      local += n;
+    }
+    uint32_t chunk_total;
+    uint32_t off = block_exclusive_scan256(local, s_wsum, chunk_total);
+#pragma unroll
+    for (int j = 0; j < DUP_RC / GS_BLOCK; j++) {
+      const uint32_t r = tid * (DUP_RC / GS_BLOCK) + j;
+      if (r < nrow) s_span_off[r] = off;
+      off += n4[j];
+    }
+    if (tid == 0) s_span_off[nrow] = chunk_total;
+    __syncthreads();
+    // never write past what the prefix sum reserved (the two evaluations of the spans agree; this keeps the
+    // kernel memory-safe even if they did not)
+    const uint32_t room = expected - min(expected, written);
+    const uint32_t emit = min(chunk_total, room);
+    for (uint32_t k = tid; k < emit; k += GS_BLOCK) {
+      int lo = 0, hi = (int)nrow - 1;  // largest row with s_span_off[row] <= k
+#pragma unroll
+      for (int it = 0; it < 10; it++) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_span_off[mid] <= k) lo = mid; else hi = mid - 1;
+      }
+      tkeys[base + written + k] = s_span_key[lo] + (k - s_span_off[lo]);
+      tvals[base + written + k] = s_id[s_span_own[lo]];
+    }
+    if (nrow > 0) {
+      last_key = s_span_key[nrow - 1];
+      last_own = s_span_own[nrow - 1];
+    }
+    written += emit;
+    __syncthreads();  // the chunk arrays are rewritten by the next iteration
+  }
+  // (unreachable when both evaluations agree) fill what is left with a valid instance of this workgroup
+  for (uint32_t k = written + tid; k < expected; k += GS_BLOCK) {
+    tkeys[base + k] = last_key;
+    tvals[base + k] = s_id[last_own];
   }
 }
 
@@ -391,13 +468,13 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
   return 0;
 }
 
-int launch_emit_instances(const GeomView& g, int P, int grid_x, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
+int launch_emit_instances(const GeomView& g, int P, int grid_x, int tile_cull, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
                           hipStream_t s, int debug) {
   const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
   hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, order, g.tiles_touched, P, g.sorted_sums);
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, g.sorted_sums, nb);
   GS_LAUNCH_CHECK(s, debug);
-  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, P, (uint32_t)grid_x, order, g.sorted_sums, tkeys,
+  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, P, (uint32_t)grid_x, tile_cull, order, g.sorted_sums, tkeys,
                      tvals);
   GS_LAUNCH_CHECK(s, debug);
   return 0;

@@ -196,6 +196,7 @@ struct PreprocessArgs {
   int* radii;
   int grid_x, grid_y;
   int antialiasing;
+  int tile_cull;  // GsView.tile_cull: 1 = emit only tiles the alpha >= 1/255 ellipse can reach (gs_tilecull.h)
 };
 int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_t s);
 int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s);
@@ -205,7 +206,7 @@ int launch_bin_prepare(const GeomView& g, int64_t capacity, hipStream_t s);
 // first_keys != NULL: the first pass reads its keys from there (left untouched) and takes value = index
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
                       const uint32_t* first_keys, hipStream_t s, int debug);
-int launch_emit_instances(const GeomView& g, int P, int grid_x, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
+int launch_emit_instances(const GeomView& g, int P, int grid_x, int tile_cull, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
                           hipStream_t s, int debug);
 int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
                        hipStream_t s);

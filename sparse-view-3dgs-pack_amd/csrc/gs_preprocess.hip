@@ -7,6 +7,7 @@
 // 236 B of reads (12 xyz + 12 scale + 16 quat + 4 opacity + 192 SH) and 96 B of writes
 // (64-B splat record, 24 B cov3D, 4 B tiles, 4 B radii).
 #include "gs_common.h"
+#include "gs_tilecull.h"
 #include "gs_math.h"
 
 // forward.cu:20-71.  sh points at this Gaussian's coefficients as 3*M floats.
@@ -156,7 +157,19 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       sp.opacity = a.opacities[idx] * h_convolution_scaling;
       sp.rect_min = minx | (miny << 16);
       sp.rect_max = maxx | (maxy << 16);
-      tiles = (maxy - miny) * (maxx - minx);
+      if (a.tile_cull) {
+        const TileCull tc = tilecull_setup(1, sp.x, sp.y, sp.cxx, sp.cxy, sp.cyy, sp.opacity);
+        if (tc.mode == 0) {
+          tiles = (maxy - miny) * (maxx - minx);
+        } else if (tc.mode == 2) {
+          for (uint32_t ty = miny; ty < maxy; ty++) {
+            uint32_t tx0;
+            tiles += tilecull_row_span(tc, ty, minx, maxx, tx0);
+          }
+        }
+      } else {
+        tiles = (maxy - miny) * (maxx - minx);
+      }
       sp.tiles = tiles;
     } while (false);
 

@@ -22,7 +22,7 @@ class GsView(C.Structure):
         ("prefiltered", C.c_int32),
         ("antialiasing", C.c_int32),
         ("debug", C.c_int32),
-        ("_pad", C.c_int32),
+        ("tile_cull", C.c_int32),
         ("bg", C.c_void_p),
         ("viewmatrix", C.c_void_p),
         ("projmatrix", C.c_void_p),
