@@ -89,6 +89,9 @@ typedef struct GsGaussians {
   const float* scales;         /* [P,3] or NULL */
   const float* rotations;      /* [P,4] or NULL (r,x,y,z; NOT renormalised, forward.cu:123) */
   const float* cov3D_precomp;  /* [P,6] or NULL */
+  const float* extra_channel;  /* [P] or NULL: a 4th per-Gaussian value blended with the same weights as the colour
+                                  (gs_forward_render_x); replaces the reference's second rasterizer pass for the NIR
+                                  albedo, mult-dwtgs/gaussian_renderer/__init__.py:151-258 */
 } GsGaussians;
 
 /* Caller-owned scratch.  geom and img sizes depend on (P, W, H); binning on the capacity in
@@ -118,6 +121,7 @@ typedef struct GsGrads {
   float* dL_dscales;    /* [P,3] */
   float* dL_drotations; /* [P,4] */
   float* dL_dcov3D;     /* [P,6] */
+  float* dL_dextra;     /* [P]  gradient of GsGaussians.extra_channel (gs_backward_x only), may be NULL */
 } GsGrads;
 
 int gs_abi_version(void);
@@ -146,6 +150,13 @@ int gs_forward_geometry(const GsView* view, const GsGaussians* g, GsScratch* scr
 int gs_forward_render(const GsView* view, const GsGaussians* g, GsScratch* scratch,
                       float* out_color, float* out_invdepth, void* stream);
 
+/* gs_forward_render with a 4th blended channel: out_extra[H,W] = sum_i extra_i alpha_i T_i + T_final * bg[0], i.e.
+ * channel 0 of a second rasterizer pass with colors_precomp = extra.repeat(1,3) - what the reference's render_nir
+ * keeps (mult-dwtgs/gaussian_renderer/__init__.py:190-256) - sharing preprocess, binning and the alpha evaluation
+ * with the colour pass.  out_extra == NULL is gs_forward_render. */
+int gs_forward_render_x(const GsView* view, const GsGaussians* g, GsScratch* scratch,
+                        float* out_color, float* out_invdepth, float* out_extra, void* stream);
+
 /* Backward of the whole rasterizer.  num_rendered is the value forward produced.
  * dL_dinvdepth may be NULL (then no inverse-depth gradient path runs).
  * workspace: >= backward_workspace_bytes from gs_scratch_bytes. */
@@ -153,6 +164,13 @@ int gs_backward(const GsView* view, const GsGaussians* g, const int32_t* radii,
                 const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
                 const float* dL_dinvdepth, const GsGrads* grads, void* workspace,
                 size_t workspace_bytes, void* stream);
+
+/* gs_backward with the image gradient of the 4th channel (dL_dextra_img [H,W], NULL = gs_backward); geometry
+ * gradients are those of the sum of both passes, grads->dL_dextra[P] receives the channel's own gradient. */
+int gs_backward_x(const GsView* view, const GsGaussians* g, const int32_t* radii,
+                  const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
+                  const float* dL_dinvdepth, const float* dL_dextra_img, const GsGrads* grads,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* present[i] = (view-space z of means3D[i]) > 0.2   (rasterizer_impl.cu:54-66) */
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,

@@ -87,6 +87,7 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   a.radii = radii;
   tile_grid(v, a.grid_x, a.grid_y);
   a.antialiasing = v->antialiasing;
+  a.extra_channel = g->extra_channel;
   a.tile_cull = v->tile_cull;
   {
     GS_PROF(ST_PREPROCESS_FWD, s);
@@ -105,9 +106,15 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
 
 int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_invdepth,
                       void* stream) {
+  return gs_forward_render_x(v, g, sc, out_color, out_invdepth, nullptr, stream);
+}
+
+int gs_forward_render_x(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_invdepth,
+                        float* out_extra, void* stream) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !sc->geom || !sc->img || !out_color) return GS_E_NULL;
+  if (out_extra && !g->extra_channel) return GS_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   const int P = g->P, W = v->image_width, H = v->image_height;
   int gx, gy;
@@ -117,6 +124,7 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
   if (P == 0) {  // rasterize_points.cu:88 - outputs stay zero
     GS_HIP_CHECK(hipMemsetAsync(out_color, 0, sizeof(float) * GS_NUM_CHANNELS * N, s));
     if (out_invdepth) GS_HIP_CHECK(hipMemsetAsync(out_invdepth, 0, sizeof(float) * N, s));
+    if (out_extra) GS_HIP_CHECK(hipMemsetAsync(out_extra, 0, sizeof(float) * N, s));
     return GS_OK;
   }
   if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
@@ -163,12 +171,13 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
     GS_PROF(ST_RENDER_FWD, s);
     // GS_FWD_KERNEL=quad selects the first-generation kernel (one pixel per lane, four waves per tile)
     static const bool quad = getenv("GS_FWD_KERNEL") && !strcmp(getenv("GS_FWD_KERNEL"), "quad");
+    if (quad && out_extra) return GS_E_UNSUPPORTED;  // the first-generation kernels blend three channels only
     if (quad)
       launch_render_fwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
                         out_invdepth, s);
     else
       launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
-                             out_invdepth, s);
+                             out_invdepth, out_extra, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
@@ -177,9 +186,17 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
 int gs_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
                 int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const GsGrads* grads,
                 void* workspace, size_t workspace_bytes, void* stream) {
+  return gs_backward_x(v, g, radii, sc, num_rendered, dL_dcolor, dL_dinvdepth, nullptr, grads, workspace, workspace_bytes,
+                       stream);
+}
+
+int gs_backward_x(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
+                  int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra,
+                  const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !grads || !dL_dcolor) return GS_E_NULL;
+  if (dL_dextra && (!g->extra_channel || !grads->dL_dextra)) return GS_E_NULL;
   const int P = g->P, W = v->image_width, H = v->image_height;
   if (P == 0) return GS_OK;
   if (!radii || !sc->geom || !sc->img || !workspace) return GS_E_NULL;
@@ -203,12 +220,13 @@ int gs_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, con
       GS_PROF(ST_RENDER_BWD, s);
       // GS_BWD_KERNEL=quad selects the first-generation kernel (one pixel per lane, four waves per tile)
       static const bool quad = getenv("GS_BWD_KERNEL") && !strcmp(getenv("GS_BWD_KERNEL"), "quad");
+      if (quad && dL_dextra) return GS_E_UNSUPPORTED;
       if (quad)
         launch_render_bwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
                           dL_dinvdepth, rows, s);
       else
         launch_render_bwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
-                               dL_dinvdepth, rows, s);
+                               dL_dinvdepth, dL_dextra, rows, s);
     }
     GS_LAUNCH_CHECK(s, v->debug);
   }
@@ -264,7 +282,7 @@ __global__ void export_geom_kernel(GeomView g, int P, float* depths, float* mean
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const Splat sp = g.splat[i];
-  const bool vis = sp.radius > 0;
+  const bool vis = sp.rect_max != 0;  // a visible Gaussian has a non-empty tile rectangle (maxx >= 1)
   if (depths) depths[i] = vis ? sp.depth : 0.f;
   if (means2D) {
     means2D[2 * i] = vis ? sp.x : 0.f;

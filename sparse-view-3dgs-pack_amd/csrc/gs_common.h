@@ -40,7 +40,7 @@ struct __attribute__((aligned(64))) Splat {
   float cxx, cxy, cyy;  // conic
   float opacity;     // opacity * antialiasing scaling
   float r, g, b;     // SH colour (+0.5, clamped) or colors_precomp
-  int32_t radius;    // 0 = culled
+  float extra;       // optional 4th blended channel (GsGaussians.extra_channel, e.g. NIR albedo), else 0
   uint32_t rect_min; // x | y << 16
   uint32_t rect_max;
   uint32_t tiles;    // tiles_touched
@@ -138,7 +138,7 @@ static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T
 static inline __host__ __device__ size_t bin_bytes(size_t cap) { return sort_bytes(cap); }
 
 // per-Gaussian gradient row accumulated by the backward blend (one 64-B line per Gaussian)
-enum { GR_MX = 0, GR_MY, GR_CXX, GR_CXY, GR_CYY, GR_OP, GR_CR, GR_CG, GR_CB, GR_ID, GR_N, GR_STRIDE = 16 };
+enum { GR_MX = 0, GR_MY, GR_CXX, GR_CXY, GR_CYY, GR_OP, GR_CR, GR_CG, GR_CB, GR_ID, GR_EXTRA, GR_N, GR_STRIDE = 16 };
 
 // rasterizer_impl.cu:35-50 (host)
 static inline uint32_t gs_higher_msb(uint32_t n) {
@@ -196,6 +196,7 @@ struct PreprocessArgs {
   int* radii;
   int grid_x, grid_y;
   int antialiasing;
+  const float* extra_channel;  // [P] or NULL
   int tile_cull;  // GsView.tile_cull: 1 = emit only tiles the alpha >= 1/255 ellipse can reach (gs_tilecull.h)
 };
 int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_t s);
@@ -220,10 +221,10 @@ int launch_render_bwd(const uint2* ranges, const uint32_t* point_list, int W, in
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                           float* out_invdepth, hipStream_t s);
+                           float* out_invdepth, float* out_extra, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                           const float* dL_dpix, const float* dL_dinvdepth, float* grad_rows, hipStream_t s);
+                           const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, hipStream_t s);
 
 struct PreprocessBwdArgs {
   int P, D, M;

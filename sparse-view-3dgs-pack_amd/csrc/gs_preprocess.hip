@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
     sp.x = sp.y = sp.depth = sp.invdepth = 0.f;
     sp.cxx = sp.cxy = sp.cyy = sp.opacity = 0.f;
     sp.r = sp.g = sp.b = 0.f;
-    sp.radius = 0;
+    sp.extra = 0.f;
+    int radius_out = 0;
     sp.rect_min = sp.rect_max = sp.tiles = sp.clamped = 0;
     float cov3D[6] = {0, 0, 0, 0, 0, 0};
     bool write_cov = false;
@@ -150,7 +151,8 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       }
       sp.depth = p_view.z;
       sp.invdepth = 1 / p_view.z;
-      sp.radius = radius_i;
+      radius_out = radius_i;
+      sp.extra = a.extra_channel ? a.extra_channel[idx] : 0.f;
       sp.x = pix_x;
       sp.y = pix_y;
       sp.cxx = conic.x; sp.cxy = conic.y; sp.cyy = conic.z;
@@ -186,7 +188,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
     g.tiles_touched[idx] = tiles;
     // key of the per-Gaussian depth sort (gs_binning.hip): culled Gaussians sort behind everything
     g.depth_keys[idx] = tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
-    a.radii[idx] = sp.radius;
+    a.radii[idx] = radius_out;
   }
   // per-workgroup partial sum of tiles_touched for the prefix sum
   __shared__ uint32_t red[GS_BLOCK / 64];

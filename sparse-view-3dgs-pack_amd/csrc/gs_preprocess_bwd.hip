@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
   V3 dL_dmean = {0, 0, 0};
   float dL_dmean2D_x = 0.f, dL_dmean2D_y = 0.f;
   float dL_dcov[6] = {0, 0, 0, 0, 0, 0};
-  float dL_dop = 0.f;
+  float dL_dop = 0.f, dL_dextra = 0.f;
   V3 dL_dcolor = {0, 0, 0};
   V3 dL_dscale = {0, 0, 0};
   float dL_dq[4] = {0, 0, 0, 0};
@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
     dL_dop = g1.y;
     dL_dcolor = {g1.z, g1.w, g2.x};
     const float dL_dinvdepth = g2.y;
+    dL_dextra = g2.z;
 
     // ------------------------------------------------------------------ computeCov2DCUDA
     const float* cov3D = a.cov3D + 6 * (size_t)idx;
@@ -296,6 +297,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
     o.dL_dcolors[3 * idx + 2] = dL_dcolor.z;
   }
   if (o.dL_dopacity) o.dL_dopacity[idx] = dL_dop;
+  if (o.dL_dextra) o.dL_dextra[idx] = dL_dextra;
   if (o.dL_dcov3D) {
     float2* cd = reinterpret_cast<float2*>(o.dL_dcov3D + (size_t)idx * 6);
     cd[0] = make_float2(dL_dcov[0], dL_dcov[1]);

@@ -48,15 +48,15 @@ __device__ __forceinline__ float row_total_in_lane15(float v) {
 
 #define WB 64  // batch = one list entry per lane
 
-template <bool HAS_INVDEPTH>
-__global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
+template <bool HAS_INVDEPTH, bool HAS_EXTRA>
+__global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) render_bwd_wave_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const Splat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-    const float* __restrict__ dL_invdepths, float* __restrict__ grad_rows) {
+    const float* __restrict__ dL_invdepths, const float* __restrict__ dL_dextra, float* __restrict__ grad_rows) {
   __shared__ float4 s_a[WB];  // x, y, invdepth, -
   __shared__ float4 s_c[WB];  // conic, opacity
-  __shared__ float4 s_k[WB];  // rgb
+  __shared__ float4 s_k[WB];  // rgb, 4th channel
   __shared__ uint32_t s_id[WB];
 
   const int tile = blockIdx.x;
@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
   const float pixfx0 = (float)px0, pixfy0 = (float)py0;
   const size_t HW = (size_t)H * W;
 
-  float T[4], Tbg[4], dLp0[4], dLp1[4], dLp2[4], dLinv[4];  // Tbg = T_final * (bg . dL_dpixel)
-  float acc0[4], acc1[4], acc2[4], accD[4], lastc0[4], lastc1[4], lastc2[4], lastD[4], last_alpha[4];
+  float T[4], Tbg[4], dLp0[4], dLp1[4], dLp2[4], dLinv[4], dLpX[4];  // Tbg = T_final * (bg . dL_dpixel)
+  float acc0[4], acc1[4], acc2[4], accD[4], accX[4], lastc0[4], lastc1[4], lastc2[4], lastD[4], lastX[4], last_alpha[4];
   uint32_t lastc[4];
   uint32_t lmax = 0;
 #pragma unroll
@@ -87,13 +87,15 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
     dLp1[s] = inside ? dL_dpixels[HW + pix_id] : 0.f;
     dLp2[s] = inside ? dL_dpixels[2 * HW + pix_id] : 0.f;
     dLinv[s] = (HAS_INVDEPTH && inside) ? dL_invdepths[pix_id] : 0.f;
+    dLpX[s] = (HAS_EXTRA && inside) ? dL_dextra[pix_id] : 0.f;
     float b = 0;
+    if (HAS_EXTRA) b += bg[0] * dLpX[s];  // the 4th channel's image is X + T bg[0]
     b += bg[0] * dLp0[s];
     b += bg[1] * dLp1[s];
     b += bg[2] * dLp2[s];
     Tbg[s] = T[s] * b;
-    acc0[s] = acc1[s] = acc2[s] = accD[s] = 0.f;
-    lastc0[s] = lastc1[s] = lastc2[s] = lastD[s] = last_alpha[s] = 0.f;
+    acc0[s] = acc1[s] = acc2[s] = accD[s] = accX[s] = 0.f;
+    lastc0[s] = lastc1[s] = lastc2[s] = lastD[s] = lastX[s] = last_alpha[s] = 0.f;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, off, 64));
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
       // reduction:  mean2D.x = (0.5 W / log2e) * sum h (2 qa dx + qb dy),  conic.xx = -0.5 * sum h dx^2, ...
       // with h = opacity * G * dL_dalpha.
       float v_mx = 0.f, v_my = 0.f, v_cxx = 0.f, v_cxy = 0.f, v_cyy = 0.f, v_op = 0.f;
-      float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_id = 0.f;
+      float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_id = 0.f, v_x = 0.f;
       const float4 k = s_k[j];
       const float q2a = co.x + co.x, q2c = co.z + co.z;
 #pragma unroll
@@ -193,6 +195,12 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
             dL_dalpha = fmaf(a.z - accD[s], dLinv[s], dL_dalpha);
             v_id = fmaf(w, dLinv[s], v_id);
           }
+          if (HAS_EXTRA) {
+            accX[s] = fmaf(la, lastX[s] - accX[s], accX[s]);
+            lastX[s] = k.w;
+            dL_dalpha = fmaf(k.w - accX[s], dLpX[s], dL_dalpha);
+            v_x = fmaf(w, dLpX[s], v_x);
+          }
           dL_dalpha = fmaf(dL_dalpha, T[s], -Tbg[s] * rinv);  // *T, then + (-T_final/(1-alpha)) * bg_dot_dpixel
           last_alpha[s] = alpha[s];
           v_op = fmaf(G[s], dL_dalpha, v_op);
@@ -213,13 +221,16 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
       const float s4 = swap32_add(v_c2, v_id);                                  // (8|9)
       const float t0 = row_total_in_lane15(swap16_add(s0, s1));                 // rows: 0 1 2 3
       const float t1 = row_total_in_lane15(swap16_add(s2, s3));                 // rows: 4 5 6 7
-      const float t2 = row_total_in_lane15(swap16_add(s4, 0.f));                // rows: 8 - 9 -
+      const float s5 = HAS_EXTRA ? swap32_add(v_x, 0.f) : 0.f;                  // (10|-)
+      const float t2 = row_total_in_lane15(swap16_add(s4, s5));                 // rows: 8 10 9 -
       if ((lane & 15) == 15) {
         float* row = grad_rows + (size_t)s_id[j] * GR_STRIDE;
         const int q = lane >> 4;
         if (t0 != 0.0f) atomicAdd(row + q, t0 * rowscale0);      // mean2D.x, mean2D.y, conic.xx, conic.xy
         if (t1 != 0.0f) atomicAdd(row + 4 + q, t1 * rowscale1);  // conic.yy, opacity, colour r, g
-        if (!(q & 1) && (HAS_INVDEPTH || q == 0) && t2 != 0.0f) atomicAdd(row + 8 + (q >> 1), t2);
+        // colour b (row 0 -> slot 8), 4th channel (row 1 -> slot 10), inverse depth (row 2 -> slot 9)
+        const bool live2 = q == 0 || (HAS_EXTRA && q == 1) || (HAS_INVDEPTH && q == 2);
+        if (live2 && t2 != 0.0f) atomicAdd(row + (q == 0 ? GR_CB : (q == 1 ? GR_EXTRA : GR_ID)), t2);
       }
     }
   }
@@ -227,12 +238,15 @@ __global__ void __launch_bounds__(64, 4) render_bwd_wave_kernel(
 
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                           const float* dL_dpix, const float* dL_dinvdepth, float* grad_rows, hipStream_t s) {
-  if (dL_dinvdepth)
-    hipLaunchKernelGGL(render_bwd_wave_kernel<true>, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x,
-                       splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, grad_rows);
-  else
-    hipLaunchKernelGGL(render_bwd_wave_kernel<false>, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x,
-                       splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, grad_rows);
+                           const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows,
+                           hipStream_t s) {
+#define GS_BWD_WAVE(ID, EX)                                                                                            \
+  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, \
+                     grid_x, splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, dL_dextra, grad_rows)
+  if (dL_dinvdepth && dL_dextra) GS_BWD_WAVE(true, true);
+  else if (dL_dinvdepth) GS_BWD_WAVE(true, false);
+  else if (dL_dextra) GS_BWD_WAVE(false, true);
+  else GS_BWD_WAVE(false, false);
+#undef GS_BWD_WAVE
   return 0;
 }

@@ -11,16 +11,19 @@
 
 #define WB 64
 
+template <bool HAS_EXTRA>
 __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list, int W, int H,
                                                              int grid_x, const Splat* __restrict__ splat,
                                                              const float* __restrict__ bg, float* __restrict__ final_T,
                                                              uint32_t* __restrict__ n_contrib,
                                                              float* __restrict__ out_color,
-                                                             float* __restrict__ out_invdepth) {
-  __shared__ float4 s_a[WB];  // x, y, invdepth, -
+                                                             float* __restrict__ out_invdepth,
+                                                             float* __restrict__ out_extra) {
+  __shared__ float4 s_a[WB];  // x, y, invdepth, cull extent y
   __shared__ float4 s_c[WB];  // conic, opacity
-  __shared__ float4 s_k[WB];  // rgb
+  __shared__ float4 s_k[WB];  // rgb, cull extent x
+  __shared__ float s_e[HAS_EXTRA ? WB : 1];  // 4th channel (N1: NIR albedo blended with the same weights)
 
   const int tile = blockIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -33,7 +36,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
   const int n = (int)(range.y - range.x);
   const int rounds = (n + WB - 1) / WB;
 
-  float T[4], C0[4], C1[4], C2[4], D[4];
+  float T[4], C0[4], C1[4], C2[4], D[4], X[4];
   uint32_t last_contributor[4];
   bool done[4], inside[4];
 #pragma unroll
@@ -42,7 +45,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     inside[s] = px < W && py < H;
     done[s] = !inside[s];
     T[s] = 1.0f;
-    C0[s] = C1[s] = C2[s] = D[s] = 0.f;
+    C0[s] = C1[s] = C2[s] = D[s] = X[s] = 0.f;
     last_contributor[s] = 0;
   }
 
@@ -71,6 +74,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       const float ey = ok ? sqrtf(L2 * rc.x / det) * 1.02f + 1.0f : (L2 >= 0.f ? 3.0e38f : -1.0f);
       s_k[lane] = make_float4(rk.x, rk.y, rk.z, ex);
       s_a[lane].w = ey;
+      if (HAS_EXTRA) s_e[lane] = rk.w;
     }
     __syncthreads();
     {
@@ -116,6 +120,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
             C1[s] += k.y * w;
             C2[s] += k.z * w;
             D[s] += a.z * w;
+            if (HAS_EXTRA) X[s] += s_e[j] * w;
             T[s] = test_T;
             last_contributor[s] = contributor;
           }
@@ -137,14 +142,19 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       out_color[HW + pix_id] = C1[s] + T[s] * bg1;
       out_color[2 * HW + pix_id] = C2[s] + T[s] * bg2;
       if (out_invdepth) out_invdepth[pix_id] = D[s];
+      if (HAS_EXTRA) out_extra[pix_id] = X[s] + T[s] * bg0;  // the reference's NIR pass keeps channel 0 (bg[0])
     }
   }
 }
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                           float* out_invdepth, hipStream_t s) {
-  hipLaunchKernelGGL(render_fwd_wave_kernel, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x, splat,
-                     bg, final_T, n_contrib, out_color, out_invdepth);
+                           float* out_invdepth, float* out_extra, hipStream_t s) {
+  if (out_extra)
+    hipLaunchKernelGGL(render_fwd_wave_kernel<true>, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x,
+                       splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
+  else
+    hipLaunchKernelGGL(render_fwd_wave_kernel<false>, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x,
+                       splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
   return 0;
 }

@@ -21,12 +21,12 @@ class _Backend:
 backend = _Backend()
 
 
-def rasterize_gaussians(*args):
-    return hip_backend().rasterize_gaussians(*args)
+def rasterize_gaussians(*args, **kw):
+    return hip_backend().rasterize_gaussians(*args, **kw)
 
 
-def rasterize_gaussians_backward(*args):
-    return hip_backend().rasterize_gaussians_backward(*args)
+def rasterize_gaussians_backward(*args, **kw):
+    return hip_backend().rasterize_gaussians_backward(*args, **kw)
 
 
 def mark_visible(*args):

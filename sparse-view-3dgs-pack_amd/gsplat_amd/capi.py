@@ -41,6 +41,7 @@ class GsGaussians(C.Structure):
         ("scales", C.c_void_p),
         ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p),
+        ("extra_channel", C.c_void_p),
     ]
 
 
@@ -66,6 +67,7 @@ class GsGrads(C.Structure):
         ("dL_dscales", C.c_void_p),
         ("dL_drotations", C.c_void_p),
         ("dL_dcov3D", C.c_void_p),
+        ("dL_dextra", C.c_void_p),
     ]
 
 
@@ -96,6 +98,9 @@ PROTOTYPES = {
     "forward_render": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P]),
     "backward": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P,
                            C.POINTER(GsGrads), _P, _SZ, _P]),
+    "forward_render_x": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P, _P]),
+    "backward_x": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P, _P,
+                             C.POINTER(GsGrads), _P, _SZ, _P]),
     "mark_visible": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
     "export_geom": (C.c_int, [C.POINTER(GsScratch), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "export_binning": (C.c_int, [C.POINTER(GsScratch), _I64, _P, _P, _P]),
@@ -127,7 +132,10 @@ PROTOTYPES = {
 }
 
 # entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
-DEVICE_ONLY = ("profile_enable", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read")
+# (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
+# reference's two 3-channel passes, so the checker does not need it)
+DEVICE_ONLY = ("profile_enable", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
+               "forward_render_x", "backward_x")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}
 

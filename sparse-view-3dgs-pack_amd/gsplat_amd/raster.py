@@ -80,8 +80,11 @@ class RasterBackend:
         v.bg, v.viewmatrix, v.projmatrix, v.campos = _ptr(bg), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
         return v
 
-    def _gauss(self, keep, device, means3D, sh, colors, opacities, scales, rotations, cov3D):
+    def _gauss(self, keep, device, means3D, sh, colors, opacities, scales, rotations, cov3D, extra=None):
         g = GsGaussians()
+        extra = _prep(extra, device)
+        keep.append(extra)
+        g.extra_channel = _ptr(extra)
         means3D, sh, colors, opacities, scales, rotations, cov3D = (
             _prep(x, device) for x in (means3D, sh, colors, opacities, scales, rotations, cov3D))
         keep += [means3D, sh, colors, opacities, scales, rotations, cov3D]
@@ -135,11 +138,13 @@ class RasterBackend:
     # ------------------------------------------------------------------ forward
     def rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                             cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
-                            sh, degree, campos, prefiltered, antialiasing, debug):
+                            sh, degree, campos, prefiltered, antialiasing, debug, extra=None):
         """= RasterizeGaussiansCUDA (rasterize_points.cu:35-124).
 
         Returns (num_rendered, color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
-        invdepth[1,H,W]).  binningBuffer carries its capacity in its length (see _capacity)."""
+        invdepth[1,H,W]).  binningBuffer carries its capacity in its length (see _capacity).
+        extra [P] (not part of the reference's signature): a 4th per-Gaussian channel blended in the same
+        pass (gs_forward_render_x); the tuple then ends with its image [1,H,W]."""
         if means3D.ndim != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:58-60
         self._check_device(means3D)
@@ -150,14 +155,24 @@ class RasterBackend:
         out_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
         out_invdepth = torch.zeros((1, H, W), **f32)
         radii = torch.zeros((P,), dtype=torch.int32, device=device)
+        out_extra = None if extra is None else torch.zeros((1, H, W), **f32)
+        tail = () if extra is None else (out_extra,)
         if P == 0:  # rasterize_points.cu:88
             e = torch.empty((0,), **u8)
-            return 0, out_color, radii, e, e.clone(), e.clone(), out_invdepth
+            return (0, out_color, radii, e, e.clone(), e.clone(), out_invdepth) + tail
+
+        def render(scratch):
+            if extra is None:
+                self.api.call("forward_render", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
+                              out_invdepth.data_ptr(), stream)
+            else:
+                self.api.call("forward_render_x", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
+                              out_invdepth.data_ptr(), out_extra.data_ptr(), stream)
 
         keep = []
         view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
                           degree, prefiltered, antialiasing, debug)
-        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra)
         stream = self._stream(device)
 
         gb, ib, _, _ = self.scratch_bytes(P, W, H, 0)
@@ -186,13 +201,12 @@ class RasterBackend:
                 _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
                 binning = torch.empty((bb,), **u8)
                 s2 = self._scratch(geom, img, binning, cap)
-                self.api.call("forward_render", C.byref(view), C.byref(g), C.byref(s2), out_color.data_ptr(),
-                              out_invdepth.data_ptr(), stream)
+                render(s2)
                 ev.synchronize()
                 num_rendered = int(nr_host[0])
                 self._update_hint(num_rendered)
                 if num_rendered <= cap:
-                    return num_rendered, out_color, radii, geom, binning, img, out_invdepth
+                    return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
                 del binning
             else:
                 cur.synchronize()  # the reference's blocking D2H (rasterizer_impl.cu:284)
@@ -207,19 +221,18 @@ class RasterBackend:
         _, _, bb, _ = self.scratch_bytes(P, W, H, num_rendered)
         binning = torch.empty((bb,), **u8)
         s = self._scratch(geom, img, binning, num_rendered)
-        self.api.call("forward_render", C.byref(view), C.byref(g), C.byref(s), out_color.data_ptr(),
-                      out_invdepth.data_ptr(), stream)
-        return num_rendered, out_color, radii, geom, binning, img, out_invdepth
+        render(s)
+        return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
 
     # ------------------------------------------------------------------ backward
     def rasterize_gaussians_backward(self, bg, means3D, radii, colors_precomp, opacities, scales, rotations,
                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy,
                                      dL_dout_color, dL_dout_invdepth, sh, degree, campos, geomBuffer, R,
-                                     binningBuffer, imgBuffer, antialiasing, debug):
+                                     binningBuffer, imgBuffer, antialiasing, debug, extra=None, dL_dout_extra=None):
         """= RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-223).
 
         Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
-        dL_drotations)."""
+        dL_drotations) (+ dL_dextra [P] when the forward blended a 4th channel)."""
         self._check_device(means3D)
         device = means3D.device
         P = int(means3D.shape[0])
@@ -245,12 +258,16 @@ class RasterBackend:
         dL_dscales = alloc((P, 3), **f32)
         dL_drotations = alloc((P, 4), **f32)
         ret = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+        dL_dextra = None
+        if extra is not None:
+            dL_dextra = alloc((P,), **f32)
+            ret = ret + (dL_dextra,)
         if P == 0:
             return ret
         keep = []
         view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
                           degree, False, antialiasing, debug)
-        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra)
         stream = self._stream(device)
         dL_dout_color = _prep(dL_dout_color, device)
         dL_dout_invdepth = _prep(dL_dout_invdepth, device)
@@ -268,8 +285,17 @@ class RasterBackend:
         if g.scales is None:
             dL_dscales.zero_()
             dL_drotations.zero_()
-        self.api.call("backward", C.byref(view), C.byref(g), radii.data_ptr(), C.byref(s), int(R),
-                      dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(grads), _ptr(ws), ws.numel(), stream)
+        if extra is None:
+            self.api.call("backward", C.byref(view), C.byref(g), radii.data_ptr(), C.byref(s), int(R),
+                          dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(grads), _ptr(ws), ws.numel(), stream)
+        else:
+            grads.dL_dextra = dL_dextra.data_ptr()
+            dL_dout_extra = _prep(dL_dout_extra, device)
+            if dL_dout_extra is None:
+                dL_dout_extra = torch.zeros((1, H, W), **f32)
+            self.api.call("backward_x", C.byref(view), C.byref(g), radii.data_ptr(), C.byref(s), int(R),
+                          dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), dL_dout_extra.data_ptr(), C.byref(grads),
+                          _ptr(ws), ws.numel(), stream)
         return ret
 
     # ------------------------------------------------------------------ markVisible
