@@ -282,11 +282,16 @@ int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams
 /* ---- optimiser (caller side of the path): fused Adam over ONE flat fp32 parameter buffer.
  * Replaces torch.optim.Adam(lr=0, eps=1e-15) with per-group learning rates,
  * LGDWT-GS/scene/gaussian_model.py:183-193 + train.py:279-288.  Segment k covers elements [begin, end);
- * element i uses lr_a, or lr_b when period > 0 and (i - begin) % period >= split (interleaved SH DC / rest). */
+ * element i uses lr_a, or lr_b when period > 0 and (i - begin) % period >= split (interleaved SH DC / rest).
+ * step: the segment's own 1-based step count for the bias correction, 0 = the call's `step` (torch keeps the
+ * counter per parameter: a group whose tensor was just replaced - reset_opacity, gaussian_model.py:258-261 - has
+ * no gradient that iteration, is skipped by optimizer.step() and falls one step behind the others).
+ * Elements covered by no segment are left untouched (parameter AND moments). */
 typedef struct GsAdamSeg {
   int64_t begin, end;
   float lr_a, lr_b;
   int32_t period, split;
+  int32_t step, _pad;
 } GsAdamSeg;
 /* segs is a HOST array (<= 8 entries, copied into the launch); step = 1-based iteration for the bias correction. */
 int gs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -393,13 +393,23 @@ int gso_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
                   float b1, float b2, float eps, int32_t step, void*) {
   if (!p || !g || !m || !v) return GS_E_NULL;
   if (step < 1 || nseg < 0 || nseg > 8) return GS_E_SHAPE;
-  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
-  const float inv_bc1 = (float)(1.0 / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  float seg_inv_bc1[8], seg_inv_sqrt_bc2[8];
+  for (int k = 0; k < nseg; k++) {
+    const int st = segs[k].step > 0 ? segs[k].step : step;  // torch keeps the step count per parameter
+    const double bc1 = 1.0 - pow((double)b1, (double)st), bc2 = 1.0 - pow((double)b2, (double)st);
+    seg_inv_bc1[k] = (float)(1.0 / bc1);
+    seg_inv_sqrt_bc2[k] = (float)(1.0 / sqrt(bc2));
+  }
   for (int64_t i = 0; i < n; i++) {
     float lr = 0.f;
+    int seg = -1;
     for (int k = 0; k < nseg; k++)
-      if (i >= segs[k].begin && i < segs[k].end)
+      if (i >= segs[k].begin && i < segs[k].end) {
         lr = (segs[k].period > 0 && (int)((i - segs[k].begin) % segs[k].period) >= segs[k].split) ? segs[k].lr_b : segs[k].lr_a;
+        seg = k;
+      }
+    if (seg < 0) continue;  // not optimised this step (torch skips parameters without a gradient)
+    const float inv_bc1 = seg_inv_bc1[seg], inv_sqrt_bc2 = seg_inv_sqrt_bc2[seg];
     m[i] = b1 * m[i] + (1.f - b1) * g[i];
     v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
     const float denom = sqrtf(v[i]) * inv_sqrt_bc2 + eps;

@@ -20,22 +20,26 @@ struct AdamSegs {
   long long begin[ADAM_MAX_SEG], end[ADAM_MAX_SEG];
   float lr_a[ADAM_MAX_SEG], lr_b[ADAM_MAX_SEG];
   int period[ADAM_MAX_SEG], split[ADAM_MAX_SEG];
+  float inv_bc1[ADAM_MAX_SEG], inv_sqrt_bc2[ADAM_MAX_SEG];  // bias corrections of the segment's own step count
 };
 
-__device__ __forceinline__ float adam_lr(const AdamSegs& s, long long i) {
-  float lr = 0.f;
+// step size lr / (1 - b1^t) and 1 / sqrt(1 - b2^t) of element i; false = covered by no segment (left untouched)
+__device__ __forceinline__ bool adam_coef(const AdamSegs& s, long long i, float& lr_bc1, float& inv_sqrt_bc2) {
+  bool hit = false;
 #pragma unroll
   for (int k = 0; k < ADAM_MAX_SEG; k++)
     if (k < s.n && i >= s.begin[k] && i < s.end[k]) {
-      lr = (s.period[k] > 0 && (int)((i - s.begin[k]) % s.period[k]) >= s.split[k]) ? s.lr_b[k] : s.lr_a[k];
+      const float lr = (s.period[k] > 0 && (int)((i - s.begin[k]) % s.period[k]) >= s.split[k]) ? s.lr_b[k] : s.lr_a[k];
+      lr_bc1 = lr * s.inv_bc1[k];
+      inv_sqrt_bc2 = s.inv_sqrt_bc2[k];
+      hit = true;
     }
-  return lr;
+  return hit;
 }
 
 __global__ void __launch_bounds__(GS_BLOCK) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
-                                                        AdamSegs segs, float b1, float b2, float eps, float inv_bc1,
-                                                        float inv_sqrt_bc2) {
+                                                        AdamSegs segs, float b1, float b2, float eps) {
   const long long n4 = n >> 2;
   for (long long i4 = (long long)blockIdx.x * GS_BLOCK + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * GS_BLOCK) {
     float4 pp = reinterpret_cast<float4*>(p)[i4];
@@ -48,11 +52,12 @@ __global__ void __launch_bounds__(GS_BLOCK) adam_kernel(float* __restrict__ p, c
     float* ve = reinterpret_cast<float*>(&vv);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const float lr = adam_lr(segs, i4 * 4 + k);
+      float lr_bc1, inv_sqrt_bc2;
+      if (!adam_coef(segs, i4 * 4 + k, lr_bc1, inv_sqrt_bc2)) continue;
       me[k] = b1 * me[k] + (1.f - b1) * ge[k];
       ve[k] = b2 * ve[k] + (1.f - b2) * ge[k] * ge[k];
       const float denom = sqrtf(ve[k]) * inv_sqrt_bc2 + eps;
-      pe[k] = pe[k] - (lr * inv_bc1) * (me[k] / denom);
+      pe[k] = pe[k] - lr_bc1 * (me[k] / denom);
     }
     reinterpret_cast<float4*>(p)[i4] = pp;
     reinterpret_cast<float4*>(m)[i4] = mm;
@@ -60,13 +65,15 @@ __global__ void __launch_bounds__(GS_BLOCK) adam_kernel(float* __restrict__ p, c
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
     const long long i = n4 * 4 + threadIdx.x;
-    const float lr = adam_lr(segs, i);
-    const float gi = g[i];
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = p[i] - (lr * inv_bc1) * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    float lr_bc1, inv_sqrt_bc2;
+    if (adam_coef(segs, i, lr_bc1, inv_sqrt_bc2)) {
+      const float gi = g[i];
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      p[i] = p[i] - lr_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
   }
 }
 
@@ -90,13 +97,16 @@ extern "C" int gs_adam_step(float* params, const float* grads, float* exp_avg, f
     a.lr_b[k] = on ? segs[k].lr_b : 0.f;
     a.period[k] = on ? segs[k].period : 0;
     a.split[k] = on ? segs[k].split : 0;
+    const int st = (on && segs[k].step > 0) ? segs[k].step : step;
+    const double bc1 = 1.0 - pow((double)beta1, (double)st), bc2 = 1.0 - pow((double)beta2, (double)st);
+    a.inv_bc1[k] = (float)(1.0 / bc1);
+    a.inv_sqrt_bc2[k] = (float)(1.0 / sqrt(bc2));
   }
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const long long n4 = (n + 3) / 4;
   long long blocks = (n4 + GS_BLOCK - 1) / GS_BLOCK;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(GS_BLOCK), 0, s, params, grads, exp_avg, exp_avg_sq,
-                     (long long)n, a, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+                     (long long)n, a, beta1, beta2, eps);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }

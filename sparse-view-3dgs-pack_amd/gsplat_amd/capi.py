@@ -79,7 +79,7 @@ class GsLgdwtParams(C.Structure):
 
 class GsAdamSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr_a", C.c_float), ("lr_b", C.c_float),
-                ("period", C.c_int32), ("split", C.c_int32)]
+                ("period", C.c_int32), ("split", C.c_int32), ("step", C.c_int32), ("_pad", C.c_int32)]
 
 
 _P = C.c_void_p

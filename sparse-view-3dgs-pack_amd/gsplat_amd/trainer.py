@@ -4,6 +4,8 @@
   training_setup / Adam groups   LGDWT-GS/scene/gaussian_model.py:178-201        (per-group LRs, eps 1e-15)
   render()                       LGDWT-GS/gaussian_renderer/__init__.py:18-128   (argument / return contract)
   one iteration                  LGDWT-GS/train.py:97-218,279-288                 (render, losses, backward, Adam)
+  densify / prune / reset        LGDWT-GS/scene/gaussian_model.py:258-261,316-473 (clone, split, prune, moments)
+  schedule                       LGDWT-GS/train.py:99-111,262-288, arguments/__init__.py:78-100
 
 MI355X-first differences:
   * the six parameter tensors are views into ONE flat fp32 buffer and their gradients views into one
@@ -52,32 +54,53 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(model.flat)
         self.exp_avg_sq = torch.zeros_like(model.flat)
         self.t = 0
+        # torch keeps Adam's step count per parameter; a group that is skipped (no gradient after its tensor
+        # was replaced) falls behind the others
+        self.seg_steps = {name: 0 for name, _ in FIELDS}
         self.lr = dict(LRS)
         self.lr["xyz"] = LRS["xyz"] * model.spatial_lr_scale
         self._Seg = GsAdamSeg
 
-    def segments(self):
+    def segments(self, skip=()):
         P = self.model.P
+        names = [(name, n) for name, n in FIELDS]
         segs = (self._Seg * len(FIELDS))()
-        off = 0
-        for k, (name, n) in enumerate(FIELDS):
-            segs[k].begin, segs[k].end = off, off + P * n
-            if name == "features":
-                segs[k].lr_a, segs[k].lr_b, segs[k].period, segs[k].split = self.lr["f_dc"], self.lr["f_rest"], 48, 3
-            else:
-                segs[k].lr_a, segs[k].lr_b, segs[k].period, segs[k].split = self.lr[name], 0.0, 0, 0
+        off, k = 0, 0
+        for name, n in names:
+            if name not in skip:
+                segs[k].begin, segs[k].end = off, off + P * n
+                if name == "features":
+                    segs[k].lr_a, segs[k].lr_b, segs[k].period, segs[k].split = self.lr["f_dc"], self.lr["f_rest"], 48, 3
+                else:
+                    segs[k].lr_a, segs[k].lr_b, segs[k].period, segs[k].split = self.lr[name], 0.0, 0, 0
+                segs[k].step = self.seg_steps[name]
+                k += 1
             off += P * n
-        return segs
+        return segs, k
 
-    def step(self):
+    def step(self, skip=()):
+        """skip: fields without a gradient this iteration (their tensor was replaced after backward: torch's
+        optimizer.step() leaves such a parameter, its moments and its step count alone)."""
         import ctypes as C
         m = self.model
         self.t += 1
-        segs = self.segments()
+        for name, _ in FIELDS:
+            if name not in skip:
+                self.seg_steps[name] += 1
+        segs, nseg = self.segments(skip)
+        if nseg == 0:
+            return
         stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
         self.api.call("adam_step", m.flat.data_ptr(), m.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                      self.exp_avg_sq.data_ptr(), m.flat.numel(), segs, len(FIELDS), self.betas[0], self.betas[1],
+                      self.exp_avg_sq.data_ptr(), m.flat.numel(), segs, nseg, self.betas[0], self.betas[1],
                       self.eps, self.t, stream)
+
+    def field_views(self, buf):
+        P, off, out = self.model.P, 0, {}
+        for name, n in FIELDS:
+            out[name] = buf[off:off + P * n].view(P, n)
+            off += P * n
+        return out
 
 
 class GaussianModelLite:
@@ -93,17 +116,8 @@ class GaussianModelLite:
         self.spatial_lr_scale = spatial_lr_scale
         self.max_sh_degree = 3
         self.active_sh_degree = scene.get("sh_degree", 3)
-        self.flat = torch.zeros((P * FLOATS_PER_GAUSSIAN,), dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros_like(self.flat)
-        self.params = {}
-        off = 0
-        shapes = {"xyz": (P, 3), "features": (P, 16, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
-        for name, n in FIELDS:
-            view = self.flat[off:off + P * n].view(shapes[name])
-            p = torch.nn.Parameter(view, requires_grad=True)
-            p.grad = self.flat_grad[off:off + P * n].view(shapes[name])
-            self.params[name] = p
-            off += P * n
+        self.percent_dense = 0.01  # arguments/__init__.py:91
+        self._allocate(P)
         with torch.no_grad():
             self.params["xyz"].copy_(scene["means3D"])
             self.params["features"].copy_(scene["shs"])
@@ -124,6 +138,135 @@ class GaussianModelLite:
         self.xyz_gradient_accum = torch.zeros((P, 1), device=device)
         self.denom = torch.zeros((P, 1), device=device)
         self.max_radii2D = torch.zeros((P,), device=device)
+
+    @staticmethod
+    def _shapes(P):
+        return {"xyz": (P, 3), "features": (P, 16, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+
+    def _allocate(self, P):
+        """(Re)create the flat parameter / gradient buffers for P Gaussians and the views into them."""
+        self.P = P
+        self.flat = torch.zeros((P * FLOATS_PER_GAUSSIAN,), dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.params = {}
+        off = 0
+        shapes = self._shapes(P)
+        for name, n in FIELDS:
+            view = self.flat[off:off + P * n].view(shapes[name])
+            p = torch.nn.Parameter(view, requires_grad=True)
+            p.grad = self.flat_grad[off:off + P * n].view(shapes[name])
+            self.params[name] = p
+            off += P * n
+
+    def oneupSHdegree(self):
+        """gaussian_model.py:145-147"""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ------------------------------------------------------------------ densification
+    def _relayout(self, src_idx, new_rows):
+        """New model = rows `src_idx` of the current one (parameters AND Adam moments kept) followed by
+        `new_rows` (dict field -> [n_new, width], moments zero): the flat-buffer form of _prune_optimizer +
+        cat_tensors_to_optimizer (gaussian_model.py:331-393)."""
+        opt = self.optimizer
+        if not isinstance(opt, FlatAdam):
+            raise NotImplementedError("densification needs the flat Adam state")
+        old_p = {name: self.params[name].detach().reshape(self.P, n) for name, n in FIELDS}
+        old_m, old_v = opt.field_views(opt.exp_avg), opt.field_views(opt.exp_avg_sq)
+        n_new = next(iter(new_rows.values())).shape[0] if new_rows else 0
+        P2 = int(src_idx.numel()) + n_new
+        cat_p, cat_m, cat_v = {}, {}, {}
+        for name, n in FIELDS:
+            add = new_rows[name].reshape(n_new, n) if n_new else old_p[name][:0]
+            cat_p[name] = torch.cat((old_p[name][src_idx], add), dim=0)
+            z = torch.zeros_like(add)
+            cat_m[name] = torch.cat((old_m[name][src_idx], z), dim=0)
+            cat_v[name] = torch.cat((old_v[name][src_idx], z), dim=0)
+        self._allocate(P2)
+        opt.exp_avg = torch.zeros_like(self.flat)
+        opt.exp_avg_sq = torch.zeros_like(self.flat)
+        new_m, new_v = opt.field_views(opt.exp_avg), opt.field_views(opt.exp_avg_sq)
+        with torch.no_grad():
+            for name, n in FIELDS:
+                self.params[name].reshape(P2, n).copy_(cat_p[name])
+                new_m[name].copy_(cat_m[name])
+                new_v[name].copy_(cat_v[name])
+        for p in self.params.values():  # replaced tensors have no gradient until the next backward
+            p.grad = None
+
+    @staticmethod
+    def build_rotation(r):
+        """general_utils.py:78-99 (quaternion normalised here, unlike the rasterizer)."""
+        q = r / torch.sqrt((r * r).sum(dim=1, keepdim=True))
+        w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), dim=1)
+        return R.view(-1, 3, 3)
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, radii=None, generator=None, N=2):
+        """gaussian_model.py:395-467 in one re-layout: clone small Gaussians with a large view-space gradient,
+        split large ones into N samples of their own distribution (scale / (0.8 N)), drop the split originals,
+        then prune by opacity / world size.  Row order = the reference's: [survivors, clones, split samples].
+        `generator`: CPU generator for the split samples (drawn on the CPU so every rank and every backend
+        sees the same numbers).  Returns (n_clone, n_split, n_pruned).
+        Note: the reference zeroes max_radii2D inside densification_postfix (:383) BEFORE the screen-size test of
+        :458 reads it, so that test never fires; reproduced by construction."""
+        with torch.no_grad():
+            P0 = self.P
+            grads = self.xyz_gradient_accum / self.denom
+            grads[grads.isnan()] = 0.0
+            g = grads.reshape(P0)
+            scaling = self.get_scaling
+            max_scale = scaling.max(dim=1).values
+            small = max_scale <= self.percent_dense * extent
+            clone = (g.abs() >= max_grad) & small        # torch.norm over the single column (:435)
+            split = (g >= max_grad) & ~small             # padded_grad of the clones is 0: never selected (:399-402)
+            ci = clone.nonzero().squeeze(1)
+            si = split.nonzero().squeeze(1)
+            ns = int(si.numel())
+            raw = {name: self.params[name].detach().reshape(P0, n) for name, n in FIELDS}
+            new = {name: [raw[name][ci]] for name, _ in FIELDS}
+            if ns:
+                stds = scaling[si].repeat(N, 1)
+                if generator is None:
+                    generator = torch.Generator().manual_seed(0)
+                noise = torch.randn((ns * N, 3), generator=generator, dtype=torch.float32).to(stds.device)
+                samples = noise * stds
+                rots = self.build_rotation(raw["rotation"][si]).repeat(N, 1, 1)
+                new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + raw["xyz"][si].repeat(N, 1)
+                new["xyz"].append(new_xyz)
+                new["scaling"].append(torch.log(scaling[si].repeat(N, 1) / (0.8 * N)))
+                for name in ("features", "opacity", "rotation"):
+                    new[name].append(raw[name][si].repeat(N, 1))
+            new = {name: torch.cat(v, dim=0) for name, v in new.items()}
+            n_new = new["xyz"].shape[0]
+            # final prune (:455-462) evaluated on [survivors, clones, samples]
+            keep_old = ~split
+            op_all = torch.cat((torch.sigmoid(raw["opacity"][keep_old]), torch.sigmoid(new["opacity"])), dim=0).squeeze(1)
+            prune = op_all < min_opacity
+            if max_screen_size:
+                sc_all = torch.cat((max_scale[keep_old], torch.exp(new["scaling"]).max(dim=1).values), dim=0)
+                prune = prune | (sc_all > 0.1 * extent)  # big_points_vs is all-False (max_radii2D was just zeroed)
+            n_keep_old = int(keep_old.sum())
+            src = keep_old.nonzero().squeeze(1)[~prune[:n_keep_old]]
+            keep_new = ~prune[n_keep_old:]
+            new = {name: v[keep_new] for name, v in new.items()}
+            self._relayout(src, new)
+            self.xyz_gradient_accum = torch.zeros((self.P, 1), device=self.device)
+            self.denom = torch.zeros((self.P, 1), device=self.device)
+            self.max_radii2D = torch.zeros((self.P,), device=self.device)
+            return int(ci.numel()), ns, int(prune.sum())
+
+    def reset_opacity(self):
+        """gaussian_model.py:258-261: opacity <- min(opacity, 0.01), moments of that group zeroed."""
+        with torch.no_grad():
+            op = torch.sigmoid(self.params["opacity"])
+            new = torch.minimum(op, torch.full_like(op, 0.01))
+            self.params["opacity"].copy_(torch.log(new / (1 - new)))
+            opt = self.optimizer
+            opt.field_views(opt.exp_avg)["opacity"].zero_()
+            opt.field_views(opt.exp_avg_sq)["opacity"].zero_()
 
     def update_learning_rate(self, iteration, position_lr_final=0.0000016, delay_mult=0.01, max_steps=30000):
         """gaussian_model.py:213-223: exponential decay of the xyz learning rate."""
@@ -164,7 +307,7 @@ class GaussianModelLite:
 
     def grad_views(self):
         P, off, out = self.P, 0, {}
-        shapes = {"xyz": (P, 3), "features": (P, 16, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+        shapes = self._shapes(P)
         for name, n in FIELDS:
             out[name] = self.flat_grad[off:off + P * n].view(shapes[name])
             off += P * n
@@ -257,8 +400,40 @@ def camera_to(cam, device):
                         camera_center=cam.camera_center.to(device))
 
 
+class TrainOptions:
+    """The schedule constants of LGDWT-GS/arguments/__init__.py:78-100 (OptimizationParams)."""
+
+    def __init__(self, **kw):
+        self.iterations = 30_000
+        self.position_lr_final = 0.0000016
+        self.position_lr_delay_mult = 0.01
+        self.position_lr_max_steps = 30_000
+        self.densification_interval = 100
+        self.opacity_reset_interval = 3000
+        self.densify_from_iter = 500
+        self.densify_until_iter = 15_000
+        self.densify_grad_threshold = 0.0002
+        self.min_opacity = 0.005          # train.py:273
+        self.size_threshold = 20          # train.py:272
+        self.sh_increase_interval = 1000  # train.py:102
+        self.white_background = False
+        self.cameras_extent = 1.0         # scene.cameras_extent = getNerfppNorm radius (dataset_readers.py:48-69)
+        self.seed = 0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError("unknown option %s" % k)
+            setattr(self, k, v)
+
+
+def cameras_extent(camera_centers):
+    """getNerfppNorm (dataset_readers.py:48-69): 1.1 x the largest distance of a camera centre from their mean."""
+    c = torch.stack([torch.as_tensor(x, dtype=torch.float64).reshape(3) for x in camera_centers])
+    return float((c - c.mean(dim=0, keepdim=True)).norm(dim=1).max() * 1.1)
+
+
 class Trainer:
-    """One process per GPU; `step(k)` renders this rank's camera of global step k and updates the model."""
+    """One process per GPU; `step(k)` renders this rank's camera of global step k and updates the model;
+    `train_iteration(it, opt)` is one iteration of the reference's loop with its schedule."""
 
     def __init__(self, model, cameras, gt_images, criterion, Rasterizer, Settings, bg, rank=0, world_size=1,
                  optimizer_step=True, masks=None):
@@ -268,13 +443,59 @@ class Trainer:
         self.optimizer_step = optimizer_step
         self.masks = masks  # per-camera ELF patch masks (depend on the ground truth only): cached
         self.last = None
+        self._stack = []    # train.py:106-111: cameras are drawn without replacement
+        self._rng = None
 
     def camera_index(self, k):
         return (k * self.world_size + self.rank) % len(self.cameras)
 
     def step(self, k):
+        return self._step_camera(self.camera_index(k), self.optimizer_step, ())
+
+    def draw_cameras(self, seed):
+        """train.py:106-111 for `world_size` ranks: one global step pops world_size cameras from the shared stack
+        (same python RNG on every rank), rank r takes the r-th."""
+        import random
+        if self._rng is None:
+            self._rng = random.Random(seed)
+        mine = None
+        for r in range(self.world_size):
+            if not self._stack:
+                self._stack = list(range(len(self.cameras)))
+            ci = self._stack.pop(self._rng.randint(0, len(self._stack) - 1))
+            if r == self.rank:
+                mine = ci
+        return mine
+
+    def train_iteration(self, iteration, opt):
+        """One iteration (1-based) of LGDWT-GS/train.py:97-288: LR schedule, SH ramp, camera draw, render + loss +
+        backward, densification statistics, densify / prune / opacity reset on schedule, Adam.
+        The reference replaces the parameter tensors when it densifies (their gradients are gone), so
+        optimizer.step() of that iteration changes nothing; after reset_opacity only the opacity group is
+        skipped.  Returns dict(loss, densified=(n_clone, n_split, n_pruned) or None, reset=bool, P)."""
         m = self.model
-        ci = self.camera_index(k)
+        m.update_learning_rate(iteration, opt.position_lr_final, opt.position_lr_delay_mult, opt.position_lr_max_steps)
+        if iteration % opt.sh_increase_interval == 0:
+            m.oneupSHdegree()
+        ci = self.draw_cameras(opt.seed)
+        loss = self._step_camera(ci, False, ())
+        densified, reset, skip_all = None, False, False
+        if iteration < opt.densify_until_iter:
+            if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                thr = opt.size_threshold if iteration > opt.opacity_reset_interval else None
+                gen = torch.Generator().manual_seed(opt.seed * 1000003 + iteration)
+                densified = m.densify_and_prune(opt.densify_grad_threshold, opt.min_opacity, opt.cameras_extent, thr,
+                                                self.last["radii"], generator=gen)
+                skip_all = True
+            if iteration % opt.opacity_reset_interval == 0 or (opt.white_background and iteration == opt.densify_from_iter):
+                m.reset_opacity()
+                reset = True
+        if iteration < opt.iterations and not skip_all:
+            m.optimizer.step(skip=("opacity",) if reset else ())
+        return dict(loss=loss, densified=densified, reset=reset, P=m.P, camera=ci)
+
+    def _step_camera(self, ci, optimizer_step, skip):
+        m = self.model
         m.zero_grad()
         backend = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
         backend = getattr(backend, "backend", None)
@@ -297,8 +518,8 @@ class Trainer:
             m.add_densification_stats(pkg["viewspace_points"].grad, pkg["visibility_filter"])
             if self.world_size > 1:
                 self.all_reduce()
-            if self.optimizer_step:
-                m.optimizer.step()
+            if optimizer_step:
+                m.optimizer.step(*([skip] if skip else []))
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
 

@@ -74,3 +74,48 @@ def test_two_rank_gradient_allreduce_matches_single_process_sum(oracle):
     assert torch.equal(single[0].model.flat_grad, r0["grad"])
     assert torch.equal(single[0].model.flat, r0["flat"])
     assert torch.equal(single[0].model.denom, r0["denom"]) and torch.equal(single[0].model.max_radii2D, r0["maxr"])
+
+
+def _worker_schedule(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    from gsplat_amd.trainer import TrainOptions
+    from test_trainer_cpu import make_trainer
+    orc = oracle_lib.get()
+    tr = make_trainer(orc, P=300, W=96, H=64, world_size=world, rank=rank, dwt=False)
+    opt = TrainOptions(iterations=20, densify_from_iter=2, densification_interval=3, opacity_reset_interval=5,
+                       densify_until_iter=12, cameras_extent=4.4, densify_grad_threshold=1e-7, seed=1)
+    cams, sizes = [], []
+    for it in range(1, 9):
+        out = tr.train_iteration(it, opt)
+        cams.append(out["camera"])
+        sizes.append(out["P"])
+    m = tr.model
+    torch.save(dict(flat=m.flat.clone(), m1=m.optimizer.exp_avg.clone(), m2=m.optimizer.exp_avg_sq.clone(), cams=cams,
+                    sizes=sizes), os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_schedule_with_densification_keeps_replicas_identical():
+    """Densify / prune / opacity reset run from all-reduced statistics and a shared seed: after 8 iterations of the
+    schedule both replicas hold the same number of Gaussians, bit-identical parameters and Adam moments, and
+    each global step consumed two different cameras of the shared draw-without-replacement stack."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_schedule, args=(world, _free_port(), d), nprocs=world, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"))
+        r1 = torch.load(os.path.join(d, "rank1.pt"))
+    assert r0["sizes"] == r1["sizes"] and r0["sizes"][-1] != r0["sizes"][0]
+    for k in ("flat", "m1", "m2"):
+        assert torch.equal(r0[k], r1[k]), k
+    for a, b in zip(r0["cams"], r1["cams"]):
+        assert a != b
+    both = [c for pair in zip(r0["cams"], r1["cams"]) for c in pair]
+    for k in range(0, len(both), 4):  # 4 cameras: every two global steps use each camera once
+        assert sorted(both[k:k + 4]) == [0, 1, 2, 3]
