@@ -158,6 +158,70 @@ class GaussianModelLite:
             self.params[name] = p
             off += P * n
 
+    # ------------------------------------------------------------------ files (formats: gsplat_amd/io.py)
+    @classmethod
+    def create_from_pcd(cls, points, colors, device, spatial_lr_scale=1.0, api=None, knn=None):
+        """create_from_pcd (gaussian_model.py:149-176): DC = RGB2SH(colour), rest 0, scale = sqrt of the mean squared
+        distance to the 3 nearest neighbours (clamped at 1e-7) on all axes, identity rotation, opacity 0.1, active
+        SH degree 0.  knn: callable [P,3] -> [P] (simple_knn's distCUDA2); default = the float64 brute force."""
+        from . import synthetic
+        pts = torch.as_tensor(points, dtype=torch.float32)
+        col = torch.as_tensor(colors, dtype=torch.float32)
+        P = pts.shape[0]
+        dist2 = (knn(pts) if knn is not None else synthetic.brute_force_knn_dist2(pts)).clamp_min(1e-7).cpu()
+        shs = torch.zeros((P, 16, 3))
+        shs[:, 0, :] = synthetic.rgb2sh(col)
+        scene = dict(means3D=pts, shs=shs, scales=torch.sqrt(dist2)[:, None].repeat(1, 3),
+                     rotations=torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(P, 1), opacities=torch.full((P, 1), 0.1),
+                     sh_degree=0)
+        return cls(scene, device, spatial_lr_scale=spatial_lr_scale, api=api)
+
+    def save_ply(self, path):
+        """save_ply (gaussian_model.py:240-256): raw parameters, the reference's 62-property layout."""
+        from . import io as gio
+        p = {k: v.detach().cpu().numpy() for k, v in self.params.items()}
+        gio.save_gaussians_ply(path, p["xyz"], p["features"], p["opacity"], p["scaling"], p["rotation"])
+
+    def load_ply(self, path):
+        """load_ply (gaussian_model.py:263-314): replaces the parameters (fresh Adam state), active degree = max."""
+        from . import io as gio
+        d = gio.load_gaussians_ply(path, self.max_sh_degree)
+        api = getattr(self.optimizer, "api", None)
+        self._allocate(d["xyz"].shape[0])
+        with torch.no_grad():
+            for name in self.params:
+                self.params[name].copy_(torch.from_numpy(d[name]).reshape(self.params[name].shape))
+        if api is not None:
+            self.optimizer = FlatAdam(api, self)
+        self.xyz_gradient_accum = torch.zeros((self.P, 1), device=self.device)
+        self.denom = torch.zeros((self.P, 1), device=self.device)
+        self.max_radii2D = torch.zeros((self.P,), device=self.device)
+        self.active_sh_degree = self.max_sh_degree
+
+    def capture(self):
+        """Checkpoint payload (the role of GaussianModel.capture, gaussian_model.py:62-76): flat parameters, Adam
+        moments and step counts, densification statistics."""
+        opt = self.optimizer
+        return dict(P=self.P, active_sh_degree=self.active_sh_degree, flat=self.flat.detach().cpu().clone(),
+                    exp_avg=opt.exp_avg.cpu().clone(), exp_avg_sq=opt.exp_avg_sq.cpu().clone(), t=opt.t,
+                    seg_steps=dict(opt.seg_steps), lr=dict(opt.lr), xyz_gradient_accum=self.xyz_gradient_accum.cpu().clone(),
+                    denom=self.denom.cpu().clone(), max_radii2D=self.max_radii2D.cpu().clone(),
+                    spatial_lr_scale=self.spatial_lr_scale)
+
+    def restore(self, state):
+        opt = self.optimizer
+        self._allocate(int(state["P"]))
+        with torch.no_grad():
+            self.flat.copy_(state["flat"])
+        opt.exp_avg = state["exp_avg"].to(self.device).clone()
+        opt.exp_avg_sq = state["exp_avg_sq"].to(self.device).clone()
+        opt.t, opt.seg_steps, opt.lr = int(state["t"]), dict(state["seg_steps"]), dict(state["lr"])
+        self.active_sh_degree = int(state["active_sh_degree"])
+        self.xyz_gradient_accum = state["xyz_gradient_accum"].to(self.device).clone()
+        self.denom = state["denom"].to(self.device).clone()
+        self.max_radii2D = state["max_radii2D"].to(self.device).clone()
+        self.spatial_lr_scale = state["spatial_lr_scale"]
+
     def oneupSHdegree(self):
         """gaussian_model.py:145-147"""
         if self.active_sh_degree < self.max_sh_degree:

@@ -14,6 +14,10 @@ Fixtures are data only (inputs + the reference's outputs); no reference source i
                   LGDWT-GS/utils/image_utils.py) on seeded torch.rand images (recipe of
                   fused-ssim/tests/test.py:58-91 at small sizes)
   schedule.npz    get_expon_lr_func, inverse_sigmoid (LGDWT-GS/utils/general_utils.py), RGB2SH/SH2RGB
+  colmap/         a small COLMAP model (cameras.bin, images.bin, points3D.bin + the .txt forms) written by
+                  gsplat_amd.io.write_colmap_binary from seeded data, and colmap_expected.npz = what the REFERENCE's
+                  own readers (LGDWT-GS/scene/colmap_loader.py) return for those files, plus its qvec2rotmat /
+                  rotmat2qvec -> pins the byte layout and conventions of gsplat_amd/io.py's readers
 """
 import importlib.util
 import math
@@ -38,6 +42,67 @@ graphics = load(REF + "/LGDWT-GS/utils/graphics_utils.py", "ref_graphics_utils")
 image_utils = load(REF + "/LGDWT-GS/utils/image_utils.py", "ref_image_utils")
 general = load(REF + "/LGDWT-GS/utils/general_utils.py", "ref_general_utils")
 loss_utils = load(REF + "/gaussian-splatting/utils/loss_utils.py", "ref_loss_utils")
+
+
+def gen_colmap():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "..", "sparse-view-3dgs-pack_amd"))
+    from gsplat_amd import io as gio
+    ref = load(REF + "/LGDWT-GS/scene/colmap_loader.py", "ref_colmap_loader")
+    rng = np.random.RandomState(7)
+    d = os.path.join(HERE, "colmap")
+    models = ["SIMPLE_PINHOLE", "PINHOLE", "SIMPLE_RADIAL", "OPENCV"]
+    cams = {}
+    for i, m in enumerate(models):
+        n = gio.CAMERA_MODEL_NAMES[m].num_params
+        cams[i + 1] = gio.ColmapCamera(i + 1, m, 640 + 16 * i, 480 + 8 * i, rng.uniform(300, 900, n))
+    images = {}
+    for i in range(6):
+        q = rng.randn(4)
+        q /= np.linalg.norm(q)
+        npts = [0, 3, 5, 1, 0, 2][i]
+        images[10 + i] = gio.ColmapImage(10 + i, q, rng.randn(3) * 2, 1 + i % 4, "img_%02d.png" % (5 - i),
+                                         rng.uniform(0, 600, (npts, 2)), rng.randint(-1, 50, npts).astype(np.int64))
+    pts = (rng.randn(9, 3), rng.randint(0, 256, (9, 3)), rng.uniform(0, 2, (9, 1)))
+    gio.write_colmap_binary(d, cams, images, pts)
+    with open(os.path.join(d, "cameras.txt"), "w") as f:   # only PINHOLE: the reference's text reader asserts it
+        f.write("# Camera list with one line of data per camera:\n#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n")
+        f.write("2 PINHOLE 656 488 %r %r %r %r\n" % tuple(float(x) for x in cams[2].params))
+    with open(os.path.join(d, "images.txt"), "w") as f:
+        f.write("# Image list with two lines of data per image:\n")
+        for im in images.values():
+            f.write("%d %s %s %d %s\n" % (im.id, " ".join(repr(float(x)) for x in im.qvec),
+                                          " ".join(repr(float(x)) for x in im.tvec), im.camera_id, im.name))
+            f.write(" ".join("%r %r %d" % (float(x), float(y), int(p)) for (x, y), p in zip(im.xys, im.point3D_ids)) + "\n")
+    with open(os.path.join(d, "points3D.txt"), "w") as f:
+        f.write("# 3D point list\n")
+        for i in range(9):
+            f.write("%d %s %d %d %d %r 1 2 3 4\n" % (i + 1, " ".join(repr(float(v)) for v in pts[0][i]),
+                                                     *[int(v) for v in pts[1][i]], float(pts[2][i][0])))
+    out = {}
+    rc = ref.read_intrinsics_binary(os.path.join(d, "cameras.bin"))
+    out["cam_ids"] = np.array(sorted(rc))
+    for k in sorted(rc):
+        out["cam%d_model" % k] = np.array(rc[k].model)
+        out["cam%d_wh" % k] = np.array([rc[k].width, rc[k].height])
+        out["cam%d_params" % k] = np.array(rc[k].params)
+    for tag, ri in (("bin", ref.read_extrinsics_binary(os.path.join(d, "images.bin"))),
+                    ("txt", ref.read_extrinsics_text(os.path.join(d, "images.txt")))):
+        out["img_ids_" + tag] = np.array(sorted(ri))
+        for k in sorted(ri):
+            out["img%d_%s_qt" % (k, tag)] = np.concatenate((ri[k].qvec, ri[k].tvec))
+            out["img%d_%s_cam" % (k, tag)] = np.array(ri[k].camera_id)
+            out["img%d_%s_name" % (k, tag)] = np.array(ri[k].name)
+            out["img%d_%s_xys" % (k, tag)] = np.asarray(ri[k].xys, dtype=np.float64).reshape(-1, 2)
+            out["img%d_%s_p3d" % (k, tag)] = np.asarray(ri[k].point3D_ids, dtype=np.int64)
+            out["img%d_%s_R" % (k, tag)] = ref.qvec2rotmat(ri[k].qvec)
+            out["img%d_%s_q_back" % (k, tag)] = ref.rotmat2qvec(ref.qvec2rotmat(ri[k].qvec))
+    rt = ref.read_intrinsics_text(os.path.join(d, "cameras.txt"))
+    out["txtcam_params"] = np.array(rt[2].params)
+    for tag, fn, name in (("bin", ref.read_points3D_binary, "points3D.bin"), ("txt", ref.read_points3D_text, "points3D.txt")):
+        xyz, rgb, err = fn(os.path.join(d, name))
+        out["pts_xyz_" + tag], out["pts_rgb_" + tag], out["pts_err_" + tag] = xyz, rgb, err
+    np.savez(os.path.join(HERE, "colmap_expected.npz"), **out)
 
 
 def gen_sh():
@@ -130,4 +195,5 @@ if __name__ == "__main__":
     gen_cameras()
     gen_losses()
     gen_schedule()
+    gen_colmap()
     print("golden fixtures written to", HERE)
