@@ -172,6 +172,18 @@ int gs_backward_x(const GsView* view, const GsGaussians* g, const int32_t* radii
                   const float* dL_dinvdepth, const float* dL_dextra_img, const GsGrads* grads,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The older rasterizer generation used by FSGS / DNGaussian (SURVEY 8f-4;
+ * FSGS/submodules/diff-gaussian-rasterization-confidence: `rasterize_gaussians` returns colour, depth, alpha -
+ * rasterize_points.cu, forward.cu:262-380; backward takes their three image gradients, backward.cu:414-600).
+ * Same geometry phase (gs_forward_geometry with antialiasing = 0: the 0.3 low-pass is unconditional there).
+ * out_depth[H,W] = sum depth_i alpha_i T_i (view-space z), out_alpha[H,W] = sum alpha_i T_i; no inverse depth. */
+int gs_forward_render_fsgs(const GsView* view, const GsGaussians* g, GsScratch* scratch,
+                           float* out_color, float* out_depth, float* out_alpha, void* stream);
+int gs_backward_fsgs(const GsView* view, const GsGaussians* g, const int32_t* radii,
+                     const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
+                     const float* dL_ddepth, const float* dL_dalpha, const GsGrads* grads,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* present[i] = (view-space z of means3D[i]) > 0.2   (rasterizer_impl.cu:54-66) */
 int gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
                     const float* projmatrix, uint8_t* present, void* stream);
@@ -193,6 +205,11 @@ int gs_export_img(const GsScratch* scratch, int32_t W, int32_t H, float* final_T
 size_t gs_knn_tmp_bytes(int32_t P);
 int gs_knn_mean_dist2(const float* xyz /*[P,3]*/, int32_t P, float* out /*[P]*/, void* tmp,
                       size_t tmp_bytes, void* stream);
+/* FSGS's fork of simple-knn (FSGS/submodules/simple-knn/simple_knn.cu:132-189, spatial.cu) also returns the three
+ * neighbours themselves: nearest[3 i + j] = index of the j-th nearest point of point i (nearest first; ties and
+ * the traversal order are the reference's).  nearest == NULL is gs_knn_mean_dist2. */
+int gs_knn_mean_dist2_idx(const float* xyz /*[P,3]*/, int32_t P, float* out /*[P]*/,
+                          int32_t* nearest /*[P,3]*/, void* tmp, size_t tmp_bytes, void* stream);
 
 /* ---- losses (images are [C,H,W] or [N,C,H,W] contiguous fp32) ---- */
 

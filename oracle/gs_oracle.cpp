@@ -444,9 +444,16 @@ static void radix_sort_pairs(uint64_t* kin, uint64_t* kout, uint32_t* vin, uint3
 }
 
 /* forward.cu:274-397, one tile */
+static int g_fsgs_exact_T = getenv("GSO_FSGS_T") != nullptr;
+
 static void render_tile_fwd(uint32_t tx, uint32_t ty, uint32_t hblocks, int W, int H, const Img& im,
                             const uint32_t* point_list, const Geom& gs, const float* features,
-                            const float* bg, float* out_color, float* invdepth) {
+                            const float* bg, float* out_color, float* invdepth, float* fs_depth = nullptr,
+                            float* fs_alpha = nullptr) {
+  /* fs_depth / fs_alpha != NULL: the older rasterizer generation of FSGS / DNGaussian
+   * (FSGS/submodules/diff-gaussian-rasterization-confidence/cuda_rasterizer/forward.cu:262-380): per pixel
+   * depth = sum depth_i alpha_i T_i and alpha = sum alpha_i T_i; its backward reads T_final back as 1 - alpha
+   * (backward.cu:461), so that is what the image state keeps. */
   const uint32_t r0 = im.ranges[2 * (ty * hblocks + tx)], r1 = im.ranges[2 * (ty * hblocks + tx) + 1];
   for (uint32_t ly = 0; ly < BLOCK_Y; ly++)
     for (uint32_t lx = 0; lx < BLOCK_X; lx++) {
@@ -458,6 +465,7 @@ static void render_tile_fwd(uint32_t tx, uint32_t ty, uint32_t hblocks, int W, i
       uint32_t contributor = 0, last_contributor = 0;
       float C[NCH] = {0};
       float expected_invdepth = 0.0f;
+      float weight = 0.0f, Dsum = 0.0f;
       for (uint32_t k = r0; k < r1; k++) {
         contributor++;
         uint32_t id = point_list[k];
@@ -471,18 +479,45 @@ static void render_tile_fwd(uint32_t tx, uint32_t ty, uint32_t hblocks, int W, i
         if (test_T < 0.0001f) break; /* done = true */
         for (int ch = 0; ch < NCH; ch++) C[ch] += features[id * NCH + ch] * alpha * T;
         if (invdepth) expected_invdepth += (1 / gs.depths[id]) * alpha * T;
+        if (fs_alpha) {
+          weight += alpha * T;
+          Dsum += gs.depths[id] * alpha * T;
+        }
         T = test_T;
         last_contributor = contributor;
       }
-      im.accum_alpha[pix_id] = T;
+      /* test probe (GSO_FSGS_T=1 or gso_set_fsgs_exact_T(1)): keep the exact product instead of the reference's
+       * 1 - alpha read-back, which loses up to ~1e-3 relative accuracy of T on saturated pixels
+       * (tests/test_fsgs_cpu.py attributes the difference; the HIP path keeps the product) */
+      im.accum_alpha[pix_id] = (fs_alpha && !g_fsgs_exact_T) ? 1 - weight : T;
       im.n_contrib[pix_id] = last_contributor;
+      if (fs_alpha) {
+        fs_alpha[pix_id] = weight;
+        fs_depth[pix_id] = Dsum;
+      }
       for (int ch = 0; ch < NCH; ch++) out_color[(size_t)ch * H * W + pix_id] = C[ch] + T * bg[ch];
       if (invdepth) invdepth[pix_id] = expected_invdepth;
     }
 }
 
+static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch* s, float* out_color,
+                               float* out_invdepth, float* fs_depth, float* fs_alpha);
+
 int gso_forward_render(const GsView* v, const GsGaussians* g, GsScratch* s, float* out_color,
                        float* out_invdepth, void* /*stream*/) {
+  return forward_render_impl(v, g, s, out_color, out_invdepth, nullptr, nullptr);
+}
+
+/* dgr_fsgs `rasterize_gaussians` (rasterize_points.cu of the -confidence fork): colour, depth, alpha. */
+int gso_forward_render_fsgs(const GsView* v, const GsGaussians* g, GsScratch* s, float* out_color,
+                            float* out_depth, float* out_alpha, void* /*stream*/) {
+  if (!out_depth || !out_alpha) return GS_E_NULL;
+  if (v && v->antialiasing) return GS_E_UNSUPPORTED; /* that generation has no anti-aliasing */
+  return forward_render_impl(v, g, s, out_color, nullptr, out_depth, out_alpha);
+}
+
+static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch* s, float* out_color,
+                               float* out_invdepth, float* fs_depth, float* fs_alpha) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!s || !s->geom || !s->img || !out_color) return GS_E_NULL;
@@ -493,6 +528,10 @@ int gso_forward_render(const GsView* v, const GsGaussians* g, GsScratch* s, floa
   if (P == 0) { /* rasterize_points.cu:88: outputs stay zero */
     memset(out_color, 0, sizeof(float) * NCH * N);
     if (out_invdepth) memset(out_invdepth, 0, sizeof(float) * N);
+    if (fs_alpha) {
+      memset(fs_alpha, 0, sizeof(float) * N);
+      memset(fs_depth, 0, sizeof(float) * N);
+    }
     return GS_OK;
   }
   Geom gs = geom_from(s->geom, P);
@@ -548,7 +587,8 @@ int gso_forward_render(const GsView* v, const GsGaussians* g, GsScratch* s, floa
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
   for (uint32_t ty = 0; ty < gy; ty++)
     for (uint32_t tx = 0; tx < gx; tx++)
-      render_tile_fwd(tx, ty, gx, W, H, im, b.point_list, gs, feature_ptr, v->bg, out_color, out_invdepth);
+      render_tile_fwd(tx, ty, gx, W, H, im, b.point_list, gs, feature_ptr, v->bg, out_color, out_invdepth, fs_depth,
+                      fs_alpha);
   return GS_OK;
 }
 
@@ -561,7 +601,10 @@ enum { A_MX = 0, A_MY, A_CXX, A_CXY, A_CYY, A_OP, A_CR, A_CG, A_CB, A_ID, A_N };
 static void render_tile_bwd(uint32_t tx, uint32_t ty, uint32_t hblocks, int W, int H, const Img& im,
                             const uint32_t* point_list, const Geom& gs, const float* colors,
                             const float* bg, const float* dL_dpixels, const float* dL_invdepths,
-                            std::vector<double>& loc, std::vector<uint8_t>& touched) {
+                            std::vector<double>& loc, std::vector<uint8_t>& touched,
+                            const float* fs_dL_ddepth = nullptr, const float* fs_dL_dalpha = nullptr) {
+  /* fs_*: FSGS generation (-confidence fork, backward.cu:414-600): depth and alpha image gradients; A_ID then
+   * accumulates dL_ddepth per Gaussian (backward.cu:563). */
   const uint32_t r0 = im.ranges[2 * (ty * hblocks + tx)], r1 = im.ranges[2 * (ty * hblocks + tx) + 1];
   const uint32_t n = r1 - r0;
   loc.assign((size_t)n * A_N, 0.0);
@@ -584,6 +627,11 @@ static void render_tile_bwd(uint32_t tx, uint32_t ty, uint32_t hblocks, int W, i
       float accum_invdepth_rec = 0;
       for (int i = 0; i < NCH; i++) dL_dpixel[i] = dL_dpixels[(size_t)i * H * W + pix_id];
       if (dL_invdepths) dL_invdepth = dL_invdepths[pix_id];
+      float fs_gd = 0, fs_ga = 0, accum_depth_rec = 0, accum_alpha_rec = 0, last_depth = 0;
+      if (fs_dL_dalpha) {
+        fs_gd = fs_dL_ddepth[pix_id];
+        fs_ga = fs_dL_dalpha[pix_id];
+      }
       float last_alpha = 0;
       float last_color[NCH] = {0};
       float last_invdepth = 0;
@@ -617,6 +665,15 @@ static void render_tile_bwd(uint32_t tx, uint32_t ty, uint32_t hblocks, int W, i
           last_invdepth = invd;
           dL_dalpha += (invd - accum_invdepth_rec) * dL_invdepth;
           acc[A_ID] += (double)(dchannel_dcolor * dL_invdepth);
+        }
+        if (fs_dL_dalpha) {
+          const float c_d = gs.depths[id];
+          accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+          last_depth = c_d;
+          dL_dalpha += (c_d - accum_depth_rec) * fs_gd;
+          acc[A_ID] += (double)(dchannel_dcolor * fs_gd);
+          accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
+          dL_dalpha += (1 - accum_alpha_rec) * fs_ga;
         }
         dL_dalpha *= T;
         last_alpha = alpha;
@@ -856,7 +913,7 @@ static void computeCov3D_bwd(int idx, V3 scl, float mod, V4 rot, const float* dL
 static void preprocess_bwd_one(int idx, int D, int M, const GsView* v, const GsGaussians* g,
                                const int* radii, const uint8_t* clamped, const float* dL_dmean2D /*[P][3]*/,
                                float* dL_dmeans, float* dL_dcolor, const float* dL_dcov3D, float* dL_dsh,
-                               float* dL_dscale, float* dL_drot) {
+                               float* dL_dscale, float* dL_drot, const float* fs_dL_ddepth = nullptr) {
   if (!(radii[idx] > 0)) return;
   const float* proj = v->projmatrix;
   V3 m = {g->means3D[3 * idx], g->means3D[3 * idx + 1], g->means3D[3 * idx + 2]};
@@ -872,6 +929,13 @@ static void preprocess_bwd_one(int idx, int D, int M, const GsView* v, const GsG
   dL_dmeans[3 * idx + 0] += dL_dmean.x;
   dL_dmeans[3 * idx + 1] += dL_dmean.y;
   dL_dmeans[3 * idx + 2] += dL_dmean.z;
+  if (fs_dL_ddepth) { /* -confidence fork, backward.cu:394-403: the depth = view-space z path */
+    const float* view = v->viewmatrix;
+    const float mul3 = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
+    dL_dmeans[3 * idx + 0] += (view[2] - view[3] * mul3) * fs_dL_ddepth[idx];
+    dL_dmeans[3 * idx + 1] += (view[6] - view[7] * mul3) * fs_dL_ddepth[idx];
+    dL_dmeans[3 * idx + 2] += (view[10] - view[11] * mul3) * fs_dL_ddepth[idx];
+  }
   if (g->shs) {
     V3 campos = {v->campos[0], v->campos[1], v->campos[2]};
     computeColorFromSH_bwd(idx, D, M, g->means3D, campos, g->shs, clamped, dL_dcolor, dL_dmeans, dL_dsh);
@@ -883,9 +947,29 @@ static void preprocess_bwd_one(int idx, int D, int M, const GsView* v, const GsG
   }
 }
 
+static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
+                         int64_t num_rendered, const float* dL_dcolor_img, const float* dL_dinvdepth_img,
+                         const float* fs_dL_ddepth, const float* fs_dL_dalpha, const GsGrads* out);
+
 int gso_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
                  int64_t num_rendered, const float* dL_dcolor_img, const float* dL_dinvdepth_img,
                  const GsGrads* out, void* /*ws*/, size_t /*ws_bytes*/, void* /*stream*/) {
+  return backward_impl(v, g, radii, s, num_rendered, dL_dcolor_img, dL_dinvdepth_img, nullptr, nullptr, out);
+}
+
+/* dgr_fsgs `rasterize_gaussians_backward`: image gradients of colour, depth and alpha. */
+int gso_backward_fsgs(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
+                      int64_t num_rendered, const float* dL_dcolor_img, const float* dL_ddepth_img,
+                      const float* dL_dalpha_img, const GsGrads* out, void* /*ws*/, size_t /*ws_bytes*/,
+                      void* /*stream*/) {
+  if (!dL_ddepth_img || !dL_dalpha_img) return GS_E_NULL;
+  if (v && v->antialiasing) return GS_E_UNSUPPORTED;
+  return backward_impl(v, g, radii, s, num_rendered, dL_dcolor_img, nullptr, dL_ddepth_img, dL_dalpha_img, out);
+}
+
+static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
+                         int64_t num_rendered, const float* dL_dcolor_img, const float* dL_dinvdepth_img,
+                         const float* fs_dL_ddepth, const float* fs_dL_dalpha, const GsGrads* out) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!s || !out || !dL_dcolor_img) return GS_E_NULL;
@@ -913,7 +997,7 @@ int gso_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, co
       for (uint32_t ty = 0; ty < gy; ty++)
         for (uint32_t tx = 0; tx < gx; tx++) {
           render_tile_bwd(tx, ty, gx, W, H, im, b.point_list, gs, color_ptr, v->bg, dL_dcolor_img,
-                          dL_dinvdepth_img, loc, touched);
+                          dL_dinvdepth_img, loc, touched, fs_dL_ddepth, fs_dL_dalpha);
           const uint32_t r0 = im.ranges[2 * (ty * gx + tx)];
           for (size_t k = 0; k < touched.size(); k++)
             if (touched[k]) {
@@ -952,7 +1036,8 @@ int gso_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, co
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < P; i++)
     preprocess_bwd_one(i, v->sh_degree, M, v, g, radii, gs.clamped, dL_dmean2D.data(), dL_dmeans3D.data(),
-                       dL_dcolors.data(), dL_dcov3D.data(), dL_dsh.data(), dL_dscales.data(), dL_drot.data());
+                       dL_dcolors.data(), dL_dcov3D.data(), dL_dsh.data(), dL_dscales.data(), dL_drot.data(),
+                       fs_dL_dalpha ? dL_dinvd.data() : nullptr);
   if (out->dL_dmeans3D) memcpy(out->dL_dmeans3D, dL_dmeans3D.data(), 12 * (size_t)P);
   if (out->dL_dmeans2D) memcpy(out->dL_dmeans2D, dL_dmean2D.data(), 12 * (size_t)P);
   if (out->dL_dsh && M > 0) memcpy(out->dL_dsh, dL_dsh.data(), 12 * (size_t)P * M);
@@ -1038,6 +1123,11 @@ int gso_test_sh_bwd(int32_t P, int32_t deg, int32_t M, const float* means, const
 }
 
 /* thread control for the cpu_baseline leg of bench.py ("cores" = threads actually used) */
+int gso_set_fsgs_exact_T(int32_t on) {
+  g_fsgs_exact_T = on != 0;
+  return GS_OK;
+}
+
 int gso_set_num_threads(int32_t n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);

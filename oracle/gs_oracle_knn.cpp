@@ -62,6 +62,24 @@ static inline void updateKBest3(V3 ref, V3 point, float* knn) {
   }
 }
 
+/* FSGS/submodules/simple-knn/simple_knn.cu:132-147: the index is carried through the same insertion */
+static inline void updateKBest3Idx(V3 ref, V3 point, float* knn, int32_t* ind, int32_t pid) {
+  V3 d = {point.x - ref.x, point.y - ref.y, point.z - ref.z};
+  float dist = d.x * d.x + d.y * d.y + d.z * d.z;
+  for (int j = 0; j < 3; j++) {
+    if (knn[j] > dist) {
+      float t = knn[j];
+      knn[j] = dist;
+      dist = t;
+      int32_t ti = ind[j];
+      ind[j] = pid;
+      pid = ti;
+    }
+  }
+}
+
+static int32_t* g_nearest_out = nullptr; /* set by gso_knn_mean_dist2_idx around the shared implementation */
+
 extern "C" {
 
 size_t gso_knn_tmp_bytes(int32_t) { return 128; }
@@ -99,9 +117,12 @@ int gso_knn_mean_dist2_ex(const float* xyz, int32_t P, float* out, uint32_t* mor
   for (int i = 0; i < P; i++) {
     V3 point = pts[idx[i]];
     float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    int32_t bi[3] = {0, 0, 0}; /* FSGS fork: not cleared between the two passes (simple_knn.cu:158-171) */
+    int32_t* nearest = g_nearest_out;
     for (int j = std::max(0, i - 3); j <= std::min(P - 1, i + 3); j++) {
       if (j == i) continue;
-      updateKBest3(point, pts[idx[j]], best);
+      if (nearest) updateKBest3Idx(point, pts[idx[j]], best, bi, (int32_t)idx[j]);
+      else updateKBest3(point, pts[idx[j]], best);
     }
     float reject = best[2];
     best[0] = best[1] = best[2] = FLT_MAX;
@@ -110,15 +131,24 @@ int gso_knn_mean_dist2_ex(const float* xyz, int32_t P, float* out, uint32_t* mor
       if (dist > reject || dist > best[2]) continue;
       for (int j = b * BOX_SIZE; j < std::min<int>(P, (b + 1) * BOX_SIZE); j++) {
         if (j == i) continue;
-        updateKBest3(point, pts[idx[j]], best);
+        if (nearest) updateKBest3Idx(point, pts[idx[j]], best, bi, (int32_t)idx[j]);
+        else updateKBest3(point, pts[idx[j]], best);
       }
     }
     out[idx[i]] = (best[0] + best[1] + best[2]) / 3.0f;
+    if (nearest)
+      for (int j = 0; j < 3; j++) nearest[3 * (size_t)idx[i] + j] = bi[j];
   }
   return GS_OK;
 }
 
 int gso_knn_mean_dist2(const float* xyz, int32_t P, float* out, void*, size_t, void*) {
   return gso_knn_mean_dist2_ex(xyz, P, out, nullptr);
+}
+int gso_knn_mean_dist2_idx(const float* xyz, int32_t P, float* out, int32_t* nearest, void*, size_t, void*) {
+  g_nearest_out = nearest; /* the checker is driven from one thread */
+  int rc = gso_knn_mean_dist2_ex(xyz, P, out, nullptr);
+  g_nearest_out = nullptr;
+  return rc;
 }
 }

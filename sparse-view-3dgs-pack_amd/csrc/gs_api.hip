@@ -109,12 +109,27 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
   return gs_forward_render_x(v, g, sc, out_color, out_invdepth, nullptr, stream);
 }
 
+static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_invdepth,
+                               float* out_extra, int fsgs, void* stream);
+
 int gs_forward_render_x(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_invdepth,
                         float* out_extra, void* stream) {
+  if (out_extra && g && !g->extra_channel) return GS_E_NULL;
+  return forward_render_impl(v, g, sc, out_color, out_invdepth, out_extra, 0, stream);
+}
+
+int gs_forward_render_fsgs(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_depth,
+                           float* out_alpha, void* stream) {
+  if (!out_depth || !out_alpha) return GS_E_NULL;
+  if (v && v->antialiasing) return GS_E_UNSUPPORTED;  // that rasterizer generation has no anti-aliasing
+  return forward_render_impl(v, g, sc, out_color, out_depth, out_alpha, 1, stream);
+}
+
+static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_invdepth,
+                               float* out_extra, int fsgs, void* stream) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !sc->geom || !sc->img || !out_color) return GS_E_NULL;
-  if (out_extra && !g->extra_channel) return GS_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   const int P = g->P, W = v->image_width, H = v->image_height;
   int gx, gy;
@@ -171,13 +186,13 @@ int gs_forward_render_x(const GsView* v, const GsGaussians* g, GsScratch* sc, fl
     GS_PROF(ST_RENDER_FWD, s);
     // GS_FWD_KERNEL=quad selects the first-generation kernel (one pixel per lane, four waves per tile)
     static const bool quad = getenv("GS_FWD_KERNEL") && !strcmp(getenv("GS_FWD_KERNEL"), "quad");
-    if (quad && out_extra) return GS_E_UNSUPPORTED;  // the first-generation kernels blend three channels only
+    if (quad && (out_extra || fsgs)) return GS_E_UNSUPPORTED;  // the first-generation kernels blend three channels only
     if (quad)
       launch_render_fwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
                         out_invdepth, s);
     else
       launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
-                             out_invdepth, out_extra, s);
+                             out_invdepth, out_extra, fsgs, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
@@ -190,13 +205,33 @@ int gs_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, con
                        stream);
 }
 
+static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
+                         int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra,
+                         int fsgs, const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 int gs_backward_x(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
                   int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra,
                   const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+  if (dL_dextra && g && grads && (!g->extra_channel || !grads->dL_dextra)) return GS_E_NULL;
+  return backward_impl(v, g, radii, sc, num_rendered, dL_dcolor, dL_dinvdepth, dL_dextra, 0, grads, workspace,
+                       workspace_bytes, stream);
+}
+
+int gs_backward_fsgs(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
+                     int64_t num_rendered, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                     const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dL_ddepth || !dL_dalpha) return GS_E_NULL;
+  if (v && v->antialiasing) return GS_E_UNSUPPORTED;
+  return backward_impl(v, g, radii, sc, num_rendered, dL_dcolor, dL_ddepth, dL_dalpha, 1, grads, workspace,
+                       workspace_bytes, stream);
+}
+
+static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
+                         int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra,
+                         int fsgs, const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !grads || !dL_dcolor) return GS_E_NULL;
-  if (dL_dextra && (!g->extra_channel || !grads->dL_dextra)) return GS_E_NULL;
   const int P = g->P, W = v->image_width, H = v->image_height;
   if (P == 0) return GS_OK;
   if (!radii || !sc->geom || !sc->img || !workspace) return GS_E_NULL;
@@ -220,13 +255,13 @@ int gs_backward_x(const GsView* v, const GsGaussians* g, const int32_t* radii, c
       GS_PROF(ST_RENDER_BWD, s);
       // GS_BWD_KERNEL=quad selects the first-generation kernel (one pixel per lane, four waves per tile)
       static const bool quad = getenv("GS_BWD_KERNEL") && !strcmp(getenv("GS_BWD_KERNEL"), "quad");
-      if (quad && dL_dextra) return GS_E_UNSUPPORTED;
+      if (quad && (dL_dextra || fsgs)) return GS_E_UNSUPPORTED;
       if (quad)
         launch_render_bwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
                           dL_dinvdepth, rows, s);
       else
         launch_render_bwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
-                               dL_dinvdepth, dL_dextra, rows, s);
+                               dL_dinvdepth, dL_dextra, rows, fsgs, s);
     }
     GS_LAUNCH_CHECK(s, v->debug);
   }
@@ -251,7 +286,7 @@ int gs_backward_x(const GsView* v, const GsGaussians* g, const int32_t* radii, c
   a.tan_fovx = v->tanfovx;
   a.tan_fovy = v->tanfovy;
   a.antialiasing = v->antialiasing;
-  a.has_invdepth = dL_dinvdepth != nullptr;
+  a.has_invdepth = fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0);
   a.grad_rows = rows;
   a.splat = gv.splat;
   a.out = *grads;

@@ -221,10 +221,11 @@ int launch_render_bwd(const uint2* ranges, const uint32_t* point_list, int W, in
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                           float* out_invdepth, float* out_extra, hipStream_t s);
+                           float* out_invdepth, float* out_extra, int fsgs, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                           const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, hipStream_t s);
+                           const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs,
+                           hipStream_t s);
 
 struct PreprocessBwdArgs {
   int P, D, M;
@@ -242,7 +243,7 @@ struct PreprocessBwdArgs {
   const float* campos;
   float focal_x, focal_y, tan_fovx, tan_fovy;
   int antialiasing;
-  int has_invdepth;
+  int has_invdepth;  // 0: none, 1: inverse-depth image gradient (dr_aa), 2: depth image gradient (FSGS generation)
   const float* grad_rows;  // [P][GR_STRIDE]
   const Splat* splat;
   GsGrads out;

@@ -181,23 +181,46 @@ GS_DEV float dist_box_point(const float* b, float px, float py, float pz) {
   return dx * dx + dy * dy + dz * dz;
 }
 
+// FSGS's fork also reports WHICH three points are nearest (FSGS/submodules/simple-knn/simple_knn.cu:132-189):
+// the index travels with the distance through the same insertion, starts at 0 and is NOT cleared between the
+// neighbour pass and the box pass.
+GS_DEV void update_kbest3_idx(float rx, float ry, float rz, float4 pt, float* knn, int32_t* ind, int32_t pid) {
+  const float dx = pt.x - rx, dy = pt.y - ry, dz = pt.z - rz;
+  float dist = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    if (knn[j] > dist) {
+      const float t = knn[j];
+      knn[j] = dist;
+      dist = t;
+      const int32_t ti = ind[j];
+      ind[j] = pid;
+      pid = ti;
+    }
+  }
+}
+
 // boxMeanDist, simple_knn.cu:148-184: 256 consecutive (Morton-ordered) queries per workgroup
+template <bool WITH_IDX>
 __global__ void __launch_bounds__(GS_BLOCK) knn_search_kernel(const float4* __restrict__ sorted, int P,
                                                               const uint32_t* __restrict__ order,
                                                               const float* __restrict__ boxes, int nb,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int32_t* __restrict__ nearest) {
   __shared__ float4 s_pts[KNN_BOX];
+  __shared__ uint32_t s_ord[WITH_IDX ? KNN_BOX : 1];
   __shared__ float s_box[6];
   const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
   const bool active = idx < P;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  int32_t bi[3] = {0, 0, 0};
   float reject = FLT_MAX;
   if (active) {
     q = sorted[idx];
     for (int i = max(0, idx - 3); i <= min(P - 1, idx + 3); i++) {
       if (i == idx) continue;
-      update_kbest3(q.x, q.y, q.z, sorted[i], best);
+      if (WITH_IDX) update_kbest3_idx(q.x, q.y, q.z, sorted[i], best, bi, (int32_t)order[i]);
+      else update_kbest3(q.x, q.y, q.z, sorted[i], best);
     }
     reject = best[2];
     best[0] = best[1] = best[2] = FLT_MAX;
@@ -214,16 +237,28 @@ __global__ void __launch_bounds__(GS_BLOCK) knn_search_kernel(const float4* __re
     if (!__syncthreads_or(need)) continue;
     const int base = b * KNN_BOX;
     const int cnt = min(KNN_BOX, P - base);
-    for (int k = threadIdx.x; k < cnt; k += GS_BLOCK) s_pts[k] = sorted[base + k];
+    for (int k = threadIdx.x; k < cnt; k += GS_BLOCK) {
+      s_pts[k] = sorted[base + k];
+      if (WITH_IDX) s_ord[k] = order[base + k];
+    }
     __syncthreads();
     if (need) {
       for (int k = 0; k < cnt; k++) {
         if (base + k == idx) continue;
-        update_kbest3(q.x, q.y, q.z, s_pts[k], best);
+        if (WITH_IDX) update_kbest3_idx(q.x, q.y, q.z, s_pts[k], best, bi, (int32_t)s_ord[k]);
+        else update_kbest3(q.x, q.y, q.z, s_pts[k], best);
       }
     }
   }
-  if (active) out[order[idx]] = (best[0] + best[1] + best[2]) / 3.0f;
+  if (active) {
+    const uint32_t me = order[idx];
+    out[me] = (best[0] + best[1] + best[2]) / 3.0f;
+    if (WITH_IDX) {
+      nearest[3 * (size_t)me] = bi[0];
+      nearest[3 * (size_t)me + 1] = bi[1];
+      nearest[3 * (size_t)me + 2] = bi[2];
+    }
+  }
 }
 
 extern "C" {
@@ -231,6 +266,11 @@ extern "C" {
 size_t gs_knn_tmp_bytes(int32_t P) { return knn_bytes((size_t)(P > 0 ? P : 1)); }
 
 int gs_knn_mean_dist2(const float* xyz, int32_t P, float* out, void* tmp, size_t tmp_bytes, void* stream) {
+  return gs_knn_mean_dist2_idx(xyz, P, out, nullptr, tmp, tmp_bytes, stream);
+}
+
+int gs_knn_mean_dist2_idx(const float* xyz, int32_t P, float* out, int32_t* nearest, void* tmp, size_t tmp_bytes,
+                          void* stream) {
   if (P < 0) return GS_E_SHAPE;
   if (P == 0) return GS_OK;
   if (!xyz || !out || !tmp) return GS_E_NULL;
@@ -250,8 +290,12 @@ int gs_knn_mean_dist2(const float* xyz, int32_t P, float* out, void* tmp, size_t
   if (rc) return rc;
   hipLaunchKernelGGL(knn_gather_kernel, dim3(nblk_p), dim3(GS_BLOCK), 0, s, xyz, P, bv.vals[0], t.sorted);
   hipLaunchKernelGGL(knn_box_kernel, dim3((unsigned)t.nb), dim3(GS_BLOCK), 0, s, t.sorted, P, t.boxes);
-  hipLaunchKernelGGL(knn_search_kernel, dim3(nblk_p), dim3(GS_BLOCK), 0, s, t.sorted, P, bv.vals[0], t.boxes, (int)t.nb,
-                     out);
+  if (nearest)
+    hipLaunchKernelGGL(knn_search_kernel<true>, dim3(nblk_p), dim3(GS_BLOCK), 0, s, t.sorted, P, bv.vals[0], t.boxes,
+                       (int)t.nb, out, nearest);
+  else
+    hipLaunchKernelGGL(knn_search_kernel<false>, dim3(nblk_p), dim3(GS_BLOCK), 0, s, t.sorted, P, bv.vals[0], t.boxes,
+                       (int)t.nb, out, nearest);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }

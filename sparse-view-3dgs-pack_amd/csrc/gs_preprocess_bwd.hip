@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
     float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
     float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
     float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
-    if (a.has_invdepth) dL_dtz -= dL_dinvdepth / (t.z * t.z);
+    if (a.has_invdepth == 1) dL_dtz -= dL_dinvdepth / (t.z * t.z);
     dL_dmean = xformvec4x3T({dL_dtx, dL_dty, dL_dtz}, vm);  // "=" of backward.cu:325
 
     // ------------------------------------------------------------------ preprocessCUDA backward
@@ -214,6 +214,12 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
     dm.y = (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
     dm.z = (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
     dL_dmean = dL_dmean + dm;  // "+=" of backward.cu:440
+    if (a.has_invdepth == 2) {  // FSGS generation: the slot holds dL_ddepth (view-space z), -confidence backward.cu:394-403
+      const float mul3 = vm[2] * m.x + vm[6] * m.y + vm[10] * m.z + vm[14];
+      V3 dm2 = {(vm[2] - vm[3] * mul3) * dL_dinvdepth, (vm[6] - vm[7] * mul3) * dL_dinvdepth,
+                (vm[10] - vm[11] * mul3) * dL_dinvdepth};
+      dL_dmean = dL_dmean + dm2;
+    }
 
     if (a.shs) {
       const uint32_t clamped = a.splat[idx].clamped;

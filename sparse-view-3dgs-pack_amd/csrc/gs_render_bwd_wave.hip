@@ -48,7 +48,10 @@ __device__ __forceinline__ float row_total_in_lane15(float v) {
 
 #define WB 64  // batch = one list entry per lane
 
-template <bool HAS_INVDEPTH, bool HAS_EXTRA>
+// FSGS: the older generation's backward (-confidence fork, backward.cu:414-600) = the depth channel carries the
+// view-space depth instead of its inverse and the 4th channel is the alpha image: a constant colour 1 without a
+// background term (accum_alpha_rec = last_alpha + (1 - last_alpha) accum_alpha_rec, dL_dopa += (1 - accum) dL_dalpha).
+template <bool HAS_INVDEPTH, bool HAS_EXTRA, bool FSGS>
 __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) render_bwd_wave_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const Splat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
     dLinv[s] = (HAS_INVDEPTH && inside) ? dL_invdepths[pix_id] : 0.f;
     dLpX[s] = (HAS_EXTRA && inside) ? dL_dextra[pix_id] : 0.f;
     float b = 0;
-    if (HAS_EXTRA) b += bg[0] * dLpX[s];  // the 4th channel's image is X + T bg[0]
+    if (HAS_EXTRA && !FSGS) b += bg[0] * dLpX[s];  // the 4th channel's image is X + T bg[0]
     b += bg[0] * dLp0[s];
     b += bg[1] * dLp1[s];
     b += bg[2] * dLp2[s];
@@ -124,9 +127,9 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
   for (int i = q0 / WB; i < rounds; i++) {
     __syncthreads();  // (single wave) previous batch fully consumed
     s_id[lane] = rid;
-    s_a[lane] = make_float4(ra.x, ra.y, ra.w, 0.f);
+    s_a[lane] = make_float4(ra.x, ra.y, FSGS ? ra.z : ra.w, 0.f);
     s_c[lane] = blend_stage_conic(rc);  // (qa, qb, qc, opacity), see gs_blend.h
-    s_k[lane] = rk;
+    s_k[lane] = FSGS ? make_float4(rk.x, rk.y, rk.z, 1.0f) : rk;
     __syncthreads();
     {
       const int q = (i + 1) * WB + lane;
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
         if (t0 != 0.0f) atomicAdd(row + q, t0 * rowscale0);      // mean2D.x, mean2D.y, conic.xx, conic.xy
         if (t1 != 0.0f) atomicAdd(row + 4 + q, t1 * rowscale1);  // conic.yy, opacity, colour r, g
         // colour b (row 0 -> slot 8), 4th channel (row 1 -> slot 10), inverse depth (row 2 -> slot 9)
-        const bool live2 = q == 0 || (HAS_EXTRA && q == 1) || (HAS_INVDEPTH && q == 2);
+        const bool live2 = q == 0 || (HAS_EXTRA && !FSGS && q == 1) || (HAS_INVDEPTH && q == 2);
         if (live2 && t2 != 0.0f) atomicAdd(row + (q == 0 ? GR_CB : (q == 1 ? GR_EXTRA : GR_ID)), t2);
       }
     }
@@ -239,14 +242,15 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                            const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows,
-                           hipStream_t s) {
-#define GS_BWD_WAVE(ID, EX)                                                                                            \
-  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, \
+                           int fsgs, hipStream_t s) {
+#define GS_BWD_WAVE(ID, EX, FS)                                                                                           \
+  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX, FS>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, \
                      grid_x, splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, dL_dextra, grad_rows)
-  if (dL_dinvdepth && dL_dextra) GS_BWD_WAVE(true, true);
-  else if (dL_dinvdepth) GS_BWD_WAVE(true, false);
-  else if (dL_dextra) GS_BWD_WAVE(false, true);
-  else GS_BWD_WAVE(false, false);
+  if (fsgs) GS_BWD_WAVE(true, true, true);
+  else if (dL_dinvdepth && dL_dextra) GS_BWD_WAVE(true, true, false);
+  else if (dL_dinvdepth) GS_BWD_WAVE(true, false, false);
+  else if (dL_dextra) GS_BWD_WAVE(false, true, false);
+  else GS_BWD_WAVE(false, false, false);
 #undef GS_BWD_WAVE
   return 0;
 }

@@ -11,7 +11,12 @@
 
 #define WB 64
 
-template <bool HAS_EXTRA>
+// FSGS: the older rasterizer generation of FSGS / DNGaussian (-confidence fork, forward.cu:262-380): out_invdepth
+// receives depth = sum depth_i alpha_i T_i, out_extra receives alpha = sum alpha_i T_i.  The image state keeps the
+// transmittance PRODUCT: that generation's backward reads T_final back as 1 - alpha (backward.cu:461), which on
+// saturated pixels (T ~ 1e-4) keeps only ~3 digits of T and puts ~1e-3 of fp32 noise on its gradients; the product
+// is the same quantity without the cancellation (tests/test_gpu_fsgs.py compares against both forms).
+template <bool HAS_EXTRA, bool FSGS>
 __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list, int W, int H,
                                                              int grid_x, const Splat* __restrict__ splat,
@@ -59,7 +64,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     // the whole tile is done (forward.cu:326-328)
     if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
     __syncthreads();  // single wave: previous batch fully consumed
-    s_a[lane] = make_float4(ra.x, ra.y, ra.w, 0.f);
+    s_a[lane] = make_float4(ra.x, ra.y, FSGS ? ra.z : ra.w, 0.f);
     s_c[lane] = blend_stage_conic(rc);  // (qa, qb, qc, opacity), see gs_blend.h
     {
       // Exact-safe tile cull: alpha >= 1/255 needs power >= -L with L = ln(255 * opacity); the set
@@ -121,6 +126,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
             C2[s] += k.z * w;
             D[s] += a.z * w;
             if (HAS_EXTRA) X[s] += s_e[j] * w;
+            if (FSGS) X[s] += w;
             T[s] = test_T;
             last_contributor[s] = contributor;
           }
@@ -143,18 +149,22 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       out_color[2 * HW + pix_id] = C2[s] + T[s] * bg2;
       if (out_invdepth) out_invdepth[pix_id] = D[s];
       if (HAS_EXTRA) out_extra[pix_id] = X[s] + T[s] * bg0;  // the reference's NIR pass keeps channel 0 (bg[0])
+      if (FSGS) out_extra[pix_id] = X[s];
     }
   }
 }
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                           float* out_invdepth, float* out_extra, hipStream_t s) {
-  if (out_extra)
-    hipLaunchKernelGGL(render_fwd_wave_kernel<true>, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x,
-                       splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
+                           float* out_invdepth, float* out_extra, int fsgs, hipStream_t s) {
+  if (fsgs)
+    hipLaunchKernelGGL((render_fwd_wave_kernel<false, true>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H,
+                       grid_x, splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
+  else if (out_extra)
+    hipLaunchKernelGGL((render_fwd_wave_kernel<true, false>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H,
+                       grid_x, splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
   else
-    hipLaunchKernelGGL(render_fwd_wave_kernel<false>, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x,
-                       splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
+    hipLaunchKernelGGL((render_fwd_wave_kernel<false, false>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H,
+                       grid_x, splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
   return 0;
 }

@@ -101,12 +101,16 @@ PROTOTYPES = {
     "forward_render_x": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P, _P]),
     "backward_x": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P, _P,
                              C.POINTER(GsGrads), _P, _SZ, _P]),
+    "forward_render_fsgs": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P, _P]),
+    "backward_fsgs": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P, _P,
+                                C.POINTER(GsGrads), _P, _SZ, _P]),
     "mark_visible": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
     "export_geom": (C.c_int, [C.POINTER(GsScratch), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "export_binning": (C.c_int, [C.POINTER(GsScratch), _I64, _P, _P, _P]),
     "export_img": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _P, _P, _P, _P]),
     "knn_tmp_bytes": (_SZ, [_I32]),
     "knn_mean_dist2": (C.c_int, [_P, _I32, _P, _P, _SZ, _P]),
+    "knn_mean_dist2_idx": (C.c_int, [_P, _I32, _P, _P, _P, _SZ, _P]),
     "l1_fwd": (C.c_int, [_P, _P, _I64, _P, _P]),
     "l1_bwd": (C.c_int, [_P, _P, _I64, _F, _P, _I32, _P]),
     "dwt_haar_fwd": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),

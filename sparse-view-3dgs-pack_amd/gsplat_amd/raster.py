@@ -138,13 +138,17 @@ class RasterBackend:
     # ------------------------------------------------------------------ forward
     def rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                             cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
-                            sh, degree, campos, prefiltered, antialiasing, debug, extra=None):
+                            sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False):
         """= RasterizeGaussiansCUDA (rasterize_points.cu:35-124).
 
         Returns (num_rendered, color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
         invdepth[1,H,W]).  binningBuffer carries its capacity in its length (see _capacity).
         extra [P] (not part of the reference's signature): a 4th per-Gaussian channel blended in the same
-        pass (gs_forward_render_x); the tuple then ends with its image [1,H,W]."""
+        pass (gs_forward_render_x); the tuple then ends with its image [1,H,W].
+        fsgs=True: the older generation of FSGS / DNGaussian (gs_forward_render_fsgs): the "invdepth" slot of the
+        tuple holds depth = sum depth alpha T and the tuple ends with alpha = sum alpha T, both [1,H,W]."""
+        if fsgs and (extra is not None or antialiasing):
+            raise RuntimeError("the FSGS rasterizer generation has neither anti-aliasing nor a 4th channel")
         if means3D.ndim != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:58-60
         self._check_device(means3D)
@@ -155,14 +159,17 @@ class RasterBackend:
         out_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
         out_invdepth = torch.zeros((1, H, W), **f32)
         radii = torch.zeros((P,), dtype=torch.int32, device=device)
-        out_extra = None if extra is None else torch.zeros((1, H, W), **f32)
-        tail = () if extra is None else (out_extra,)
+        out_extra = None if (extra is None and not fsgs) else torch.zeros((1, H, W), **f32)
+        tail = () if out_extra is None else (out_extra,)
         if P == 0:  # rasterize_points.cu:88
             e = torch.empty((0,), **u8)
             return (0, out_color, radii, e, e.clone(), e.clone(), out_invdepth) + tail
 
         def render(scratch):
-            if extra is None:
+            if fsgs:
+                self.api.call("forward_render_fsgs", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
+                              out_invdepth.data_ptr(), out_extra.data_ptr(), stream)
+            elif extra is None:
                 self.api.call("forward_render", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
                               out_invdepth.data_ptr(), stream)
             else:
@@ -228,11 +235,13 @@ class RasterBackend:
     def rasterize_gaussians_backward(self, bg, means3D, radii, colors_precomp, opacities, scales, rotations,
                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy,
                                      dL_dout_color, dL_dout_invdepth, sh, degree, campos, geomBuffer, R,
-                                     binningBuffer, imgBuffer, antialiasing, debug, extra=None, dL_dout_extra=None):
+                                     binningBuffer, imgBuffer, antialiasing, debug, extra=None, dL_dout_extra=None,
+                                     fsgs=False):
         """= RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-223).
 
         Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
-        dL_drotations) (+ dL_dextra [P] when the forward blended a 4th channel)."""
+        dL_drotations) (+ dL_dextra [P] when the forward blended a 4th channel).
+        fsgs=True: dL_dout_invdepth is the depth image gradient and dL_dout_extra the alpha image gradient."""
         self._check_device(means3D)
         device = means3D.device
         P = int(means3D.shape[0])
@@ -285,7 +294,17 @@ class RasterBackend:
         if g.scales is None:
             dL_dscales.zero_()
             dL_drotations.zero_()
-        if extra is None:
+        if fsgs:
+            zeros = None
+            if dL_dout_invdepth is None or _prep(dL_dout_extra, device) is None:
+                zeros = torch.zeros((1, H, W), **f32)
+            gd = dL_dout_invdepth if dL_dout_invdepth is not None else zeros
+            ga = _prep(dL_dout_extra, device)
+            ga = ga if ga is not None else zeros
+            self.api.call("backward_fsgs", C.byref(view), C.byref(g), radii.data_ptr(), C.byref(s), int(R),
+                          dL_dout_color.data_ptr(), gd.data_ptr(), ga.data_ptr(), C.byref(grads), _ptr(ws), ws.numel(),
+                          stream)
+        elif extra is None:
             self.api.call("backward", C.byref(view), C.byref(g), radii.data_ptr(), C.byref(s), int(R),
                           dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(grads), _ptr(ws), ws.numel(), stream)
         else:

@@ -176,6 +176,8 @@ def render(scene, cam, bg, antialiasing=False, want_invdepth=True):
     T_final = Tinc[:, -1] if alpha.shape[1] > 0 else torch.ones(alpha.shape[0], dtype=f64)
     color = w @ rgb[o] + T_final[:, None] * bg.to(f64)[None]
     invd = w @ (1.0 / tz[o])
+    depth = w @ tz[o]            # FSGS generation: sum depth alpha T (-confidence forward.cu:361)
+    alpha_img = w.sum(dim=1)     # ... and sum alpha T (:360)
     # n_contrib: 1-based position (within the tile's list = Gaussians whose rect holds the tile) of
     # the last blended Gaussian
     pos_in_tile = torch.cumsum(in_rect.to(torch.int64), dim=1)
@@ -183,4 +185,5 @@ def render(scene, cam, bg, antialiasing=False, want_invdepth=True):
     n_contrib = torch.where(blended, pos_in_tile, torch.zeros_like(pos_in_tile)).max(dim=1).values \
         if alpha.shape[1] > 0 else torch.zeros(alpha.shape[0], dtype=torch.int64)
     return dict(color=color.t().reshape(3, H, W), invdepth=invd.reshape(1, H, W), radii=radii,
+                depth=depth.reshape(1, H, W), alpha=alpha_img.reshape(1, H, W),
                 final_T=T_final.reshape(H, W), n_contrib=n_contrib.reshape(H, W), means2D=torch.stack([px, py], 1))

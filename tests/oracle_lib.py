@@ -50,6 +50,24 @@ class Oracle:
 
         self.Rasterizer = OracleRasterizer
         self.Settings = dgr.GaussianRasterizationSettings
+
+        # the FSGS rasterizer generation (dgr_fsgs) on the same checker
+        import dgr_fsgs
+        from dgr_fsgs._C import adapt_backward, adapt_forward
+
+        class _ImplFsgs:
+            rasterize_gaussians = staticmethod(lambda *a: adapt_forward(backend, a))
+            rasterize_gaussians_backward = staticmethod(lambda *a, opacities=None: adapt_backward(backend, a, opacities))
+            mark_visible = staticmethod(backend.mark_visible)
+
+        class _OracleFnFsgs(dgr_fsgs._RasterizeGaussians):
+            _impl = _ImplFsgs
+
+        class OracleRasterizerFsgs(dgr_fsgs.GaussianRasterizer):
+            _fn = _OracleFnFsgs
+
+        self.FsgsRasterizer = OracleRasterizerFsgs
+        self.FsgsSettings = dgr_fsgs.GaussianRasterizationSettings
         for name in ("gso_test_sh_fwd", "gso_test_sh_bwd", "gso_knn_mean_dist2_ex"):
             getattr(lib, name).restype = C.c_int
 

@@ -36,3 +36,22 @@ def test_duplicates_and_tiny_inputs(oracle):
     out2 = dist2(oracle.api, torch.tensor([[0.0, 0, 0], [1.0, 0, 0]]))
     assert torch.all(out2 > 1e30)
     assert dist2(oracle.api, torch.zeros((0, 3))).numel() == 0
+
+
+def test_fsgs_neighbour_indices_vs_brute_force(oracle):
+    """FSGS's distCUDA2 also returns the three neighbours (nearest first): checked against an exhaustive float64 search
+    on points without distance ties."""
+    import numpy as np
+    import torch
+    from gsplat_amd.knn import dist2, dist2_with_indices
+    rng = np.random.RandomState(12)
+    for P in (4, 50, 3000):
+        pts = torch.from_numpy(rng.uniform(-1.3, 1.3, (P, 3)).astype(np.float32))
+        d, idx = dist2_with_indices(oracle.api, pts)
+        assert idx.dtype == torch.int32 and idx.shape == (P, 3)
+        assert torch.equal(d, dist2(oracle.api, pts))  # same distances as the index-free entry point, bit for bit
+        D = torch.cdist(pts.double(), pts.double()) ** 2
+        D.fill_diagonal_(float("inf"))
+        want = torch.argsort(D, dim=1)[:, :3]
+        assert torch.equal(idx.long(), want)
+        assert torch.allclose(d.double(), torch.gather(D, 1, want).mean(dim=1), rtol=1e-5)
