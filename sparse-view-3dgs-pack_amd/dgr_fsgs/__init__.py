@@ -40,6 +40,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # (the reference does not keep `opacities`: its backward never reads them; this ABI validates the pointer)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer, alpha, opacities)
+        ctx.set_materialize_grads(False)
         return color, radii, depth, alpha
 
     @classmethod
@@ -47,6 +48,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer,
          alpha, opacities) = ctx.saved_tensors
+        if grad_color is None:
+            grad_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh,
                 rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug)

@@ -42,6 +42,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                               geomBuffer, binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
+        # The reference lets autograd materialise a zero gradient for an unused inverse-depth output, which keeps its
+        # depth branch alive in every backward (rasterize_points.cu:176-182).  A zero image gradient
+        # contributes exactly nothing, so here an unused output arrives as None and the backward kernel without
+        # that channel runs - same numbers, less work.
+        ctx.set_materialize_grads(False)
         return color, radii, invdepths
 
     @classmethod
@@ -50,6 +55,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer,
          binningBuffer, imgBuffer) = ctx.saved_tensors
+        if grad_out_color is None:  # only the inverse depth was used
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         args = (rs.bg, means3D, radii, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_depth, sh, rs.sh_degree, rs.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer,

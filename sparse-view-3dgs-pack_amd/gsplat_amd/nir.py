@@ -46,6 +46,7 @@ class _RasterizeGaussiansX(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                               geomBuffer, binningBuffer, imgBuffer, extra)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None (see diff_gaussian_rasterization)
         return color, radii, invdepths, extra_img
 
     @classmethod
@@ -53,6 +54,8 @@ class _RasterizeGaussiansX(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer,
          binningBuffer, imgBuffer, extra) = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         args = (rs.bg, means3D, radii, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer,
