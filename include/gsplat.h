@@ -315,6 +315,23 @@ int gs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
                  const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
                  void* stream);
 
+/* ---- per-Gaussian elementwise work of the train step outside the rasterizer ----
+ * Parameter activations of GaussianModel (LGDWT-GS/scene/gaussian_model.py:40-60,102-117): scales = exp(scaling),
+ * rotations = F.normalize(rotation) (eps 1e-12), opacities = sigmoid(opacity); all [P,k] contiguous fp32,
+ * rotation arrays 16-byte aligned.  One kernel instead of ~5 torch kernels. */
+int gs_activations_fwd(const float* scaling /*[P,3]*/, const float* rotation /*[P,4]*/,
+                       const float* opacity /*[P]*/, int32_t P, float* scales_out, float* rotations_out,
+                       float* opacities_out, void* stream);
+/* Their backward (the autograd formulas of exp / normalize / sigmoid), written (=) into d_*; one kernel. */
+int gs_activations_bwd(const float* scaling, const float* rotation, const float* opacity, int32_t P,
+                       const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
+                       float* d_scaling, float* d_rotation, float* d_opacity, void* stream);
+/* Densification statistics of one view (train.py:266-268, gaussian_model.py:471-473), for Gaussians with
+ * radii > 0: max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |dL_dmeans2D.xy|; denom += 1. */
+int gs_densify_stats(const int32_t* radii, const float* dL_dmeans2D /*[P,3]*/, int32_t P,
+                     float* max_radii2D /*[P]*/, float* xyz_gradient_accum /*[P]*/, float* denom /*[P]*/,
+                     void* stream);
+
 /* ---- optional per-stage timing (HIP events recorded on the caller's stream around every kernel
  * group).  Off by default.  bench.py enables it over the timed region to get each kernel's average
  * launch duration on the stream it is launched on.  (No reference counterpart: the reference only

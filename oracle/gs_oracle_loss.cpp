@@ -418,6 +418,64 @@ int gso_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
   return GS_OK;
 }
 
+/* ---- per-Gaussian elementwise work of the train step (restates LGDWT-GS/scene/gaussian_model.py:40-60,102-117
+ * activations with torch's autograd formulas, and train.py:266-268 + gaussian_model.py:471-473 statistics;
+ * pinned against torch itself in tests/test_model_ops.py) ---- */
+int gso_activations_fwd(const float* scaling, const float* rotation, const float* opacity, int32_t P, float* o_scales,
+                        float* o_rot, float* o_opac, void*) {
+  if (P < 0) return GS_E_SHAPE;
+  if (P == 0) return GS_OK;
+  if (!scaling || !rotation || !opacity || !o_scales || !o_rot || !o_opac) return GS_E_NULL;
+  for (int i = 0; i < P; i++) {
+    for (int k = 0; k < 3; k++) o_scales[3 * i + k] = expf(scaling[3 * i + k]);
+    const float* q = rotation + 4 * (size_t)i;
+    const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+    for (int k = 0; k < 4; k++) o_rot[4 * (size_t)i + k] = q[k] / n;
+    o_opac[i] = 1.0f / (1.0f + expf(-opacity[i]));
+  }
+  return GS_OK;
+}
+int gso_activations_bwd(const float* scaling, const float* rotation, const float* opacity, int32_t P, const float* g_scales,
+                        const float* g_rot, const float* g_opac, float* d_scaling, float* d_rotation, float* d_opacity,
+                        void*) {
+  if (P < 0) return GS_E_SHAPE;
+  if (P == 0) return GS_OK;
+  if (!scaling || !rotation || !opacity || !g_scales || !g_rot || !g_opac || !d_scaling || !d_rotation || !d_opacity)
+    return GS_E_NULL;
+  for (int i = 0; i < P; i++) {
+    for (int k = 0; k < 3; k++) d_scaling[3 * i + k] = g_scales[3 * i + k] * expf(scaling[3 * i + k]);
+    const float* q = rotation + 4 * (size_t)i;
+    const float* g = g_rot + 4 * (size_t)i;
+    float* d = d_rotation + 4 * (size_t)i;
+    const float norm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (norm > 1e-12f) {
+      const float inv = 1.0f / norm;
+      const float v[4] = {q[0] * inv, q[1] * inv, q[2] * inv, q[3] * inv};
+      const float dot = v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[3] * g[3];
+      for (int k = 0; k < 4; k++) d[k] = (g[k] - v[k] * dot) * inv;
+    } else {
+      for (int k = 0; k < 4; k++) d[k] = g[k] / 1e-12f;
+    }
+    const float s = 1.0f / (1.0f + expf(-opacity[i]));
+    d_opacity[i] = g_opac[i] * (1.0f - s) * s;
+  }
+  return GS_OK;
+}
+int gso_densify_stats(const int32_t* radii, const float* dL_dmeans2D, int32_t P, float* max_radii2D, float* accum,
+                      float* denom, void*) {
+  if (P < 0) return GS_E_SHAPE;
+  if (P == 0) return GS_OK;
+  if (!radii || !dL_dmeans2D || !max_radii2D || !accum || !denom) return GS_E_NULL;
+  for (int i = 0; i < P; i++)
+    if (radii[i] > 0) {
+      max_radii2D[i] = fmaxf(max_radii2D[i], (float)radii[i]);
+      const float gx = dL_dmeans2D[3 * i], gy = dL_dmeans2D[3 * i + 1];
+      accum[i] += sqrtf(gx * gx + gy * gy);
+      denom[i] += 1.0f;
+    }
+  return GS_OK;
+}
+
 /* ---- fused-criterion entry points (same arithmetic as the per-term functions above) ---- */
 int gso_l1_bwd_dev(const float* a, const float* b, int64_t n, const float* coef, float* g, int32_t accumulate, void*) {
   if (!a || !b || !g || !coef) return GS_E_NULL;

@@ -25,6 +25,7 @@ enum GsStage {
   ST_ELF,
   ST_DWT1,
   ST_ADAM,
+  ST_MODEL,
   ST_COUNT
 };
 

@@ -26,7 +26,7 @@ hipEvent_t get_event() {
     return e;
   }
   hipEvent_t e;
-  hipEventCreate(&e);
+  (void)hipEventCreate(&e);
   return e;
 }
 void drain_locked() {
@@ -46,7 +46,7 @@ void drain_locked() {
 void gs_prof_begin(int stage, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_mu);
   Rec r{stage, get_event(), get_event()};
-  hipEventRecord(r.a, s);
+  (void)hipEventRecord(r.a, s);
   g_open.push_back(r);
 }
 void gs_prof_end(int stage, hipStream_t s) {
@@ -55,7 +55,7 @@ void gs_prof_end(int stage, hipStream_t s) {
     if (g_open[i].stage == stage) {
       Rec r = g_open[i];
       g_open.erase(g_open.begin() + i);
-      hipEventRecord(r.b, s);
+      (void)hipEventRecord(r.b, s);
       g_done.push_back(r);
       if (g_done.size() > 4096) drain_locked();
       return;
@@ -64,7 +64,7 @@ void gs_prof_end(int stage, hipStream_t s) {
 
 static const char* kNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate", "sort_depth", "sort", "tile_ranges", "render_fwd",
                                        "bwd_memset", "render_bwd", "preprocess_bwd", "knn", "l1", "dwt2_l1_fwd",
-                                       "dwt2_l1_bwd", "ssim_fwd", "ssim_bwd", "patch_dwt", "elf_map", "dwt_haar", "adam"};
+                                       "dwt2_l1_bwd", "ssim_fwd", "ssim_bwd", "patch_dwt", "elf_map", "dwt_haar", "adam", "model_ops"};
 
 extern "C" {
 int gs_profile_enable(int32_t on) {

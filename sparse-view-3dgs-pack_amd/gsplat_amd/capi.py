@@ -128,6 +128,9 @@ PROTOTYPES = {
     "ssim_bwd_uniform": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "lgdwt_combine": (C.c_int, [_P, _P, C.POINTER(GsLgdwtParams), _P, _P]),
     "adam_step": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P]),
+    "activations_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P]),
+    "activations_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "densify_stats": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P]),
     "profile_enable": (C.c_int, [_I32]),
     "profile_reset": (C.c_int, []),
     "profile_stage_count": (C.c_int, []),

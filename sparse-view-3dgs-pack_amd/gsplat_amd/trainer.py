@@ -103,6 +103,43 @@ class FlatAdam:
         return out
 
 
+def _stream_of(t):
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else None
+
+
+class _FusedActivations(torch.autograd.Function):
+    """scales, rotations, opacities = exp(_scaling), normalize(_rotation), sigmoid(_opacity) in one kernel each way
+    (gs_activations_fwd / gs_activations_bwd); the backward writes straight into the model's flat gradient buffer
+    and hands those views to autograd, so nothing is copied afterwards."""
+
+    @staticmethod
+    def forward(ctx, scaling, rotation, opacity, model):
+        api = model.optimizer.api
+        P = scaling.shape[0]
+        scales, rots, opac = torch.empty_like(scaling), torch.empty_like(rotation), torch.empty_like(opacity)
+        api.call("activations_fwd", scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(), P, scales.data_ptr(),
+                 rots.data_ptr(), opac.data_ptr(), _stream_of(scaling))
+        ctx.model = model
+        ctx.save_for_backward(scaling, rotation, opacity)
+        ctx.set_materialize_grads(False)
+        return scales, rots, opac
+
+    @staticmethod
+    def backward(ctx, g_s, g_r, g_o):
+        scaling, rotation, opacity = ctx.saved_tensors
+        model = ctx.model
+        P = scaling.shape[0]
+        v = model.grad_views()
+        g_s = torch.zeros_like(scaling) if g_s is None else g_s.contiguous()
+        g_r = torch.zeros_like(rotation) if g_r is None else g_r.contiguous()
+        g_o = torch.zeros_like(opacity) if g_o is None else g_o.contiguous()
+        model.optimizer.api.call("activations_bwd", scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(), P,
+                                 g_s.data_ptr(), g_r.data_ptr(), g_o.data_ptr(), v["scaling"].data_ptr(),
+                                 v["rotation"].data_ptr(), v["opacity"].data_ptr(), _stream_of(scaling))
+        return v["scaling"], v["rotation"], v["opacity"], None
+
+
 class GaussianModelLite:
     """Raw (pre-activation) parameters of P Gaussians at max SH degree 3."""
 
@@ -363,6 +400,14 @@ class GaussianModelLite:
     def get_features(self):
         return self.params["features"]
 
+    def fused_activations(self):
+        """(scales, rotations, opacities) through the fused kernels, or None when the model has no C-ABI optimizer
+        (then the caller uses the get_* properties)."""
+        api = getattr(self.optimizer, "api", None)
+        if api is None or not hasattr(api, "_activations_fwd"):
+            return None
+        return _FusedActivations.apply(self.params["scaling"], self.params["rotation"], self.params["opacity"], self)
+
     def zero_grad(self):
         """set_to_none, as the reference does (train.py:283-288): autograd then ASSIGNS the new gradients
         instead of adding them to a zeroed buffer (no 236 B/Gaussian memset, no read-modify-write)."""
@@ -395,6 +440,17 @@ class GaussianModelLite:
             elif g.data_ptr() != view.data_ptr():
                 view.copy_(g)
             p.grad = view
+
+    def update_view_statistics(self, radii, viewspace_grad):
+        """train.py:266-268 + add_densification_stats in one kernel (gs_densify_stats) when available."""
+        api = getattr(self.optimizer, "api", None)
+        if api is not None and hasattr(api, "_densify_stats") and viewspace_grad is not None and viewspace_grad.is_contiguous():
+            api.call("densify_stats", radii.data_ptr(), viewspace_grad.data_ptr(), self.P, self.max_radii2D.data_ptr(),
+                     self.xyz_gradient_accum.data_ptr(), self.denom.data_ptr(), _stream_of(radii))
+            return
+        # train.py:268 (radii are 0 for culled Gaussians, so a plain maximum equals the masked update)
+        torch.maximum(self.max_radii2D, radii.to(torch.float32), out=self.max_radii2D)
+        self.add_densification_stats(viewspace_grad, radii > 0)
 
     def add_densification_stats(self, viewspace_grad, visible_mask):
         # gaussian_model.py:471-473, written without boolean indexing (no host sync); rows of culled
@@ -431,14 +487,20 @@ class _TorchAdamWithFeatureSplit:
 
 
 def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifier=1.0, antialiasing=False,
-           debug=False, filter_as_indices=True, clamp=True):
+           debug=False, filter_as_indices=True, clamp=True, fused=False):
     """= render() of LGDWT-GS/gaussian_renderer/__init__.py:18-128 (SH evaluated by the rasterizer, scale +
     rotation given, no exposure): returns {render, viewspace_points, visibility_filter, radii, depth}."""
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    act = pc.fused_activations() if fused else None
+    if act is None:
+        screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+        act = (pc.get_scaling, pc.get_rotation, pc.get_opacity)
+    else:  # the step loop's lean form: a zero leaf carries the view-space gradient (no `+ 0` copy, one fill)
+        screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    scales, rotations, opacities = act
     rs = Settings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
@@ -448,7 +510,7 @@ def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifie
     rasterizer = Rasterizer(raster_settings=rs)
     rendered_image, radii, depth_image = rasterizer(
         means3D=pc.get_xyz, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None,
-        opacities=pc.get_opacity, scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
+        opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=None)
     if clamp:  # gaussian_renderer/__init__.py:119; the fused criterion applies (and differentiates) it itself
         rendered_image = rendered_image.clamp(0, 1)
     return {"render": rendered_image, "viewspace_points": screenspace_points,
@@ -567,7 +629,7 @@ class Trainer:
             m.arm_grad_arena(backend)
         fused = getattr(self.criterion, "fused", False)
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=False,
-                     clamp=not fused)
+                     clamp=not fused, fused=True)
         mask = None if self.masks is None else self.masks[ci]
         if fused:
             loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
@@ -577,9 +639,7 @@ class Trainer:
         radii = pkg["radii"]
         with torch.no_grad():
             m.collect_grads()
-            # train.py:268 (radii are 0 for culled Gaussians, so a plain maximum equals the masked update)
-            torch.maximum(m.max_radii2D, radii.to(torch.float32), out=m.max_radii2D)
-            m.add_densification_stats(pkg["viewspace_points"].grad, pkg["visibility_filter"])
+            m.update_view_statistics(radii, pkg["viewspace_points"].grad)
             if self.world_size > 1:
                 self.all_reduce()
             if optimizer_step:
