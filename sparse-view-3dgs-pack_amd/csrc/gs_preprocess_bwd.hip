@@ -20,9 +20,21 @@ struct ShRegsB {
   __device__ __forceinline__ V3 operator()(int k) const { return {f[3 * k], f[3 * k + 1], f[3 * k + 2]}; }
 };
 
-// backward.cu:23-142.  Writes dL_dsh rows into out[48] (registers) and returns dL_dmean.
+// Where sh_backward puts row k of dL_dsh: an LDS row (M == 16, leaves coalesced) or the global row itself.  (A
+// register array here ends up in scratch memory - the generic-M path indexes it dynamically - which showed up as
+// 384 B per Gaussian of extra HBM write traffic in the WRITE_SIZE counter.)
+struct ShSink {
+  float* p;
+  __device__ __forceinline__ void set(int k, V3 v) const {
+    p[3 * k] = v.x;
+    p[3 * k + 1] = v.y;
+    p[3 * k + 2] = v.z;
+  }
+};
+
+// backward.cu:23-142.  Writes the dL_dsh rows it computes through `dsh` and returns dL_dmean.
 template <typename SH>
-GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped, V3 dL_dRGB, V3* dsh /*[16]*/) {
+GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped, V3 dL_dRGB, const ShSink& dsh) {
   V3 dir_orig = pos - campos;
   V3 dir = dir_orig / length3(dir_orig);
   dL_dRGB.x *= (clamped & 1u) ? 0 : 1;
@@ -31,14 +43,14 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
   V3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
   float x = dir.x, y = dir.y, z = dir.z;
   float dRGBdsh0 = SH_C0;
-  dsh[0] = dRGBdsh0 * dL_dRGB;
+  dsh.set(0, dRGBdsh0 * dL_dRGB);
   if (deg > 0) {
     float dRGBdsh1 = -SH_C1 * y;
     float dRGBdsh2 = SH_C1 * z;
     float dRGBdsh3 = -SH_C1 * x;
-    dsh[1] = dRGBdsh1 * dL_dRGB;
-    dsh[2] = dRGBdsh2 * dL_dRGB;
-    dsh[3] = dRGBdsh3 * dL_dRGB;
+    dsh.set(1, dRGBdsh1 * dL_dRGB);
+    dsh.set(2, dRGBdsh2 * dL_dRGB);
+    dsh.set(3, dRGBdsh3 * dL_dRGB);
     dRGBdx = -SH_C1 * sh(3);
     dRGBdy = -SH_C1 * sh(1);
     dRGBdz = SH_C1 * sh(2);
@@ -50,11 +62,11 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
       float dRGBdsh6 = SH_C2_2 * (2.f * zz - xx - yy);
       float dRGBdsh7 = SH_C2_3 * xz;
       float dRGBdsh8 = SH_C2_4 * (xx - yy);
-      dsh[4] = dRGBdsh4 * dL_dRGB;
-      dsh[5] = dRGBdsh5 * dL_dRGB;
-      dsh[6] = dRGBdsh6 * dL_dRGB;
-      dsh[7] = dRGBdsh7 * dL_dRGB;
-      dsh[8] = dRGBdsh8 * dL_dRGB;
+      dsh.set(4, dRGBdsh4 * dL_dRGB);
+      dsh.set(5, dRGBdsh5 * dL_dRGB);
+      dsh.set(6, dRGBdsh6 * dL_dRGB);
+      dsh.set(7, dRGBdsh7 * dL_dRGB);
+      dsh.set(8, dRGBdsh8 * dL_dRGB);
       dRGBdx = dRGBdx + (SH_C2_0 * y * sh(4) + SH_C2_2 * 2.f * -x * sh(6) + SH_C2_3 * z * sh(7) + SH_C2_4 * 2.f * x * sh(8));
       dRGBdy = dRGBdy + (SH_C2_0 * x * sh(4) + SH_C2_1 * z * sh(5) + SH_C2_2 * 2.f * -y * sh(6) + SH_C2_4 * 2.f * -y * sh(8));
       dRGBdz = dRGBdz + (SH_C2_1 * y * sh(5) + SH_C2_2 * 2.f * 2.f * z * sh(6) + SH_C2_3 * x * sh(7));
@@ -66,13 +78,13 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
         float dRGBdsh13 = SH_C3_4 * x * (4.f * zz - xx - yy);
         float dRGBdsh14 = SH_C3_5 * z * (xx - yy);
         float dRGBdsh15 = SH_C3_6 * x * (xx - 3.f * yy);
-        dsh[9] = dRGBdsh9 * dL_dRGB;
-        dsh[10] = dRGBdsh10 * dL_dRGB;
-        dsh[11] = dRGBdsh11 * dL_dRGB;
-        dsh[12] = dRGBdsh12 * dL_dRGB;
-        dsh[13] = dRGBdsh13 * dL_dRGB;
-        dsh[14] = dRGBdsh14 * dL_dRGB;
-        dsh[15] = dRGBdsh15 * dL_dRGB;
+        dsh.set(9, dRGBdsh9 * dL_dRGB);
+        dsh.set(10, dRGBdsh10 * dL_dRGB);
+        dsh.set(11, dRGBdsh11 * dL_dRGB);
+        dsh.set(12, dRGBdsh12 * dL_dRGB);
+        dsh.set(13, dRGBdsh13 * dL_dRGB);
+        dsh.set(14, dRGBdsh14 * dL_dRGB);
+        dsh.set(15, dRGBdsh15 * dL_dRGB);
         dRGBdx = dRGBdx + (SH_C3_0 * sh(9) * 3.f * 2.f * xy + SH_C3_1 * sh(10) * yz + SH_C3_2 * sh(11) * -2.f * xy +
                            SH_C3_3 * sh(12) * -3.f * 2.f * xz + SH_C3_4 * sh(13) * (-3.f * xx + 4.f * zz - yy) +
                            SH_C3_5 * sh(14) * 2.f * xz + SH_C3_6 * sh(15) * 3.f * (xx - yy));
@@ -90,8 +102,13 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
 }
 
 __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdArgs a) {
-  const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
-  if (idx >= a.P) return;
+  // dL_dsh rows (192 B per Gaussian) leave through LDS so that every store instruction of a wave covers 1 KiB of
+  // consecutive addresses; written per lane (12 x 16 B at a 192-B stride) the same bytes cost 2.3x the HBM write
+  // traffic (rocprofv3 WRITE_SIZE, profiles/).  Row stride 49 words: conflict-free per-lane writes.
+  __shared__ float s_sh[GS_BLOCK * 49];
+  const int idx_raw = blockIdx.x * GS_BLOCK + threadIdx.x;
+  const bool in_range = idx_raw < a.P;
+  const int idx = in_range ? idx_raw : a.P - 1;  // out-of-range lanes shadow the last Gaussian and store nothing
   const bool visible = a.radii[idx] > 0;
 
   V3 dL_dmean = {0, 0, 0};
@@ -101,9 +118,14 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
   V3 dL_dcolor = {0, 0, 0};
   V3 dL_dscale = {0, 0, 0};
   float dL_dq[4] = {0, 0, 0, 0};
-  V3 dsh[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) dsh[k] = {0.f, 0.f, 0.f};
+  // dL_dsh sink: zero row first (culled Gaussians and coefficients above the active degree stay 0)
+  const bool sh_lds = a.shs && a.out.dL_dsh && a.M == 16;
+  const bool sh_global = a.shs && a.out.dL_dsh && !sh_lds && in_range;  // generic M: straight to the global row
+  ShSink dsh{sh_global ? a.out.dL_dsh + (size_t)idx * a.M * 3 : s_sh + threadIdx.x * 49};
+  {
+    const int nfl_row = sh_global ? a.M * 3 : 48;
+    for (int k = 0; k < nfl_row; k++) dsh.p[k] = 0.f;
+  }
 
   if (visible) {
     const float4* gr = reinterpret_cast<const float4*>(a.grad_rows + (size_t)idx * GR_STRIDE);
@@ -287,6 +309,18 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
 
   // ---- write every row (zeros when culled)
   const GsGrads& o = a.out;
+  if (sh_lds) {
+    __syncthreads();
+    const int first = blockIdx.x * GS_BLOCK;
+    const int nfl = min(GS_BLOCK, a.P - first) * 48;  // floats this workgroup owns, a multiple of 4
+    float* dst = o.dL_dsh + (size_t)first * 48;
+    for (int j = 4 * threadIdx.x; j < nfl; j += 4 * GS_BLOCK) {
+      const int r = j / 48, c = j - r * 48;  // c is a multiple of 4: the four floats are in one row
+      const float* src = s_sh + r * 49 + c;
+      *reinterpret_cast<float4*>(dst + j) = make_float4(src[0], src[1], src[2], src[3]);
+    }
+  }
+  if (!in_range) return;
   if (o.dL_dmeans3D) {
     o.dL_dmeans3D[3 * idx] = dL_dmean.x;
     o.dL_dmeans3D[3 * idx + 1] = dL_dmean.y;
@@ -317,20 +351,6 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
       o.dL_dscales[3 * idx + 2] = dL_dscale.z;
     }
     if (o.dL_drotations) reinterpret_cast<float4*>(o.dL_drotations)[idx] = make_float4(dL_dq[0], dL_dq[1], dL_dq[2], dL_dq[3]);
-  }
-  if (a.shs && o.dL_dsh) {
-    if (a.M == 16) {
-      float4* dst = reinterpret_cast<float4*>(o.dL_dsh + (size_t)idx * 48);
-      const float* f = reinterpret_cast<const float*>(dsh);
-#pragma unroll
-      for (int k = 0; k < 12; k++) dst[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
-    } else {
-      float* dst = o.dL_dsh + (size_t)idx * a.M * 3;
-      for (int k = 0; k < a.M; k++) {
-        V3 v = k < 16 ? dsh[k] : V3{0.f, 0.f, 0.f};
-        dst[3 * k] = v.x; dst[3 * k + 1] = v.y; dst[3 * k + 2] = v.z;
-      }
-    }
   }
 }
 

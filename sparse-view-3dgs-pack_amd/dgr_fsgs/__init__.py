@@ -56,8 +56,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = cls._impl.rasterize_gaussians_backward(*args, opacities=opacities)
         c = rs.confidence
-        return (grad_means3D * c, grad_means2D, grad_sh * c[..., None], grad_colors_precomp * c, grad_opacities * c,
-                grad_scales * c, grad_rotations * c, grad_cov3Ds_precomp * c, None)
+
+        def scaled(g, w):  # gradients of absent inputs (None) stay None
+            return None if g is None or g.numel() == 0 else g * w
+        return (scaled(grad_means3D, c), grad_means2D, scaled(grad_sh, c[..., None]), scaled(grad_colors_precomp, c),
+                scaled(grad_opacities, c), scaled(grad_scales, c), scaled(grad_rotations, c),
+                scaled(grad_cov3Ds_precomp, c), None)
 
 
 class GaussianRasterizationSettings(NamedTuple):

@@ -260,9 +260,13 @@ class RasterBackend:
             return alloc(shape, **f32)
         dL_dmeans3D = out("means3D", (P, 3))
         dL_dmeans2D = alloc((P, 3), **f32)
-        dL_dcolors = alloc((P, NUM_CHANNELS), **f32)
+        # gradients of inputs that were not given ("absent" colours / covariances) are not produced: the reference
+        # returns zero tensors for them (rasterize_points.cu:163-178) which autograd then drops
+        has_colors = colors_precomp is not None and colors_precomp.numel() != 0
+        has_cov = cov3D_precomp is not None and cov3D_precomp.numel() != 0
+        dL_dcolors = alloc((P, NUM_CHANNELS), **f32) if has_colors else None
         dL_dopacity = alloc((P, 1), **f32)
-        dL_dcov3D = alloc((P, 6), **f32)
+        dL_dcov3D = alloc((P, 6), **f32) if has_cov else None
         dL_dsh = out("sh", (P, M, 3))
         dL_dscales = alloc((P, 3), **f32)
         dL_drotations = alloc((P, 4), **f32)
@@ -288,9 +292,9 @@ class RasterBackend:
         grads = GsGrads()
         grads.dL_dmeans3D, grads.dL_dmeans2D = dL_dmeans3D.data_ptr(), dL_dmeans2D.data_ptr()
         grads.dL_dsh = _ptr(dL_dsh)
-        grads.dL_dcolors, grads.dL_dopacity = dL_dcolors.data_ptr(), dL_dopacity.data_ptr()
+        grads.dL_dcolors, grads.dL_dopacity = _ptr(dL_dcolors), dL_dopacity.data_ptr()
         grads.dL_dscales, grads.dL_drotations = dL_dscales.data_ptr(), dL_drotations.data_ptr()
-        grads.dL_dcov3D = dL_dcov3D.data_ptr()
+        grads.dL_dcov3D = _ptr(dL_dcov3D)
         if g.scales is None:
             dL_dscales.zero_()
             dL_drotations.zero_()
