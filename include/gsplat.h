@@ -337,6 +337,9 @@ int gs_densify_stats(const int32_t* radii, const float* dL_dmeans2D /*[P,3]*/, i
  * launch duration on the stream it is launched on.  (No reference counterpart: the reference only
  * brackets whole iterations with a torch.cuda.Event pair, LGDWT-GS/train.py:65-66,97,220.) ---- */
 int gs_profile_enable(int32_t on);
+/* Restrict the timers to one stage (index as in gs_profile_stage_name; < 0 = all stages again).  Every recorded
+ * event pair drains the pipeline for ~10 us, so a throughput measurement keeps only the kernel it reports on. */
+int gs_profile_only(int32_t stage);
 int gs_profile_reset(void);
 int gs_profile_stage_count(void);
 const char* gs_profile_stage_name(int32_t stage);

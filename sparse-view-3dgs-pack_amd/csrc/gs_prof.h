@@ -32,12 +32,14 @@ enum GsStage {
 void gs_prof_begin(int stage, hipStream_t s);
 void gs_prof_end(int stage, hipStream_t s);
 extern int g_gs_prof_on;
+extern int g_gs_prof_only;
 
 struct GsProfScope {
   int stage;
   hipStream_t s;
   bool on;
-  GsProfScope(int st, hipStream_t str) : stage(st), s(str), on(g_gs_prof_on != 0) {
+  GsProfScope(int st, hipStream_t str)
+      : stage(st), s(str), on(g_gs_prof_on != 0 && (g_gs_prof_only < 0 || g_gs_prof_only == st)) {
     // every kernel group of the library is bracketed by one of these scopes: drop any stale error another
     // runtime user of this thread left behind, so that the launch check that follows reports OUR launches only
     (void)hipGetLastError();

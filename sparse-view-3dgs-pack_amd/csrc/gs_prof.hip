@@ -6,6 +6,7 @@
 #include "gs_prof.h"
 
 int g_gs_prof_on = 0;
+int g_gs_prof_only = -1;  // >= 0: record this stage only (an event pair costs ~10 us of drained pipeline per stage)
 
 namespace {
 struct Rec {
@@ -70,6 +71,12 @@ extern "C" {
 int gs_profile_enable(int32_t on) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_gs_prof_on = on ? 1 : 0;
+  return GS_OK;
+}
+int gs_profile_only(int32_t stage) {
+  if (stage >= ST_COUNT) return GS_E_SHAPE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_gs_prof_only = stage < 0 ? -1 : stage;
   return GS_OK;
 }
 int gs_profile_reset(void) {

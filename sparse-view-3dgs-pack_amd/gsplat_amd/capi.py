@@ -132,6 +132,7 @@ PROTOTYPES = {
     "activations_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "densify_stats": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P]),
     "profile_enable": (C.c_int, [_I32]),
+    "profile_only": (C.c_int, [_I32]),
     "profile_reset": (C.c_int, []),
     "profile_stage_count": (C.c_int, []),
     "profile_stage_name": (C.c_char_p, [_I32]),
@@ -141,7 +142,7 @@ PROTOTYPES = {
 # entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
 # (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
 # reference's two 3-channel passes, so the checker does not need it)
-DEVICE_ONLY = ("profile_enable", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
+DEVICE_ONLY = ("profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
                "forward_render_x", "backward_x")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}
