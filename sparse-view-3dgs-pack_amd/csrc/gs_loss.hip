@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(GS_BLOCK) patch_dwt_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------------ SSIM
 // 32x32 output tile per 256-thread workgroup; 42x42 input halo tile in LDS, horizontal pass to LDS,
-// vertical pass from LDS.  fused-ssim/ssim.cu:9-19:
+// vertical pass from LDS (both register-blocked, see ssim_conv_tile).  fused-ssim/ssim.cu:9-19:
 __constant__ float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f,
                              0.10936068743467331f,  0.21300552785396576f,  0.26601171493530273f,
                              0.21300552785396576f,  0.10936068743467331f,  0.036000773310661316f,
@@ -339,31 +339,66 @@ __constant__ float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.03
 #define ST 32
 #define SH (ST + 10)
 
-template <int NQ>
-__device__ __forceinline__ void ssim_conv_tile(float (*tile)[SH][SH + 1], float (*hor)[SH][ST + 1], float (&out)[4][NQ]) {
-  // horizontal: SH rows x ST cols, NQ quantities
-  for (int k = threadIdx.x; k < SH * ST; k += GS_BLOCK) {
-    const int r = k / ST, c = k % ST;
+#define HS 40  // row stride of the horizontal-pass buffer: 4 rows apart = 160 words = 32 banks, so the two half-waves
+               // of the vertical pass (rows 4 ly0 .. and 4 (ly0 + 1) ..) read disjoint halves of the 64 banks
+
+// Separable 11-tap convolution of NQ quantities over the 42x42 halo tile.  Register-blocked: a thread produces 4
+// adjacent outputs along the pass direction from 14 inputs (sliding window), i.e. 3.5 LDS reads per output and
+// quantity instead of 11; in the forward the five quantities (a, a^2, b, b^2, ab) are formed from the two image
+// planes on the fly, so only those two are staged.  Every output is still the sum over t = 0..10 in ascending
+// order (the order of fused-ssim/ssim.cu:60-100 and of the checker).  out[j] belongs to tile row 4 * (tid / 32) + j,
+// column tid % 32.
+template <int NQ, bool FWD>
+__device__ __forceinline__ void ssim_conv_tile(const float (*tile)[SH][SH + 1], float (*hor)[SH][HS], float (&out)[4][NQ]) {
+  for (int item = threadIdx.x; item < SH * (ST / 4); item += GS_BLOCK) {
+    const int r = item / (ST / 4), c0 = (item % (ST / 4)) * 4;
+    float acc[4][NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      float v = 0.f;
+    for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int t = 0; t < 11; t++) v += GW[t] * tile[q][r][c + t];
-      hor[q][r][c] = v;
+      for (int q = 0; q < NQ; q++) acc[j][q] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 14; e++) {
+      float val[NQ];
+      if (FWD) {
+        const float a = tile[0][r][c0 + e], b = tile[1][r][c0 + e];
+        val[0] = a; val[1] = a * a; val[2] = b; val[3 % NQ] = b * b; val[4 % NQ] = a * b;
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) val[q] = tile[q][r][c0 + e];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int t = e - j;
+        if (t >= 0 && t < 11) {
+#pragma unroll
+          for (int q = 0; q < NQ; q++) acc[j][q] += GW[t] * val[q];
+        }
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < NQ; q++) hor[q][r][c0 + j] = acc[j][q];
   }
   __syncthreads();
-  // vertical: each thread 4 output rows (ly = threadIdx.x/32 + 8*m), column threadIdx.x % 32
-  const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
+  const int lx = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
-    const int ly = ly0 + 8 * m;
+  for (int j = 0; j < 4; j++)
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      float v = 0.f;
+    for (int q = 0; q < NQ; q++) out[j][q] = 0.f;
 #pragma unroll
-      for (int t = 0; t < 11; t++) v += GW[t] * hor[q][ly + t][lx];
-      out[m][q] = v;
+  for (int e = 0; e < 14; e++) {
+    float val[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) val[q] = hor[q][r0 + e][lx];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int t = e - j;
+      if (t >= 0 && t < 11) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) out[j][q] += GW[t] * val[q];
+      }
     }
   }
 }
@@ -372,8 +407,8 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
                                                             int H, int W, float C1, float C2, float* __restrict__ ssim_map,
                                                             float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
                                                             float* __restrict__ dm_dsigma12, float* sum_out) {
-  __shared__ float tile[5][SH][SH + 1];
-  __shared__ float hor[5][SH][ST + 1];
+  __shared__ float tile[2][SH][SH + 1];
+  __shared__ float hor[5][SH][HS];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
   for (int k = threadIdx.x; k < SH * SH; k += GS_BLOCK) {
@@ -385,19 +420,16 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
       b = img2[plane + (size_t)y * W + x];
     }
     tile[0][r][c] = a;
-    tile[1][r][c] = a * a;
-    tile[2][r][c] = b;
-    tile[3][r][c] = b * b;
-    tile[4][r][c] = a * b;
+    tile[1][r][c] = b;
   }
   __syncthreads();
   float out[4][5];
-  ssim_conv_tile<5>(tile, hor, out);
+  ssim_conv_tile<5, true>(tile, hor, out);
   const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
   float msum = 0.f;
 #pragma unroll
   for (int m = 0; m < 4; m++) {
-    const int x = bx + lx, y = by + ly0 + 8 * m;
+    const int x = bx + lx, y = by + 4 * ly0 + m;
     if (x >= W || y >= H) continue;
     const float mu1 = out[m][0], mu2 = out[m][2];
     const float sigma1_sq = out[m][1] - mu1 * mu1;
@@ -435,7 +467,7 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
                                                             int accumulate, const float* __restrict__ clamp_src) {
   __shared__ float tile[3][SH][SH + 1];
   const float gu = coef_dev ? coef_dev[0] : 0.f;  // uniform dL/dssim_map (mean reduction upstream)
-  __shared__ float hor[3][SH][ST + 1];
+  __shared__ float hor[3][SH][HS];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
   for (int k = threadIdx.x; k < SH * SH; k += GS_BLOCK) {
@@ -455,11 +487,11 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
   }
   __syncthreads();
   float out[4][3];
-  ssim_conv_tile<3>(tile, hor, out);
+  ssim_conv_tile<3, false>(tile, hor, out);
   const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
 #pragma unroll
   for (int m = 0; m < 4; m++) {
-    const int x = bx + lx, y = by + ly0 + 8 * m;
+    const int x = bx + lx, y = by + 4 * ly0 + m;
     if (x >= W || y >= H) continue;
     const size_t o = plane + (size_t)y * W + x;
     float dL = 0.0f;
