@@ -227,13 +227,16 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
       const float s5 = HAS_EXTRA ? swap32_add(v_x, 0.f) : 0.f;                  // (10|-)
       const float t2 = row_total_in_lane15(swap16_add(s4, s5));                 // rows: 8 10 9 -
       if ((lane & 15) == 15) {
+        // (no "!= 0" tests: an entry that reaches this point has a touched pixel, its sums are non-zero in practice
+        // and three exec-mask regions cost more than the rare zero add)
         float* row = grad_rows + (size_t)s_id[j] * GR_STRIDE;
         const int q = lane >> 4;
-        if (t0 != 0.0f) atomicAdd(row + q, t0 * rowscale0);      // mean2D.x, mean2D.y, conic.xx, conic.xy
-        if (t1 != 0.0f) atomicAdd(row + 4 + q, t1 * rowscale1);  // conic.yy, opacity, colour r, g
-        // colour b (row 0 -> slot 8), 4th channel (row 1 -> slot 10), inverse depth (row 2 -> slot 9)
+        atomicAdd(row + q, t0 * rowscale0);      // mean2D.x, mean2D.y, conic.xx, conic.xy
+        atomicAdd(row + 4 + q, t1 * rowscale1);  // conic.yy, opacity, colour r, g
+        // colour b (row 0 -> slot 8), 4th channel (row 1 -> slot 10), inverse depth (row 2 -> slot 9); rows without a
+        // value add their 0 to the padding slot 11 so that the instruction keeps one lane-dependent address form
         const bool live2 = q == 0 || (HAS_EXTRA && !FSGS && q == 1) || (HAS_INVDEPTH && q == 2);
-        if (live2 && t2 != 0.0f) atomicAdd(row + (q == 0 ? GR_CB : (q == 1 ? GR_EXTRA : GR_ID)), t2);
+        atomicAdd(row + (q == 0 ? GR_CB : (q == 1 ? GR_EXTRA : (q == 2 ? GR_ID : GR_N))), live2 ? t2 : 0.0f);
       }
     }
   }
