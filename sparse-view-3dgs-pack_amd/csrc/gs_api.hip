@@ -192,7 +192,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
                         out_invdepth, s);
     else
       launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
-                             out_invdepth, out_extra, fsgs, s);
+                             out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;

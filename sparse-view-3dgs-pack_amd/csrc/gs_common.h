@@ -221,7 +221,7 @@ int launch_render_bwd(const uint2* ranges, const uint32_t* point_list, int W, in
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                           float* out_invdepth, float* out_extra, int fsgs, hipStream_t s);
+                           float* out_invdepth, float* out_extra, int fsgs, int cull, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                            const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs,

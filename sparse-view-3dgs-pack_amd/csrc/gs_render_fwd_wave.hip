@@ -16,7 +16,9 @@
 // transmittance PRODUCT: that generation's backward reads T_final back as 1 - alpha (backward.cu:461), which on
 // saturated pixels (T ~ 1e-4) keeps only ~3 digits of T and puts ~1e-3 of fp32 noise on its gradients; the product
 // is the same quantity without the cancellation (tests/test_gpu_fsgs.py compares against both forms).
-template <bool HAS_EXTRA, bool FSGS>
+// CULL: per-entry ellipse-extent test against the tile (for the reference's bounding-square lists); with the
+// culled lists of gs_tilecull.h every entry already passed a tighter test at emission time.
+template <bool HAS_EXTRA, bool FSGS, bool CULL>
 __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list, int W, int H,
                                                              int grid_x, const Splat* __restrict__ splat,
@@ -66,7 +68,9 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     __syncthreads();  // single wave: previous batch fully consumed
     s_a[lane] = make_float4(ra.x, ra.y, FSGS ? ra.z : ra.w, 0.f);
     s_c[lane] = blend_stage_conic(rc);  // (qa, qb, qc, opacity), see gs_blend.h
-    {
+    if (!CULL) {
+      s_k[lane] = rk;
+    } else {
       // Exact-safe tile cull: alpha >= 1/255 needs power >= -L with L = ln(255 * opacity); the set
       // {d : d^T Q d <= 2L} is an ellipse whose half-extent along x is sqrt(2 L Sigma_xx), Sigma = Q^-1
       // (Sigma_xx = Q_yy / det Q).  A tile whose pixel range lies beyond that extent (+2 % and one pixel of
@@ -79,8 +83,8 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       const float ey = ok ? sqrtf(L2 * rc.x / det) * 1.02f + 1.0f : (L2 >= 0.f ? 3.0e38f : -1.0f);
       s_k[lane] = make_float4(rk.x, rk.y, rk.z, ex);
       s_a[lane].w = ey;
-      if (HAS_EXTRA) s_e[lane] = rk.w;
     }
+    if (HAS_EXTRA) s_e[lane] = rk.w;
     __syncthreads();
     {
       const int nxt = (i + 1) * WB + lane;
@@ -94,7 +98,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       const uint32_t contributor = (uint32_t)(i * WB + j + 1);
       const float4 a = s_a[j];
       const float4 k = s_k[j];
-      {  // wave-uniform: distance from the centre to the tile's pixel range, per axis
+      if (CULL) {  // wave-uniform: distance from the centre to the tile's pixel range, per axis
         const float ddx = fmaxf(fmaxf(tile_fx0 - a.x, a.x - (tile_fx0 + 15.0f)), 0.f);
         const float ddy = fmaxf(fmaxf(tile_fy0 - a.y, a.y - (tile_fy0 + 15.0f)), 0.f);
         if (ddx > k.w || ddy > a.w) continue;
@@ -156,15 +160,17 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                           float* out_invdepth, float* out_extra, int fsgs, hipStream_t s) {
-  if (fsgs)
-    hipLaunchKernelGGL((render_fwd_wave_kernel<false, true>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H,
-                       grid_x, splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
-  else if (out_extra)
-    hipLaunchKernelGGL((render_fwd_wave_kernel<true, false>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H,
-                       grid_x, splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
-  else
-    hipLaunchKernelGGL((render_fwd_wave_kernel<false, false>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H,
-                       grid_x, splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra);
+                           float* out_invdepth, float* out_extra, int fsgs, int cull, hipStream_t s) {
+#define GS_FWD_WAVE(EX, FS, CU)                                                                                          \
+  hipLaunchKernelGGL((render_fwd_wave_kernel<EX, FS, CU>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, \
+                     grid_x, splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra)
+  if (fsgs) {
+    if (cull) GS_FWD_WAVE(false, true, true); else GS_FWD_WAVE(false, true, false);
+  } else if (out_extra) {
+    if (cull) GS_FWD_WAVE(true, false, true); else GS_FWD_WAVE(true, false, false);
+  } else {
+    if (cull) GS_FWD_WAVE(false, false, true); else GS_FWD_WAVE(false, false, false);
+  }
+#undef GS_FWD_WAVE
   return 0;
 }
