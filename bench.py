@@ -265,7 +265,7 @@ def main():
                        "scene": "trained-like (SURVEY 8d), seed 0", "cameras_per_step": world,
                        "num_rendered_last_view": R_last, "loss": "L1+SSIM" + ("+DWT2" if dwt else "") +
                        ("+patchDWT" if patch else ""), "optimizer": "Adam eps 1e-15, fused HIP kernel over the flat buffer",
-                       "parallelism": "camera-sharded dp%d, one all-reduce of 59 f32/Gaussian" % world},
+                       "parallelism": "camera-sharded dp%d, one all-reduce of 61 f32/Gaussian (59 gradients + 2 statistic increments)" % world},
             "roofline": roofline,
             "stages": stages,
             "stages_note": "HIP events; %s measured inside the timed region, the other stages in a separate untimed "

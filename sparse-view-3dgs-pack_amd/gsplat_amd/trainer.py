@@ -184,7 +184,11 @@ class GaussianModelLite:
         """(Re)create the flat parameter / gradient buffers for P Gaussians and the views into them."""
         self.P = P
         self.flat = torch.zeros((P * FLOATS_PER_GAUSSIAN,), dtype=torch.float32, device=self.device)
-        self.flat_grad = torch.zeros_like(self.flat)
+        # gradient buffer + a [2, P] tail for this step's densification-statistic increments: the data-parallel
+        # exchange is then ONE all-reduce (SUM) over gradients and increments together
+        self.exchange = torch.zeros((P * (FLOATS_PER_GAUSSIAN + 2),), dtype=torch.float32, device=self.device)
+        self.flat_grad = self.exchange[:P * FLOATS_PER_GAUSSIAN]
+        self.stat_delta = self.exchange[P * FLOATS_PER_GAUSSIAN:].view(2, P)
         self.params = {}
         off = 0
         shapes = self._shapes(P)
@@ -441,12 +445,24 @@ class GaussianModelLite:
                 view.copy_(g)
             p.grad = view
 
-    def update_view_statistics(self, radii, viewspace_grad):
-        """train.py:266-268 + add_densification_stats in one kernel (gs_densify_stats) when available."""
+    def update_view_statistics(self, radii, viewspace_grad, into_delta=False):
+        """train.py:266-268 + add_densification_stats in one kernel (gs_densify_stats) when available.
+        into_delta: write this view's increments of xyz_gradient_accum / denom into `stat_delta` (zeroed first)
+        instead of the running totals - the data-parallel step sums the increments over ranks before adding them."""
         api = getattr(self.optimizer, "api", None)
+        if into_delta:
+            self.stat_delta.zero_()
+        acc = self.stat_delta[0] if into_delta else self.xyz_gradient_accum
+        den = self.stat_delta[1] if into_delta else self.denom
         if api is not None and hasattr(api, "_densify_stats") and viewspace_grad is not None and viewspace_grad.is_contiguous():
             api.call("densify_stats", radii.data_ptr(), viewspace_grad.data_ptr(), self.P, self.max_radii2D.data_ptr(),
-                     self.xyz_gradient_accum.data_ptr(), self.denom.data_ptr(), _stream_of(radii))
+                     acc.data_ptr(), den.data_ptr(), _stream_of(radii))
+            return
+        if into_delta:
+            vm = (radii > 0).to(torch.float32)
+            torch.maximum(self.max_radii2D, radii.to(torch.float32), out=self.max_radii2D)
+            acc += torch.norm(viewspace_grad[:, :2], dim=-1) * vm
+            den += vm
             return
         # train.py:268 (radii are 0 for culled Gaussians, so a plain maximum equals the masked update)
         torch.maximum(self.max_radii2D, radii.to(torch.float32), out=self.max_radii2D)
@@ -639,7 +655,7 @@ class Trainer:
         radii = pkg["radii"]
         with torch.no_grad():
             m.collect_grads()
-            m.update_view_statistics(radii, pkg["viewspace_points"].grad)
+            m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
             if self.world_size > 1:
                 self.all_reduce()
             if optimizer_step:
@@ -648,12 +664,14 @@ class Trainer:
         return loss.detach()
 
     def all_reduce(self):
-        """The one exchange step of the data-parallel path: sum of the 59-floats-per-Gaussian gradient
-        buffer (236 B x P) + densification statistics, RCCL over xGMI (gloo in the CPU tests)."""
+        """The one exchange step of the data-parallel path: ONE sum over the exchange buffer = the 59-floats-per-
+        Gaussian gradients (236 B x P) followed by this step's increments of the densification statistics (8 B x P),
+        plus a max over max_radii2D; RCCL over xGMI (gloo in the CPU tests).  The summed increments are then added
+        to the running totals, so every replica holds the statistics of ALL cameras of the step."""
         m = self.model
-        work = [dist.all_reduce(m.flat_grad, op=dist.ReduceOp.SUM, async_op=True),
-                dist.all_reduce(m.xyz_gradient_accum, op=dist.ReduceOp.SUM, async_op=True),
-                dist.all_reduce(m.denom, op=dist.ReduceOp.SUM, async_op=True),
+        work = [dist.all_reduce(m.exchange, op=dist.ReduceOp.SUM, async_op=True),
                 dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)]
         for w in work:
             w.wait()
+        m.xyz_gradient_accum += m.stat_delta[0].unsqueeze(1)
+        m.denom += m.stat_delta[1].unsqueeze(1)
