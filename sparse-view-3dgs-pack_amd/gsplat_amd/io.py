@@ -118,11 +118,12 @@ def gaussian_attribute_names(n_rest=45):
     return names
 
 
-def save_gaussians_ply(path, xyz, features, opacity, scaling, rotation):
+def save_gaussians_ply(path, xyz, features, opacity, scaling, rotation, extra=None):
     """save_ply (gaussian_model.py:240-256).  All arguments are the RAW (pre-activation) parameters as arrays:
     xyz [P,3], features [P,K,3] (coefficient-major: DC first, as the rasterizer reads them), opacity [P,1],
     scaling [P,3], rotation [P,4].  The file stores the SH block channel-major (`transpose(1, 2)`), DC and rest
-    separately, and zero normals."""
+    separately, and zero normals.  extra: dict name -> [P] / [P,1] array appended as further float properties in
+    the given order (the multispectral variant appends `nir_albedo`, mult-dwtgs/scene/gaussian_model.py:317-338)."""
     xyz, features, opacity, scaling, rotation = (np.asarray(a, dtype=np.float32) for a in
                                                  (xyz, features, opacity, scaling, rotation))
     P, K = xyz.shape[0], features.shape[1]
@@ -130,6 +131,9 @@ def save_gaussians_ply(path, xyz, features, opacity, scaling, rotation):
     f_rest = np.transpose(features[:, 1:, :], (0, 2, 1)).reshape(P, 3 * (K - 1))
     cols = np.concatenate((xyz, np.zeros_like(xyz), f_dc, f_rest, opacity.reshape(P, 1), scaling, rotation), axis=1)
     names = gaussian_attribute_names(3 * (K - 1))
+    for k, v in (extra or {}).items():
+        names.append(k)
+        cols = np.concatenate((cols, np.asarray(v, dtype=np.float32).reshape(P, 1)), axis=1)
     out = np.empty(P, dtype=[(n, "f4") for n in names])
     for i, n in enumerate(names):
         out[n] = cols[:, i]
@@ -162,7 +166,10 @@ def load_gaussians_ply(path, max_sh_degree=3):
     scaling = np.stack([v[n] for n in numbered("scale_")], axis=1).astype(np.float32)
     rotation = np.stack([v[n] for n in numbered("rot")], axis=1).astype(np.float32)
     opacity = np.asarray(v["opacity"], dtype=np.float32)[:, None]
-    return dict(xyz=xyz, features=features, opacity=opacity, scaling=scaling, rotation=rotation)
+    out = dict(xyz=xyz, features=features, opacity=opacity, scaling=scaling, rotation=rotation)
+    if "nir_albedo" in names:  # multispectral models (mult-dwtgs/scene/gaussian_model.py:411-416)
+        out["nir_albedo"] = np.asarray(v["nir_albedo"], dtype=np.float32)[:, None]
+    return out
 
 
 BasicPointCloud = collections.namedtuple("BasicPointCloud", ["points", "colors", "normals"])

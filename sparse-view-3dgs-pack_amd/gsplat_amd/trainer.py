@@ -27,7 +27,11 @@ import torch.distributed as dist
 FIELDS = (("xyz", 3), ("features", 48), ("opacity", 1), ("scaling", 3), ("rotation", 4))
 FLOATS_PER_GAUSSIAN = sum(n for _, n in FIELDS)  # 59
 # LGDWT-GS/arguments/__init__.py:79-86 (position_lr_init, feature_lr, opacity_lr, scaling_lr, rotation_lr)
-LRS = {"xyz": 0.00016, "f_dc": 0.0025, "f_rest": 0.0025 / 20.0, "opacity": 0.025, "scaling": 0.005, "rotation": 0.001}
+LRS = {"xyz": 0.00016, "f_dc": 0.0025, "f_rest": 0.0025 / 20.0, "opacity": 0.025, "scaling": 0.005, "rotation": 0.001,
+       # multispectral variant (mult-dwtgs/scene/gaussian_model.py:266-280): albedo at position_lr_init (unscaled,
+       # no schedule), the global gain at feature_lr
+       "nir_albedo": 0.00016, "nir_gain": 0.0025}
+NIR_FIELD = ("nir_albedo", 1)
 
 
 def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
@@ -56,15 +60,15 @@ class FlatAdam:
         self.t = 0
         # torch keeps Adam's step count per parameter; a group that is skipped (no gradient after its tensor
         # was replaced) falls behind the others
-        self.seg_steps = {name: 0 for name, _ in FIELDS}
+        self.seg_steps = {name: 0 for name, _ in model.fields}
         self.lr = dict(LRS)
         self.lr["xyz"] = LRS["xyz"] * model.spatial_lr_scale
         self._Seg = GsAdamSeg
 
     def segments(self, skip=()):
         P = self.model.P
-        names = [(name, n) for name, n in FIELDS]
-        segs = (self._Seg * len(FIELDS))()
+        names = [(name, n) for name, n in self.model.fields]
+        segs = (self._Seg * len(names))()
         off, k = 0, 0
         for name, n in names:
             if name not in skip:
@@ -84,7 +88,7 @@ class FlatAdam:
         import ctypes as C
         m = self.model
         self.t += 1
-        for name, _ in FIELDS:
+        for name, _ in self.model.fields:
             if name not in skip:
                 self.seg_steps[name] += 1
         segs, nseg = self.segments(skip)
@@ -97,7 +101,7 @@ class FlatAdam:
 
     def field_views(self, buf):
         P, off, out = self.model.P, 0, {}
-        for name, n in FIELDS:
+        for name, n in self.model.fields:
             out[name] = buf[off:off + P * n].view(P, n)
             off += P * n
         return out
@@ -143,7 +147,7 @@ class _FusedActivations(torch.autograd.Function):
 class GaussianModelLite:
     """Raw (pre-activation) parameters of P Gaussians at max SH degree 3."""
 
-    def __init__(self, scene, device, spatial_lr_scale=1.0, api=None):
+    def __init__(self, scene, device, spatial_lr_scale=1.0, api=None, with_nir=False):
         """scene: dict of ACTIVATED tensors as produced by gsplat_amd.synthetic (means3D, scales,
         rotations, opacities, shs[P,16,3]) - converted back to raw form as create_from_pcd would hold them.
         api: C-ABI implementation that provides adam_step (None: torch.optim.Adam on the same flat buffers)."""
@@ -154,6 +158,14 @@ class GaussianModelLite:
         self.max_sh_degree = 3
         self.active_sh_degree = scene.get("sh_degree", 3)
         self.percent_dense = 0.01  # arguments/__init__.py:91
+        # multispectral variant: one more per-Gaussian parameter (raw NIR albedo, sigmoid-activated) and a global gain
+        # (mult-dwtgs/scene/gaussian_model.py:183-186,266-280,408-423).  The reference only creates them in load_ply
+        # (SURVEY Q5): here they exist from the start, initialised as its load_ply does - albedo = the DC coefficient
+        # it would broadcast (channel 0 is the one its render keeps), gain = 1.
+        self.with_nir = bool(with_nir)
+        self.fields = FIELDS + ((NIR_FIELD,) if self.with_nir else ())
+        self.width = sum(n for _, n in self.fields)
+        self.nir_gain = None
         self._allocate(P)
         with torch.no_grad():
             self.params["xyz"].copy_(scene["means3D"])
@@ -162,6 +174,11 @@ class GaussianModelLite:
             self.params["opacity"].copy_(torch.log(op / (1 - op)))
             self.params["scaling"].copy_(torch.log(scene["scales"]))
             self.params["rotation"].copy_(scene["rotations"])
+            if self.with_nir:
+                self.params["nir_albedo"].copy_(scene["shs"][:, 0, 0:1])
+        if self.with_nir:
+            self.nir_gain = torch.nn.Parameter(torch.tensor(1.0, dtype=torch.float32, device=device))
+            self.nir_gain_optimizer = torch.optim.Adam([self.nir_gain], lr=LRS["nir_gain"], eps=1e-15)
         if api is not None:
             self.optimizer = FlatAdam(api, self)
         else:
@@ -178,21 +195,23 @@ class GaussianModelLite:
 
     @staticmethod
     def _shapes(P):
-        return {"xyz": (P, 3), "features": (P, 16, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+        return {"xyz": (P, 3), "features": (P, 16, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4),
+                "nir_albedo": (P, 1)}
 
     def _allocate(self, P):
         """(Re)create the flat parameter / gradient buffers for P Gaussians and the views into them."""
         self.P = P
-        self.flat = torch.zeros((P * FLOATS_PER_GAUSSIAN,), dtype=torch.float32, device=self.device)
+        W = self.width
+        self.flat = torch.zeros((P * W,), dtype=torch.float32, device=self.device)
         # gradient buffer + a [2, P] tail for this step's densification-statistic increments: the data-parallel
         # exchange is then ONE all-reduce (SUM) over gradients and increments together
-        self.exchange = torch.zeros((P * (FLOATS_PER_GAUSSIAN + 2),), dtype=torch.float32, device=self.device)
-        self.flat_grad = self.exchange[:P * FLOATS_PER_GAUSSIAN]
-        self.stat_delta = self.exchange[P * FLOATS_PER_GAUSSIAN:].view(2, P)
+        self.exchange = torch.zeros((P * (W + 2),), dtype=torch.float32, device=self.device)
+        self.flat_grad = self.exchange[:P * W]
+        self.stat_delta = self.exchange[P * W:].view(2, P)
         self.params = {}
         off = 0
         shapes = self._shapes(P)
-        for name, n in FIELDS:
+        for name, n in self.fields:
             view = self.flat[off:off + P * n].view(shapes[name])
             p = torch.nn.Parameter(view, requires_grad=True)
             p.grad = self.flat_grad[off:off + P * n].view(shapes[name])
@@ -221,7 +240,8 @@ class GaussianModelLite:
         """save_ply (gaussian_model.py:240-256): raw parameters, the reference's 62-property layout."""
         from . import io as gio
         p = {k: v.detach().cpu().numpy() for k, v in self.params.items()}
-        gio.save_gaussians_ply(path, p["xyz"], p["features"], p["opacity"], p["scaling"], p["rotation"])
+        extra = {"nir_albedo": p["nir_albedo"]} if self.with_nir else None
+        gio.save_gaussians_ply(path, p["xyz"], p["features"], p["opacity"], p["scaling"], p["rotation"], extra=extra)
 
     def load_ply(self, path):
         """load_ply (gaussian_model.py:263-314): replaces the parameters (fresh Adam state), active degree = max."""
@@ -229,6 +249,9 @@ class GaussianModelLite:
         d = gio.load_gaussians_ply(path, self.max_sh_degree)
         api = getattr(self.optimizer, "api", None)
         self._allocate(d["xyz"].shape[0])
+        if self.with_nir and "nir_albedo" not in d:
+            # mult-dwtgs/scene/gaussian_model.py:417-421: no NIR property in the file -> start from the DC coefficient
+            d["nir_albedo"] = d["features"][:, 0, 0:1].copy()
         with torch.no_grad():
             for name in self.params:
                 self.params[name].copy_(torch.from_numpy(d[name]).reshape(self.params[name].shape))
@@ -276,12 +299,12 @@ class GaussianModelLite:
         opt = self.optimizer
         if not isinstance(opt, FlatAdam):
             raise NotImplementedError("densification needs the flat Adam state")
-        old_p = {name: self.params[name].detach().reshape(self.P, n) for name, n in FIELDS}
+        old_p = {name: self.params[name].detach().reshape(self.P, n) for name, n in self.fields}
         old_m, old_v = opt.field_views(opt.exp_avg), opt.field_views(opt.exp_avg_sq)
         n_new = next(iter(new_rows.values())).shape[0] if new_rows else 0
         P2 = int(src_idx.numel()) + n_new
         cat_p, cat_m, cat_v = {}, {}, {}
-        for name, n in FIELDS:
+        for name, n in self.fields:
             add = new_rows[name].reshape(n_new, n) if n_new else old_p[name][:0]
             cat_p[name] = torch.cat((old_p[name][src_idx], add), dim=0)
             z = torch.zeros_like(add)
@@ -292,7 +315,7 @@ class GaussianModelLite:
         opt.exp_avg_sq = torch.zeros_like(self.flat)
         new_m, new_v = opt.field_views(opt.exp_avg), opt.field_views(opt.exp_avg_sq)
         with torch.no_grad():
-            for name, n in FIELDS:
+            for name, n in self.fields:
                 self.params[name].reshape(P2, n).copy_(cat_p[name])
                 new_m[name].copy_(cat_m[name])
                 new_v[name].copy_(cat_v[name])
@@ -330,8 +353,8 @@ class GaussianModelLite:
             ci = clone.nonzero().squeeze(1)
             si = split.nonzero().squeeze(1)
             ns = int(si.numel())
-            raw = {name: self.params[name].detach().reshape(P0, n) for name, n in FIELDS}
-            new = {name: [raw[name][ci]] for name, _ in FIELDS}
+            raw = {name: self.params[name].detach().reshape(P0, n) for name, n in self.fields}
+            new = {name: [raw[name][ci]] for name, _ in self.fields}
             if ns:
                 stds = scaling[si].repeat(N, 1)
                 if generator is None:
@@ -342,8 +365,9 @@ class GaussianModelLite:
                 new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + raw["xyz"][si].repeat(N, 1)
                 new["xyz"].append(new_xyz)
                 new["scaling"].append(torch.log(scaling[si].repeat(N, 1) / (0.8 * N)))
-                for name in ("features", "opacity", "rotation"):
-                    new[name].append(raw[name][si].repeat(N, 1))
+                for name, _ in self.fields:
+                    if name not in ("xyz", "scaling"):
+                        new[name].append(raw[name][si].repeat(N, 1))
             new = {name: torch.cat(v, dim=0) for name, v in new.items()}
             n_new = new["xyz"].shape[0]
             # final prune (:455-462) evaluated on [survivors, clones, samples]
@@ -421,7 +445,7 @@ class GaussianModelLite:
     def grad_views(self):
         P, off, out = self.P, 0, {}
         shapes = self._shapes(P)
-        for name, n in FIELDS:
+        for name, n in self.fields:
             out[name] = self.flat_grad[off:off + P * n].view(shapes[name])
             off += P * n
         return out
@@ -675,3 +699,93 @@ class Trainer:
             w.wait()
         m.xyz_gradient_accum += m.stat_delta[0].unsqueeze(1)
         m.denom += m.stat_delta[1].unsqueeze(1)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# multispectral (RGB + NIR) step: counterpart of LGDWT-GS/mult-dwtgs/train_nir.py:81-125 on the fused 4-channel pass
+# ----------------------------------------------------------------------------------------------------------------
+def render_rgb_nir(viewpoint_camera, pc, Settings, bg_color, scaling_modifier=1.0, antialiasing=False, debug=False,
+                   two_pass_rasterizer=None):
+    """= render() + render_nir() of mult-dwtgs/gaussian_renderer/__init__.py:18-258: {render (clamped to [0,1] as
+    :119 does), nir (channel 0 of the NIR pass, not clamped), viewspace_points, visibility_filter, radii, depth}.
+    Default: ONE pass with the NIR albedo as a 4th blended channel (gsplat_amd.nir).  two_pass_rasterizer = a
+    `GaussianRasterizer` class: the reference's two 3-channel passes through it (used as the parity target)."""
+    from .nir import GaussianRasterizerX, nir_colors
+    rs = Settings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=debug, antialiasing=antialiasing)
+    act = pc.fused_activations()
+    if act is None:
+        act = (pc.get_scaling, pc.get_rotation, pc.get_opacity)
+    scales, rotations, opacities = act
+    nir = nir_colors(torch.sigmoid(pc.params["nir_albedo"]), pc.nir_gain)  # get_nir_albedo * clamp(gain), render_nir:166-169
+    ssp = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    if two_pass_rasterizer is None:
+        color, radii, depth, nir_img = GaussianRasterizerX(rs)(
+            means3D=pc.get_xyz, means2D=ssp, opacities=opacities, extra=nir, shs=pc.get_features, scales=scales,
+            rotations=rotations)
+        ssp2 = None
+    else:
+        rast = two_pass_rasterizer(raster_settings=rs)
+        color, radii, depth = rast(means3D=pc.get_xyz, means2D=ssp, shs=pc.get_features, opacities=opacities,
+                                   scales=scales, rotations=rotations)
+        ssp2 = torch.zeros_like(pc.get_xyz, requires_grad=True)
+        img3, _, _ = rast(means3D=pc.get_xyz, means2D=ssp2, shs=None, colors_precomp=nir[:, None].repeat(1, 3),
+                          opacities=opacities, scales=scales, rotations=rotations)
+        nir_img = img3[0:1]
+    return {"render": color.clamp(0, 1), "nir": nir_img, "viewspace_points": ssp, "viewspace_points_nir": ssp2,
+            "visibility_filter": radii > 0, "radii": radii, "depth": depth}
+
+
+class NirCriterion:
+    """train_nir.py:88-104: (1 - l) L1 + l (1 - SSIM) on RGB, plus nir_weight * (L1 + 0.2 (1 - SSIM)) on the NIR image
+    (mult-dwtgs/utils/loss_utils.py:93-144; the reference evaluates the single-channel SSIM on three identical
+    copies, whose mean is the single-channel value)."""
+
+    def __init__(self, ops, lambda_dssim=0.2, nir_weight=1.0, nir_l1_weight=1.0, nir_ssim_weight=0.2):
+        self.ops, self.lambda_dssim, self.nir_weight = ops, lambda_dssim, nir_weight
+        self.nir_l1_weight, self.nir_ssim_weight = nir_l1_weight, nir_ssim_weight
+
+    def __call__(self, image, gt_image, nir_pred, nir_gt):
+        o = self.ops
+        l1 = o.l1_loss(image, gt_image)
+        rgb = (1.0 - self.lambda_dssim) * l1 + self.lambda_dssim * (1.0 - o.ssim(image, gt_image))
+        nir = self.nir_l1_weight * o.l1_loss(nir_pred, nir_gt) + self.nir_ssim_weight * (1.0 - o.ssim(nir_pred, nir_gt))
+        return rgb + self.nir_weight * nir, dict(rgb=rgb.detach(), nir=nir.detach())
+
+
+class TrainerNIR(Trainer):
+    """Trainer for a model created with with_nir=True: one fused 4-channel pass per view, RGB + NIR losses, Adam over
+    the 60-float rows (59 + raw NIR albedo) and the global gain."""
+
+    def __init__(self, model, cameras, gt_images, nir_images, criterion, Settings, bg, two_pass_rasterizer=None, **kw):
+        super().__init__(model, cameras, gt_images, criterion, None, Settings, bg, **kw)
+        self.nirs = nir_images
+        self.two_pass = two_pass_rasterizer
+
+    def _step_camera(self, ci, optimizer_step, skip):
+        m = self.model
+        m.zero_grad()
+        if m.nir_gain.grad is not None:
+            m.nir_gain.grad = None
+        pkg = render_rgb_nir(self.cameras[ci], m, self.Settings, self.bg, two_pass_rasterizer=self.two_pass)
+        loss, parts = self.criterion(pkg["render"], self.gts[ci], pkg["nir"], self.nirs[ci])
+        loss.backward()
+        radii = pkg["radii"]
+        with torch.no_grad():
+            m.collect_grads()
+            vg = pkg["viewspace_points"].grad
+            if pkg["viewspace_points_nir"] is not None and pkg["viewspace_points_nir"].grad is not None:
+                vg = vg + pkg["viewspace_points_nir"].grad
+            m.update_view_statistics(radii, vg.contiguous(), into_delta=self.world_size > 1)
+            if self.world_size > 1:
+                self.all_reduce()
+                dist.all_reduce(m.nir_gain.grad, op=dist.ReduceOp.SUM)
+            if optimizer_step:
+                m.optimizer.step(*([skip] if skip else []))
+                m.nir_gain_optimizer.step()
+        self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
+        return loss.detach()

@@ -236,3 +236,22 @@ def test_model_ply_and_checkpoint_round_trip(tmp_path, oracle):
         mm.flat_grad.copy_(grad)
         mm.optimizer.step()
     assert torch.equal(m3.flat, m.flat) and m3.optimizer.seg_steps == m.optimizer.seg_steps
+
+
+def test_nir_model_ply_round_trip(tmp_path, oracle):
+    from gsplat_amd.trainer import GaussianModelLite
+    sc = synthetic.trained_like(30, seed=2)
+    m = GaussianModelLite(sc, torch.device("cpu"), api=oracle.api, with_nir=True)
+    with torch.no_grad():
+        m.params["nir_albedo"].copy_(torch.linspace(-2, 2, 30)[:, None])
+    p = str(tmp_path / "nir.ply")
+    m.save_ply(p)
+    v = gio.read_ply(p)
+    assert v.dtype.names[-1] == "nir_albedo" and len(v.dtype.names) == 63
+    m2 = GaussianModelLite(synthetic.trained_like(5, seed=3), torch.device("cpu"), api=oracle.api, with_nir=True)
+    m2.load_ply(p)
+    assert m2.P == 30 and torch.equal(m2.flat, m.flat)
+    plain = str(tmp_path / "plain.ply")
+    GaussianModelLite(sc, torch.device("cpu"), api=oracle.api).save_ply(plain)
+    m2.load_ply(plain)  # no NIR property: albedo starts from the DC coefficient
+    assert torch.equal(m2.params["nir_albedo"].detach()[:, 0], m2.params["features"].detach()[:, 0, 0])
