@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - train-step views/s (fwd+bwd) of the MI355X rasterizer + LGDWT loss path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1|c5|tiny]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
               --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,7 +35,10 @@ CONFIGS = {
     "c2": (500_000, 800, 800, True, False, "BASELINE configs[1]: 500k Gaussians, 800x800, global DWT"),
     "c1": (10_000, 400, 400, False, False, "BASELINE configs[0]: 10k Gaussians, 400x400, DWT off"),
     "tiny": (2_000, 256, 160, True, True, "plumbing check"),
+    # multispectral step (train_nir.py: L1 + SSIM on RGB and on the NIR image, no DWT terms): ONE fused 4-channel pass
+    "c5": (1_000_000, 1920, 1080, False, False, "BASELINE configs[4]: RGB+NIR 4-channel render, 1M Gaussians, 1080p"),
 }
+NIR_CONFIGS = ("c5",)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -73,6 +76,15 @@ def build_workload(cfg, device, rank, world, seed=0):
             img = render(cams[ci], gt_model, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg)["render"]
             gts[ci] = (torch.round(img * 255.0) / 255.0).contiguous()
     del gt_model
+    if cfg in NIR_CONFIGS:
+        from gsplat_amd.losses import LossOps
+        from gsplat_amd.trainer import NirCriterion, TrainerNIR
+        g = torch.Generator().manual_seed(seed + 2)
+        nirs = [None if x is None else (torch.round(torch.rand((1, H, W), generator=g) * 255.0) / 255.0).to(device) for x in gts]
+        model = GaussianModelLite(scene, device, api=hip_api_(), with_nir=True)
+        tr = TrainerNIR(model, cams, gts, nirs, NirCriterion(LossOps(hip_api_())), dgr.GaussianRasterizationSettings, bg,
+                        rank=rank, world_size=world)
+        return tr, scene, cams, gts
     model = GaussianModelLite(scene, device, api=hip_api_())
     crit = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch)
     masks = None
@@ -271,7 +283,7 @@ def main():
             "stages_note": "HIP events; %s measured inside the timed region, the other stages in a separate untimed "
                            "pass of the same step (each event pair drains the pipeline for ~10 us)" % dom_stage,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config not in NIR_CONFIGS:
             ci = tr.camera_index(k - 1)
             out["cpu_baseline"] = cpu_baseline(args.config, scene, cams[ci], gts[ci], log)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
