@@ -317,8 +317,8 @@ int gs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 
 /* ---- per-Gaussian elementwise work of the train step outside the rasterizer ----
  * Parameter activations of GaussianModel (LGDWT-GS/scene/gaussian_model.py:40-60,102-117): scales = exp(scaling),
- * rotations = F.normalize(rotation) (eps 1e-12), opacities = sigmoid(opacity); all [P,k] contiguous fp32,
- * rotation arrays 16-byte aligned.  One kernel instead of ~5 torch kernels. */
+ * rotations = F.normalize(rotation) (eps 1e-12), opacities = sigmoid(opacity); all [P,k] contiguous fp32 (any
+ * 4-byte alignment).  One kernel instead of ~5 torch kernels. */
 int gs_activations_fwd(const float* scaling /*[P,3]*/, const float* rotation /*[P,4]*/,
                        const float* opacity /*[P]*/, int32_t P, float* scales_out, float* rotations_out,
                        float* opacities_out, void* stream);

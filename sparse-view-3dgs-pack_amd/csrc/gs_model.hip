@@ -19,10 +19,15 @@ __global__ void __launch_bounds__(GS_BLOCK) act_fwd_kernel(const float* __restri
   o_scales[3 * i] = expf(scaling[3 * i]);
   o_scales[3 * i + 1] = expf(scaling[3 * i + 1]);
   o_scales[3 * i + 2] = expf(scaling[3 * i + 2]);
-  const float4 q = reinterpret_cast<const float4*>(rotation)[i];
+  // (scalar accesses: after a densification the rotation segment of the flat buffer starts at 220 P bytes, which is
+  // 16-byte aligned only when P is a multiple of 4)
+  const float4 q = make_float4(rotation[4 * i], rotation[4 * i + 1], rotation[4 * i + 2], rotation[4 * i + 3]);
   // F.normalize: v / max(||v||_2, eps), eps = 1e-12
   const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-  reinterpret_cast<float4*>(o_rot)[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+  o_rot[4 * i] = q.x / n;
+  o_rot[4 * i + 1] = q.y / n;
+  o_rot[4 * i + 2] = q.z / n;
+  o_rot[4 * i + 3] = q.w / n;
   o_opac[i] = 1.0f / (1.0f + expf(-opacity[i]));
 }
 
@@ -38,8 +43,8 @@ __global__ void __launch_bounds__(GS_BLOCK) act_bwd_kernel(const float* __restri
   d_scaling[3 * i + 1] = g_scales[3 * i + 1] * expf(scaling[3 * i + 1]);
   d_scaling[3 * i + 2] = g_scales[3 * i + 2] * expf(scaling[3 * i + 2]);
   // v = q / n, n = max(||q||, eps):  dq = (g - v (v . g)) / n   (n clamped: dq = g / eps)
-  const float4 q = reinterpret_cast<const float4*>(rotation)[i];
-  const float4 g = reinterpret_cast<const float4*>(g_rot)[i];
+  const float4 q = make_float4(rotation[4 * i], rotation[4 * i + 1], rotation[4 * i + 2], rotation[4 * i + 3]);
+  const float4 g = make_float4(g_rot[4 * i], g_rot[4 * i + 1], g_rot[4 * i + 2], g_rot[4 * i + 3]);
   const float norm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
   float4 d;
   if (norm > 1e-12f) {
@@ -50,7 +55,10 @@ __global__ void __launch_bounds__(GS_BLOCK) act_bwd_kernel(const float* __restri
   } else {
     d = make_float4(g.x / 1e-12f, g.y / 1e-12f, g.z / 1e-12f, g.w / 1e-12f);
   }
-  reinterpret_cast<float4*>(d_rotation)[i] = d;
+  d_rotation[4 * i] = d.x;
+  d_rotation[4 * i + 1] = d.y;
+  d_rotation[4 * i + 2] = d.z;
+  d_rotation[4 * i + 3] = d.w;
   // sigmoid backward: grad * s * (1 - s)
   const float s = 1.0f / (1.0f + expf(-opacity[i]));
   d_opacity[i] = g_opac[i] * (1.0f - s) * s;
@@ -78,7 +86,6 @@ int gs_activations_fwd(const float* scaling, const float* rotation, const float*
   if (P < 0) return GS_E_SHAPE;
   if (P == 0) return GS_OK;
   if (!scaling || !rotation || !opacity || !scales_out || !rotations_out || !opacities_out) return GS_E_NULL;
-  if ((((uintptr_t)rotation | (uintptr_t)rotations_out) & 15) != 0) return GS_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_MODEL, s);
   hipLaunchKernelGGL(act_fwd_kernel, dim3((P + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, scaling, rotation, opacity, P,
@@ -95,7 +102,6 @@ int gs_activations_bwd(const float* scaling, const float* rotation, const float*
   if (!scaling || !rotation || !opacity || !dL_dscales || !dL_drotations || !dL_dopacities || !d_scaling || !d_rotation ||
       !d_opacity)
     return GS_E_NULL;
-  if ((((uintptr_t)rotation | (uintptr_t)dL_drotations | (uintptr_t)d_rotation) & 15) != 0) return GS_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_MODEL, s);
   hipLaunchKernelGGL(act_bwd_kernel, dim3((P + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, scaling, rotation, opacity, P,

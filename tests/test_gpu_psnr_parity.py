@@ -60,3 +60,30 @@ def test_training_psnr_parity_hip_vs_oracle(hip, oracle):
     # by a few lr; the population stays together
     d = (h["flat"] - o["flat"])
     assert float(d.abs().max()) < 0.1 and float(d.pow(2).mean().sqrt()) < 1e-3, (float(d.abs().max()), float(d.pow(2).mean().sqrt()))
+
+
+def test_schedule_with_densification_runs_on_the_gpu(hip):
+    """train_iteration on the HIP backend through densify / prune / opacity reset: the flat buffers are re-laid out,
+    the next iterations render and step the grown model, statistics restart at zero."""
+    import diff_gaussian_rasterization as dgr
+    import lgdwt_loss
+    from gsplat_amd import synthetic
+    from gsplat_amd.trainer import GaussianModelLite, TrainOptions, Trainer, camera_to, cameras_extent
+    dev = torch.device("cuda")
+    sc = synthetic.trained_like(20000, seed=2, scale_mult=1.0)
+    cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(320, 240)[:6]]
+    g = torch.Generator().manual_seed(0)
+    gts = [torch.rand((3, 240, 320), generator=g).to(dev) for _ in cams]
+    model = GaussianModelLite(sc, dev, api=hip.api)
+    crit = lgdwt_loss.criterion(dwt_enable=True, patch_dwt_enable=False)
+    tr = Trainer(model, cams, gts, crit, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, torch.zeros(3, device=dev))
+    opt = TrainOptions(iterations=40, densify_from_iter=4, densification_interval=5, opacity_reset_interval=12,
+                       densify_until_iter=30, cameras_extent=cameras_extent([c.camera_center for c in cams]), seed=4)
+    sizes, losses = [], []
+    for it in range(1, 28):
+        out = tr.train_iteration(it, opt)
+        sizes.append(out["P"])
+        losses.append(float(out["loss"]))
+    assert len(set(sizes)) > 1 and all(torch.isfinite(torch.tensor(losses)))
+    assert model.flat.numel() == model.P * 59 and model.optimizer.exp_avg.numel() == model.flat.numel()
+    assert model.exchange.numel() == model.P * 61 and model.denom.shape == (model.P, 1)
