@@ -62,7 +62,13 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
   __shared__ float4 s_k[WB];  // rgb, 4th channel
   __shared__ uint32_t s_id[WB];
 
-  const int tile = blockIdx.x;
+  // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so tile
+  // t = xcd * ceil(T/8) + id/8 keeps a contiguous band of the image - whose tiles share splat records - on one L2
+  const int n_tiles = grid_x * ((H + TILE_Y - 1) / TILE_Y);
+  const int per_xcd = (int)(gridDim.x >> 3);  // the grid is padded to a multiple of 8 workgroups
+  const int tile_sw = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (tile_sw >= n_tiles) return;
+  const int tile = tile_sw;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int lane = threadIdx.x;
   const uint2 range = ranges[tile];
@@ -247,7 +253,7 @@ int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int 
                            const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows,
                            int fsgs, hipStream_t s) {
 #define GS_BWD_WAVE(ID, EX, FS)                                                                                           \
-  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX, FS>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, \
+  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX, FS>), dim3(((grid_x * grid_y + 7) / 8) * 8), dim3(64), 0, s, ranges, point_list, W, H, \
                      grid_x, splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, dL_dextra, grad_rows)
   if (fsgs) GS_BWD_WAVE(true, true, true);
   else if (dL_dinvdepth && dL_dextra) GS_BWD_WAVE(true, true, false);

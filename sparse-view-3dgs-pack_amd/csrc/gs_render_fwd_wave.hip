@@ -32,7 +32,13 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
   __shared__ float4 s_k[WB];  // rgb, cull extent x
   __shared__ float s_e[HAS_EXTRA ? WB : 1];  // 4th channel (N1: NIR albedo blended with the same weights)
 
-  const int tile = blockIdx.x;
+  // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so tile
+  // t = xcd * ceil(T/8) + id/8 keeps a contiguous band of the image - whose tiles share splat records - on one L2
+  const int n_tiles = grid_x * ((H + TILE_Y - 1) / TILE_Y);
+  const int per_xcd = (int)(gridDim.x >> 3);  // the grid is padded to a multiple of 8 workgroups
+  const int tile_sw = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (tile_sw >= n_tiles) return;
+  const int tile = tile_sw;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int lane = threadIdx.x;
   const int px0 = tile_x * TILE_X + (lane & 7), py0 = tile_y * TILE_Y + (lane >> 3);
@@ -162,7 +168,7 @@ int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int 
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                            float* out_invdepth, float* out_extra, int fsgs, int cull, hipStream_t s) {
 #define GS_FWD_WAVE(EX, FS, CU)                                                                                          \
-  hipLaunchKernelGGL((render_fwd_wave_kernel<EX, FS, CU>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, \
+  hipLaunchKernelGGL((render_fwd_wave_kernel<EX, FS, CU>), dim3(((grid_x * grid_y + 7) / 8) * 8), dim3(64), 0, s, ranges, point_list, W, H, \
                      grid_x, splat, bg, final_T, n_contrib, out_color, out_invdepth, out_extra)
   if (fsgs) {
     if (cull) GS_FWD_WAVE(false, true, true); else GS_FWD_WAVE(false, true, false);
