@@ -50,14 +50,37 @@ __global__ void __launch_bounds__(GS_BLOCK) adam_kernel(float* __restrict__ p, c
     const float* ge = reinterpret_cast<const float*>(&gg);
     float* me = reinterpret_cast<float*>(&mm);
     float* ve = reinterpret_cast<float*>(&vv);
+    // Fast path: the four elements lie in one segment (always, except where a segment boundary is not a multiple
+    // of 4): one table walk and one 64-bit modulo per vector instead of four
+    const long long i0 = i4 * 4;
+    int seg = -1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      float lr_bc1, inv_sqrt_bc2;
-      if (!adam_coef(segs, i4 * 4 + k, lr_bc1, inv_sqrt_bc2)) continue;
-      me[k] = b1 * me[k] + (1.f - b1) * ge[k];
-      ve[k] = b2 * ve[k] + (1.f - b2) * ge[k] * ge[k];
-      const float denom = sqrtf(ve[k]) * inv_sqrt_bc2 + eps;
-      pe[k] = pe[k] - lr_bc1 * (me[k] / denom);
+    for (int k = 0; k < ADAM_MAX_SEG; k++)
+      if (k < segs.n && i0 >= segs.begin[k] && i0 + 3 < segs.end[k]) seg = k;
+    if (seg >= 0) {
+      const float inv_sqrt_bc2 = segs.inv_sqrt_bc2[seg];
+      const float lra = segs.lr_a[seg] * segs.inv_bc1[seg], lrb = segs.lr_b[seg] * segs.inv_bc1[seg];
+      const int period = segs.period[seg], split = segs.split[seg];
+      int ph = period > 0 ? (int)((i0 - segs.begin[seg]) % period) : 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float lr_bc1 = (period > 0 && ph >= split) ? lrb : lra;
+        me[k] = b1 * me[k] + (1.f - b1) * ge[k];
+        ve[k] = b2 * ve[k] + (1.f - b2) * ge[k] * ge[k];
+        const float denom = sqrtf(ve[k]) * inv_sqrt_bc2 + eps;
+        pe[k] = pe[k] - lr_bc1 * (me[k] / denom);
+        ph = (ph + 1 == period) ? 0 : ph + 1;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float lr_bc1, inv_sqrt_bc2;
+        if (!adam_coef(segs, i0 + k, lr_bc1, inv_sqrt_bc2)) continue;
+        me[k] = b1 * me[k] + (1.f - b1) * ge[k];
+        ve[k] = b2 * ve[k] + (1.f - b2) * ge[k] * ge[k];
+        const float denom = sqrtf(ve[k]) * inv_sqrt_bc2 + eps;
+        pe[k] = pe[k] - lr_bc1 * (me[k] / denom);
+      }
     }
     reinterpret_cast<float4*>(p)[i4] = pp;
     reinterpret_cast<float4*>(m)[i4] = mm;
