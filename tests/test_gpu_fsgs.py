@@ -86,3 +86,29 @@ def test_fsgs_knn_indices_bit_exact_vs_oracle(hip, oracle, P, seed):
     d1, i1 = distCUDA2(pts.cuda())
     assert torch.equal(d1.cpu().view(torch.int32), d0.view(torch.int32))
     assert torch.equal(i1.cpu(), i0)
+
+
+def test_dng_package_is_the_fsgs_generation_without_confidence(hip):
+    """dgr_dng: 12 settings fields, same (color, radii, depth, alpha) outputs as dgr_fsgs with confidence 1 and the
+    same gradients; sknn_dng._C.distCUDA2 is the plain distance."""
+    import dgr_dng
+    from simple_knn._C import distCUDA2 as d_base
+    from sknn_dng._C import distCUDA2 as d_dng
+    assert dgr_dng.GaussianRasterizationSettings._fields == dgr_fsgs.GaussianRasterizationSettings._fields[:-1]
+    sc = synthetic.trained_like(4000, seed=9, sh_degree=2)
+    cam = synthetic.orbit_cameras(256, 192)[4]
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(0)
+    dL = [torch.randn((3, 192, 256), generator=g), torch.randn((1, 192, 256), generator=g), torch.randn((1, 192, 256), generator=g)]
+    a = fsgs_run(dgr_fsgs.GaussianRasterizer, dgr_fsgs.GaussianRasterizationSettings, sc, cam, torch.zeros(3), dev, *dL)
+
+    def settings_without_confidence(**kw):  # fsgs_run builds the settings with a confidence keyword
+        kw.pop("confidence")
+        return dgr_dng.GaussianRasterizationSettings(**kw)
+    b = fsgs_run(dgr_dng.GaussianRasterizer, settings_without_confidence, sc, cam, torch.zeros(3), dev, *dL)
+    for k in ("color", "depth", "alpha", "radii"):
+        assert torch.equal(a[k], b[k]), k
+    for k in a["grads"]:
+        assert torch.allclose(a["grads"][k], b["grads"][k], rtol=1e-4, atol=1e-6 * float(a["grads"][k].abs().max())), k
+    pts = sc["means3D"].to(dev)
+    assert torch.equal(d_dng(pts), d_base(pts))
