@@ -109,6 +109,7 @@ def test_dng_package_is_the_fsgs_generation_without_confidence(hip):
     for k in ("color", "depth", "alpha", "radii"):
         assert torch.equal(a[k], b[k]), k
     for k in a["grads"]:
-        assert torch.allclose(a["grads"][k], b["grads"][k], rtol=1e-4, atol=1e-6 * float(a["grads"][k].abs().max())), k
+        # same kernels, different atomic order between the two runs
+        assert float((a["grads"][k] - b["grads"][k]).abs().max()) <= 2e-4 * max(1e-12, float(a["grads"][k].abs().max())), k
     pts = sc["means3D"].to(dev)
     assert torch.equal(d_dng(pts), d_base(pts))
