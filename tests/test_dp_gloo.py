@@ -103,20 +103,23 @@ def _worker_schedule(rank, world, port, outdir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_schedule_with_densification_keeps_replicas_identical():
+@pytest.mark.parametrize("world", [2, 4])
+def test_schedule_with_densification_keeps_replicas_identical(world):
     """Densify / prune / opacity reset run from all-reduced statistics and a shared seed: after 8 iterations of the
-    schedule both replicas hold the same number of Gaussians, bit-identical parameters and Adam moments, and
-    each global step consumed two different cameras of the shared draw-without-replacement stack."""
-    world = 2
+    schedule all replicas hold the same number of Gaussians, bit-identical parameters and Adam moments, and each
+    global step consumed `world` different cameras of the shared draw-without-replacement stack."""
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_schedule, args=(world, _free_port(), d), nprocs=world, join=True)
-        r0 = torch.load(os.path.join(d, "rank0.pt"))
-        r1 = torch.load(os.path.join(d, "rank1.pt"))
-    assert r0["sizes"] == r1["sizes"] and r0["sizes"][-1] != r0["sizes"][0]
-    for k in ("flat", "m1", "m2"):
-        assert torch.equal(r0[k], r1[k]), k
-    for a, b in zip(r0["cams"], r1["cams"]):
-        assert a != b
-    both = [c for pair in zip(r0["cams"], r1["cams"]) for c in pair]
-    for k in range(0, len(both), 4):  # 4 cameras: every two global steps use each camera once
-        assert sorted(both[k:k + 4]) == [0, 1, 2, 3]
+        rs = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(world)]
+    r0 = rs[0]
+    assert r0["sizes"][-1] != r0["sizes"][0]
+    for r in rs[1:]:
+        assert r["sizes"] == r0["sizes"]
+        for k in ("flat", "m1", "m2"):
+            assert torch.equal(r0[k], r[k]), k
+    per_step = list(zip(*[r["cams"] for r in rs]))  # cameras of ranks 0..world-1 at each global step
+    for cams in per_step:
+        assert len(set(cams)) == world
+    flat = [c for cams in per_step for c in cams]
+    for k in range(0, len(flat), 4):  # 4 cameras in the scene: every 4 draws are a permutation of them
+        assert sorted(flat[k:k + 4]) == [0, 1, 2, 3]
