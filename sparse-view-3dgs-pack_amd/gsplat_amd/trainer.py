@@ -85,19 +85,32 @@ class FlatAdam:
     def step(self, skip=()):
         """skip: fields without a gradient this iteration (their tensor was replaced after backward: torch's
         optimizer.step() leaves such a parameter, its moments and its step count alone)."""
-        import ctypes as C
-        m = self.model
+        self.begin_step(skip)
+        self.step_range(0, self.model.flat.numel(), skip)
+
+    def begin_step(self, skip=()):
         self.t += 1
         for name, _ in self.model.fields:
             if name not in skip:
                 self.seg_steps[name] += 1
+
+    def step_range(self, lo, hi, skip=()):
+        """The update of elements [lo, hi) of the flat buffers (lo a multiple of 4): the data-parallel step applies
+        Adam chunk by chunk as the chunks of the gradient all-reduce arrive.  The segment table is shifted by -lo so
+        that the kernel's element index i stands for element lo + i (a negative `begin` keeps the phase of the
+        interleaved SH learning rates)."""
+        import ctypes as C
+        m = self.model
         segs, nseg = self.segments(skip)
-        if nseg == 0:
+        if nseg == 0 or hi <= lo:
             return
+        for k in range(nseg):
+            segs[k].begin -= lo
+            segs[k].end -= lo
         stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
-        self.api.call("adam_step", m.flat.data_ptr(), m.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                      self.exp_avg_sq.data_ptr(), m.flat.numel(), segs, nseg, self.betas[0], self.betas[1],
-                      self.eps, self.t, stream)
+        self.api.call("adam_step", m.flat.data_ptr() + 4 * lo, m.flat_grad.data_ptr() + 4 * lo,
+                      self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
+                      self.betas[0], self.betas[1], self.eps, self.t, stream)
 
     def field_views(self, buf):
         P, off, out = self.model.P, 0, {}
@@ -680,23 +693,42 @@ class Trainer:
         with torch.no_grad():
             m.collect_grads()
             m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
-            if self.world_size > 1:
-                self.all_reduce()
-            if optimizer_step:
-                m.optimizer.step(*([skip] if skip else []))
+            self.exchange_and_step(optimizer_step, skip)
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
 
-    def all_reduce(self):
-        """The one exchange step of the data-parallel path: ONE sum over the exchange buffer = the 59-floats-per-
-        Gaussian gradients (236 B x P) followed by this step's increments of the densification statistics (8 B x P),
-        plus a max over max_radii2D; RCCL over xGMI (gloo in the CPU tests).  The summed increments are then added
-        to the running totals, so every replica holds the statistics of ALL cameras of the step."""
+    DP_CHUNKS = 4
+
+    def exchange_and_step(self, optimizer_step, skip=()):
+        """The one exchange step of the data-parallel path and the optimizer step.  The exchange buffer = the 59-
+        floats-per-Gaussian gradients (236 B x P) followed by this step's increments of the densification statistics
+        (8 B x P) is summed over ranks in DP_CHUNKS consecutive all-reduces (RCCL over xGMI; gloo in the CPU tests)
+        issued back to back; as soon as chunk k has arrived its slice of the flat Adam update runs while chunks
+        k+1.. are still on the links, so the optimizer (0.3 ms at 1 M Gaussians) hides behind the communication.
+        A max over max_radii2D travels alongside.  The summed increments are then added to the running totals, so
+        every replica holds the statistics of ALL cameras of the step."""
         m = self.model
-        work = [dist.all_reduce(m.exchange, op=dist.ReduceOp.SUM, async_op=True),
-                dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)]
-        for w in work:
+        opt = m.optimizer
+        chunked = isinstance(opt, FlatAdam)
+        if self.world_size <= 1:
+            if optimizer_step:
+                opt.step(*([skip] if skip else []))
+            return
+        n_grad = m.flat_grad.numel()
+        nch = self.DP_CHUNKS if chunked else 1
+        bounds = [(i * n_grad // nch) // 4 * 4 for i in range(nch)] + [m.exchange.numel()]
+        works = [dist.all_reduce(m.exchange[bounds[i]:bounds[i + 1]], op=dist.ReduceOp.SUM, async_op=True)
+                 for i in range(nch)]
+        wmax = dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)
+        if optimizer_step and chunked:
+            opt.begin_step(skip)
+        for i, w in enumerate(works):
             w.wait()
+            if optimizer_step and chunked:
+                opt.step_range(bounds[i], min(bounds[i + 1], n_grad), skip)
+        if optimizer_step and not chunked:
+            opt.step()
+        wmax.wait()
         m.xyz_gradient_accum += m.stat_delta[0].unsqueeze(1)
         m.denom += m.stat_delta[1].unsqueeze(1)
 
@@ -782,10 +814,9 @@ class TrainerNIR(Trainer):
                 vg = vg + pkg["viewspace_points_nir"].grad
             m.update_view_statistics(radii, vg.contiguous(), into_delta=self.world_size > 1)
             if self.world_size > 1:
-                self.all_reduce()
                 dist.all_reduce(m.nir_gain.grad, op=dist.ReduceOp.SUM)
+            self.exchange_and_step(optimizer_step, skip)
             if optimizer_step:
-                m.optimizer.step(*([skip] if skip else []))
                 m.nir_gain_optimizer.step()
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()

@@ -65,3 +65,32 @@ def test_hip_adam_matches_oracle(hip, oracle):
         o.optimizer.step()
     assert float((a.flat.cpu() - o.flat).abs().max()) < 1e-6
     assert float((a.optimizer.exp_avg_sq.cpu() - o.optimizer.exp_avg_sq).abs().max()) < 1e-9
+
+
+def _chunked_equals_whole(api, device):
+    a, _ = _models(api, P=1237, device=device)
+    b, _ = _models(api, P=1237, device=device)
+    g = torch.Generator().manual_seed(3)
+    n = a.flat.numel()
+    for it in range(1, 4):
+        grad = (torch.randn(n, generator=g) * 1e-2).to(device)
+        a.flat_grad.copy_(grad)
+        b.flat_grad.copy_(grad)
+        a.optimizer.step()
+        b.optimizer.begin_step()
+        bounds = [0, (n // 3) // 4 * 4, (2 * n // 3) // 4 * 4, n]   # chunk starts are multiples of 4 elements
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            b.optimizer.step_range(lo, hi)
+    assert torch.equal(a.flat, b.flat) and torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
+    assert a.optimizer.seg_steps == b.optimizer.seg_steps
+
+
+def test_chunkwise_adam_equals_one_call_on_the_oracle(oracle):
+    """The data-parallel step applies Adam chunk by chunk as the all-reduce chunks arrive (segment table shifted by
+    the chunk start, SH learning-rate phase kept): bit-identical to one call."""
+    _chunked_equals_whole(oracle.api, "cpu")
+
+
+@pytest.mark.gpu
+def test_chunkwise_adam_equals_one_call_on_the_gpu(hip):
+    _chunked_equals_whole(hip.api, "cuda")
