@@ -184,14 +184,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
   GS_LAUNCH_CHECK(s, v->debug);
   {
     GS_PROF(ST_RENDER_FWD, s);
-    // GS_FWD_KERNEL=quad selects the first-generation kernel (one pixel per lane, four waves per tile)
-    static const bool quad = getenv("GS_FWD_KERNEL") && !strcmp(getenv("GS_FWD_KERNEL"), "quad");
-    if (quad && (out_extra || fsgs)) return GS_E_UNSUPPORTED;  // the first-generation kernels blend three channels only
-    if (quad)
-      launch_render_fwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
-                        out_invdepth, s);
-    else
-      launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
+    launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
                              out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
@@ -253,14 +246,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   if (num_rendered > 0) {
     {
       GS_PROF(ST_RENDER_BWD, s);
-      // GS_BWD_KERNEL=quad selects the first-generation kernel (one pixel per lane, four waves per tile)
-      static const bool quad = getenv("GS_BWD_KERNEL") && !strcmp(getenv("GS_BWD_KERNEL"), "quad");
-      if (quad && (dL_dextra || fsgs)) return GS_E_UNSUPPORTED;
-      if (quad)
-        launch_render_bwd(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
-                          dL_dinvdepth, rows, s);
-      else
-        launch_render_bwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
+      launch_render_bwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
                                dL_dinvdepth, dL_dextra, rows, fsgs, s);
     }
     GS_LAUNCH_CHECK(s, v->debug);

@@ -212,12 +212,6 @@ int launch_emit_instances(const GeomView& g, int P, int grid_x, int tile_cull, c
 int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
                        hipStream_t s);
 
-int launch_render_fwd(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
-                      const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                      float* out_invdepth, hipStream_t s);
-int launch_render_bwd(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
-                      const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                      const float* dL_dpix, const float* dL_dinvdepth, float* grad_rows, hipStream_t s);
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,

@@ -1,6 +1,6 @@
 // gs_render_bwd_wave.hip - backward blend, "one wave64 per tile, four pixels per lane".
 //
-// Measured on the first backward kernel (gs_render_bwd.hip, one pixel per lane, four waves per tile): of
+// Measured on the first-generation backward kernel (since removed: one pixel per lane, four waves per tile): of
 // 1.40 ms, the per-pair alpha test costs 0.31 ms, the gradient math 0.30 ms and the cross-lane reduction of
 // the ten per-Gaussian sums 0.61 ms (+0.18 ms LDS accumulate / flush).  The reduction is paid once per
 // (wave, Gaussian) pair with a touched lane, i.e. up to four times per (tile, Gaussian).

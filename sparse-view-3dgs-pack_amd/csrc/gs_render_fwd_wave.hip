@@ -2,7 +2,7 @@
 //
 // Same decomposition as gs_render_bwd_wave.hip: a 64-thread workgroup (one wave) owns a 16x16 tile, lane l
 // blends the pixel at the same position of each 8x8 quadrant.  Compared with the four-waves-per-tile kernel
-// (gs_render_fwd.hip) the per-Gaussian LDS broadcast reads and loop overhead are paid once per tile instead
+// (since removed) the per-Gaussian LDS broadcast reads and loop overhead are paid once per tile instead
 // of once per quadrant, batches are 64 entries (a tile stops within 64 entries of its last live pixel, not
 // 256) and there is no workgroup barrier on which three waves wait for the slowest one.
 // Replaces renderCUDA<3> forward (forward.cu:274-397); per-pixel arithmetic and stopping rules unchanged.
