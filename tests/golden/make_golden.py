@@ -14,6 +14,9 @@ Fixtures are data only (inputs + the reference's outputs); no reference source i
                   LGDWT-GS/utils/image_utils.py) on seeded torch.rand images (recipe of
                   fused-ssim/tests/test.py:58-91 at small sizes)
   schedule.npz    get_expon_lr_func, inverse_sigmoid (LGDWT-GS/utils/general_utils.py), RGB2SH/SH2RGB
+  nir_loss.npz    the multispectral step's loss (mult-dwtgs/train_nir.py:88-104) from the reference's own functions
+                  (mult-dwtgs/utils/loss_utils.py: l1_loss, ssim, combined_nir_loss) with autograd gradients
+                  -> pins gsplat_amd.trainer.NirCriterion
   colmap/         a small COLMAP model (cameras.bin, images.bin, points3D.bin + the .txt forms) written by
                   gsplat_amd.io.write_colmap_binary from seeded data, and colmap_expected.npz = what the REFERENCE's
                   own readers (LGDWT-GS/scene/colmap_loader.py) return for those files, plus its qvec2rotmat /
@@ -42,6 +45,25 @@ graphics = load(REF + "/LGDWT-GS/utils/graphics_utils.py", "ref_graphics_utils")
 image_utils = load(REF + "/LGDWT-GS/utils/image_utils.py", "ref_image_utils")
 general = load(REF + "/LGDWT-GS/utils/general_utils.py", "ref_general_utils")
 loss_utils = load(REF + "/gaussian-splatting/utils/loss_utils.py", "ref_loss_utils")
+
+
+def gen_nir_loss():
+    ref = load(REF + "/LGDWT-GS/mult-dwtgs/utils/loss_utils.py", "ref_nir_loss_utils")
+    g = torch.Generator().manual_seed(77)
+    H, W = 45, 61
+    image = torch.rand((3, H, W), generator=g).requires_grad_(True)
+    gt = torch.rand((3, H, W), generator=g)
+    nir = (torch.rand((1, H, W), generator=g) * 1.2 - 0.1).requires_grad_(True)   # the NIR render is not clamped
+    nir_gt = torch.rand((1, H, W), generator=g)
+    lam, nir_weight = 0.2, 1.0
+    Ll1 = ref.l1_loss(image, gt)
+    loss = (1.0 - lam) * Ll1 + lam * (1.0 - ref.ssim(image, gt))
+    nir_loss = ref.combined_nir_loss(nir, nir_gt, l1_weight=1.0, ssim_weight=0.2)
+    total = loss + nir_weight * nir_loss
+    total.backward()
+    np.savez(os.path.join(HERE, "nir_loss.npz"), image=image.detach().numpy(), gt=gt.numpy(), nir=nir.detach().numpy(),
+             nir_gt=nir_gt.numpy(), rgb_loss=loss.item(), nir_loss=nir_loss.item(), total=total.item(),
+             d_image=image.grad.numpy(), d_nir=nir.grad.numpy())
 
 
 def gen_colmap():
@@ -196,4 +218,5 @@ if __name__ == "__main__":
     gen_losses()
     gen_schedule()
     gen_colmap()
+    gen_nir_loss()
     print("golden fixtures written to", HERE)

@@ -57,3 +57,21 @@ def test_fused_four_channel_step_equals_two_pass_step(hip):
     a.optimizer_step = True
     l = [float(a.step(k)) for k in range(0, 30, 3)]
     assert l[-1] < l[0]
+
+
+def test_nir_criterion_matches_the_reference_loss_functions(oracle):
+    """Golden from the reference's own l1_loss / ssim / combined_nir_loss (tests/golden/nir_loss.npz, generator
+    make_golden.py): value and both image gradients."""
+    import os
+
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "nir_loss.npz"))
+    image = torch.from_numpy(z["image"]).requires_grad_(True)
+    nir = torch.from_numpy(z["nir"]).requires_grad_(True)
+    crit = NirCriterion(LossOps(oracle.api))
+    total, parts = crit(image, torch.from_numpy(z["gt"]), nir, torch.from_numpy(z["nir_gt"]))
+    total.backward()
+    assert abs(float(parts["rgb"]) - float(z["rgb_loss"])) < 2e-6 and abs(float(parts["nir"]) - float(z["nir_loss"])) < 2e-6
+    assert abs(float(total) - float(z["total"])) < 3e-6
+    assert float((image.grad - torch.from_numpy(z["d_image"])).abs().max()) < 1e-7 + 2e-4 * float(np.abs(z["d_image"]).max())
+    assert float((nir.grad - torch.from_numpy(z["d_nir"])).abs().max()) < 1e-7 + 2e-4 * float(np.abs(z["d_nir"]).max())
