@@ -52,7 +52,7 @@ __device__ __forceinline__ float row_total_in_lane15(float v) {
 // view-space depth instead of its inverse and the 4th channel is the alpha image: a constant colour 1 without a
 // background term (accum_alpha_rec = last_alpha + (1 - last_alpha) accum_alpha_rec, dL_dopa += (1 - accum) dL_dalpha).
 template <bool HAS_INVDEPTH, bool HAS_EXTRA, bool FSGS>
-__global__ void __launch_bounds__(64, 3) render_bwd_wave_kernel(
+__global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) render_bwd_wave_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const Splat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
