@@ -369,6 +369,7 @@ const char* gso_build_info(void) { return "gs_oracle: CPU restatement, fp32, -ff
 
 int gso_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R, size_t out[3], size_t* bwd_ws) {
   if (!out) return GS_E_NULL;
+  if (P < 0 || W <= 0 || H <= 0 || R < 0) return GS_E_SHAPE;
   size_t T = (size_t)((W + BLOCK_X - 1) / BLOCK_X) * ((H + BLOCK_Y - 1) / BLOCK_Y);
   out[0] = geom_bytes((size_t)P);
   out[1] = img_bytes((size_t)W * H, T);
