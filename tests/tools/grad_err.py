@@ -18,6 +18,20 @@ sc = (synthetic.init_like if kind == "init" else synthetic.trained_like)(P, seed
 cam = synthetic.orbit_cameras(W, H)[3]
 g = torch.Generator().manual_seed(5)
 dL = torch.randn((3, H, W), generator=g)
+if len(sys.argv) > 6 and sys.argv[6] == "mask":  # what the parity tests do: drop pixels whose threshold decision flipped
+    from gsplat_amd import hip_backend
+    from test_gpu_raster_parity import flip_mask, forward_state
+    hb = hip_backend()
+    h0 = forward_state(hb, sc, cam, torch.device("cuda"), torch.zeros(3), False)
+    o0 = forward_state(orc.backend, sc, cam, torch.device("cpu"), torch.zeros(3), False)
+    keep = ~flip_mask(h0, o0) if h0["num_rendered"] == o0["num_rendered"] else None
+    if keep is None:
+        hb.tile_cull = False
+        h0 = forward_state(hb, sc, cam, torch.device("cuda"), torch.zeros(3), False)
+        keep = ~flip_mask(h0, o0)
+        hb.tile_cull = True
+    print("flipped pixels:", int((~keep).sum()))
+    dL = dL * keep.float()
 ho = run_scene(dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, sc, cam, torch.device("cuda"), dL_dcolor=dL)
 oo = run_scene(orc.Rasterizer, orc.Settings, sc, cam, torch.device("cpu"), dL_dcolor=dL)
 for k in oo["grads"]:
