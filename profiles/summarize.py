@@ -31,6 +31,8 @@ def short(name):
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(stats)))
+import shutil
+shutil.copyfile(stats, os.path.join(here, "%s_rocprofv3_kernel_stats_full.csv" % tag))  # the unedited summary
 with open(os.path.join(here, "%s_kernel_stats.csv" % tag), "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
