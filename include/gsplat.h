@@ -270,6 +270,14 @@ int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
  * host arithmetic on .item() values. ---- */
 int gs_l1_bwd_dev(const float* a, const float* b, int64_t n, const float* coef_dev /*[1]*/, float* grad_a,
                   int32_t accumulate, void* stream);
+/* gs_l1_fwd + gs_dwt2_l1_fwd from ONE read of the two images: l1_sum[0] += sum |pred - gt|, band_sums[8] as
+ * gs_dwt2_l1_fwd; and their two backward kernels as one write of the gradient image:
+ * grad_pred (+= if accumulate) = l1_coef_dev[0] * sign(pred - gt) + the gs_dwt2_l1_bwd term. */
+int gs_l1_dwt2_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* l1_sum,
+                   float* band_sums, void* stream);
+int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
+                   const float* l1_coef_dev /*[1]*/, const float* coef_dev /*[8]*/, float* grad_pred,
+                   int32_t accumulate, void* stream);
 /* like gs_ssim_fwd but returns sum(ssim_map) (+=, zero it first) instead of the map */
 int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1,
                     float C2, float* sum_out, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,

@@ -481,6 +481,20 @@ int gso_l1_bwd_dev(const float* a, const float* b, int64_t n, const float* coef,
   if (!a || !b || !g || !coef) return GS_E_NULL;
   return gso_l1_bwd(a, b, n, 1.0f * coef[0], g, accumulate, nullptr);
 }
+int gso_l1_dwt2_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* l1_sum, float* band_sums,
+                    void*) {
+  if (!l1_sum) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  int rc = gso_l1_fwd(pred, gt, (int64_t)C * H * W, l1_sum, nullptr);
+  return rc ? rc : gso_dwt2_l1_fwd(pred, gt, C, H, W, band_sums, nullptr);
+}
+int gso_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* l1_coef,
+                    const float* coef, float* grad, int32_t accumulate, void*) {
+  if (!l1_coef) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  int rc = gso_l1_bwd_dev(pred, gt, (int64_t)C * H * W, l1_coef, grad, accumulate, nullptr);
+  return rc ? rc : gso_dwt2_l1_bwd(pred, gt, C, H, W, coef, grad, 1, nullptr);
+}
 int gso_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1, float C2,
                      float* sum_out, float* d1, float* d2, float* d3, void*) {
   if (!sum_out) return GS_E_NULL;

@@ -151,7 +151,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
   ImgView iv = img_view(sc->img, N, T);
   SortBufs bv = sort_view(sc->binning, (size_t)cap);
 
-  launch_bin_prepare(gv, cap, s);
+  launch_bin_prepare(gv, cap, iv.ranges, (int)T, s);
   GS_LAUNCH_CHECK(s, v->debug);
   if (cap > 0) {
     {  // 1. depth order of the P Gaussians: 4 passes; pass 0 reads the keys preprocess wrote (kept intact, so the

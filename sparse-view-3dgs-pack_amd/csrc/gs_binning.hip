@@ -23,11 +23,17 @@
 #include "gs_common.h"
 #include "gs_tilecull.h"
 
-__global__ void bin_prepare_kernel(GeomHeader* hdr, uint32_t capacity) {
-  const uint32_t R = hdr->num_rendered;
-  const bool ovf = R > capacity;
-  hdr->overflow = ovf ? 1u : 0u;
-  hdr->sort_n = ovf ? 0u : R;
+// header of the binning phase + the zeroed tile ranges (tiles no instance reaches stay (0,0)) in one launch
+__global__ void __launch_bounds__(GS_BLOCK) bin_prepare_kernel(GeomHeader* hdr, uint32_t capacity, uint2* __restrict__ ranges,
+                                                               int T) {
+  const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+  if (i < T) ranges[i] = make_uint2(0u, 0u);
+  if (i == 0) {
+    const uint32_t R = hdr->num_rendered;
+    const bool ovf = R > capacity;
+    hdr->overflow = ovf ? 1u : 0u;
+    hdr->sort_n = ovf ? 0u : R;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,9 +396,10 @@ __global__ void __launch_bounds__(GS_BLOCK) tile_ranges_kernel(const uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-int launch_bin_prepare(const GeomView& g, int64_t capacity, hipStream_t s) {
+int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T, hipStream_t s) {
   uint32_t cap32 = capacity > 0xFFFFFFFFll ? 0xFFFFFFFFu : (capacity < 0 ? 0u : (uint32_t)capacity);
-  hipLaunchKernelGGL(bin_prepare_kernel, dim3(1), dim3(1), 0, s, g.hdr, cap32);
+  hipLaunchKernelGGL(bin_prepare_kernel, dim3((uint32_t)((T + GS_BLOCK - 1) / GS_BLOCK > 0 ? (T + GS_BLOCK - 1) / GS_BLOCK : 1)),
+                     dim3(GS_BLOCK), 0, s, g.hdr, cap32, ranges, T);
   return 0;
 }
 
@@ -482,8 +489,7 @@ int launch_emit_instances(const GeomView& g, int P, int grid_x, int tile_cull, c
 
 int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_bound, uint2* ranges, int T,
                        hipStream_t s) {
-  hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, s);
-  if (e != hipSuccess) return (int)e;
+  // `ranges` was zeroed by launch_bin_prepare at the start of the phase
   if (n_bound > 0)
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((uint32_t)((n_bound + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, s,
                        tkeys, n_dev, ranges);

@@ -203,7 +203,7 @@ int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_
 int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
-int launch_bin_prepare(const GeomView& g, int64_t capacity, hipStream_t s);
+int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T, hipStream_t s);
 // first_keys != NULL: the first pass reads its keys from there (left untouched) and takes value = index
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
                       const uint32_t* first_keys, hipStream_t s, int debug);

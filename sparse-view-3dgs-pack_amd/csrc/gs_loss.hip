@@ -131,20 +131,45 @@ __global__ void __launch_bounds__(GS_BLOCK) dwt_bwd_kernel(const float* dll, con
 // ------------------------------------------------------------------------------------------------ fused 2-level DWT L1
 // One thread per level-2 coefficient = a 4x4 pixel block of one channel.  It forms the four level-1
 // blocks (bands of pred and gt separately, as the reference does) and the level-2 block of their LL1.
+// The same 16 pixels also give the plain L1 term (loss_utils.py:40-41) for free, so the fused criterion gets both
+// from one read of the two images.  FAST (H, W multiples of 4, 16-byte aligned rows) moves whole float4 rows.
+struct Px44 {
+  float v[4][4];  // [row][col] of the 4x4 pixel block (padding already replicated)
+};
 struct Blk44 {
   float l1[2][2][4];  // [r][c][band] level-1 bands (r,c = position inside the level-2 block)
   float l2[4];
 };
-__device__ __forceinline__ void load_blk44(const float* __restrict__ p, int H, int W, int i2, int j2, int h1, int w1,
-                                           Blk44& o) {
+template <bool FAST>
+__device__ __forceinline__ void load_px44(const float* __restrict__ p, int H, int W, int i2, int j2, int h1, int w1,
+                                          Px44& o) {
+  if (FAST) {
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      const float4 q = reinterpret_cast<const float4*>(p + (size_t)(4 * i2 + y) * W)[j2];
+      o.v[y][0] = q.x; o.v[y][1] = q.y; o.v[y][2] = q.z; o.v[y][3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int r1 = min(2 * i2 + r, h1 - 1), c1 = min(2 * j2 + c, w1 - 1);  // symmetric repeat of LL1's last sample
+        const int y0 = 2 * r1, y1 = min(2 * r1 + 1, H - 1), x0 = 2 * c1, x1 = min(2 * c1 + 1, W - 1);
+        o.v[2 * r][2 * c] = p[(size_t)y0 * W + x0];
+        o.v[2 * r][2 * c + 1] = p[(size_t)y0 * W + x1];
+        o.v[2 * r + 1][2 * c] = p[(size_t)y1 * W + x0];
+        o.v[2 * r + 1][2 * c + 1] = p[(size_t)y1 * W + x1];
+      }
+  }
+}
+__device__ __forceinline__ void bands_of(const Px44& x, Blk44& o) {
   float ll[2][2];
 #pragma unroll
   for (int r = 0; r < 2; r++)
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      const int r1 = min(2 * i2 + r, h1 - 1), c1 = min(2 * j2 + c, w1 - 1);  // symmetric repeat of LL1's last sample
-      const int y0 = 2 * r1, y1 = min(2 * r1 + 1, H - 1), x0 = 2 * c1, x1 = min(2 * c1 + 1, W - 1);
-      const Bands b = haar_block(p[(size_t)y0 * W + x0], p[(size_t)y0 * W + x1], p[(size_t)y1 * W + x0], p[(size_t)y1 * W + x1]);
+      const Bands b = haar_block(x.v[2 * r][2 * c], x.v[2 * r][2 * c + 1], x.v[2 * r + 1][2 * c], x.v[2 * r + 1][2 * c + 1]);
       o.l1[r][c][0] = b.ll; o.l1[r][c][1] = b.lh; o.l1[r][c][2] = b.hl; o.l1[r][c][3] = b.hh;
       ll[r][c] = b.ll;
     }
@@ -152,83 +177,142 @@ __device__ __forceinline__ void load_blk44(const float* __restrict__ p, int H, i
   o.l2[0] = b2.ll; o.l2[1] = b2.lh; o.l2[2] = b2.hl; o.l2[3] = b2.hh;
 }
 
+// sums[0..7] += band L1 sums; sums[8] (only when l1_sum != nullptr, added there) += sum |pred - gt|
+template <bool FAST>
 __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                               int C, int H, int W, float* band_sums) {
+                                                               int C, int H, int W, float* band_sums, float* l1_sum) {
   const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
   const int64_t total = (int64_t)C * h2 * w2;
-  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t o = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; o < total; o += (int64_t)gridDim.x * GS_BLOCK) {
     const int j2 = (int)(o % w2), i2 = (int)((o / w2) % h2), c = (int)(o / ((int64_t)w2 * h2));
+    Px44 pa, pb;
+    load_px44<FAST>(pred + (size_t)c * H * W, H, W, i2, j2, h1, w1, pa);
+    load_px44<FAST>(gt + (size_t)c * H * W, H, W, i2, j2, h1, w1, pb);
     Blk44 a, b;
-    load_blk44(pred + (size_t)c * H * W, H, W, i2, j2, h1, w1, a);
-    load_blk44(gt + (size_t)c * H * W, H, W, i2, j2, h1, w1, b);
+    bands_of(pa, a);
+    bands_of(pb, b);
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
       for (int cc = 0; cc < 2; cc++)
-        if (2 * i2 + r < h1 && 2 * j2 + cc < w1) {
+        if (FAST || (2 * i2 + r < h1 && 2 * j2 + cc < w1)) {
 #pragma unroll
           for (int k = 0; k < 4; k++) s[k] += fabsf(a.l1[r][cc][k] - b.l1[r][cc][k]);
         }
 #pragma unroll
     for (int k = 0; k < 4; k++) s[4 + k] += fabsf(a.l2[k] - b.l2[k]);
+    if (l1_sum) {
+#pragma unroll
+      for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+          if (FAST || (4 * i2 + y < H && 4 * j2 + x < W)) s[8] += fabsf(pa.v[y][x] - pb.v[y][x]);
+    }
   }
-  block_sum_atomic<8>(s, band_sums);
+  if (l1_sum) {
+    // the nine sums go to two places: fold the L1 one through the same reduction, then route it
+    __shared__ float red9[GS_BLOCK / 64][9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      float x = s[k];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+      if ((threadIdx.x & 63) == 0) red9[threadIdx.x >> 6][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+      float t = 0.f;
+      for (int w = 0; w < GS_BLOCK / 64; w++) t += red9[w][threadIdx.x];
+      if (t != 0.f) atomicAdd(threadIdx.x < 8 ? &band_sums[threadIdx.x] : l1_sum, t);
+    }
+  } else {
+    float s8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s8[k] = s[k];
+    block_sum_atomic<8>(s8, band_sums);
+  }
 }
 
+// grad (+= if accumulate) = DWT adjoint of the band signs (coef[8]) [+ l1_coef[0] * sign(pred - gt)]
+template <bool FAST>
 __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                                                int C, int H, int W, const float* __restrict__ coef,
-                                                               float* __restrict__ grad, int accumulate) {
+                                                               const float* __restrict__ l1_coef, float* __restrict__ grad,
+                                                               int accumulate) {
   const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
   const int64_t total = (int64_t)C * h2 * w2;
   float cf[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) cf[k] = coef[k];
+  const float c1l = l1_coef ? l1_coef[0] : 0.f;
   for (int64_t o = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; o < total; o += (int64_t)gridDim.x * GS_BLOCK) {
     const int j2 = (int)(o % w2), i2 = (int)((o / w2) % h2), c = (int)(o / ((int64_t)w2 * h2));
+    Px44 pa, pb;
+    load_px44<FAST>(pred + (size_t)c * H * W, H, W, i2, j2, h1, w1, pa);
+    load_px44<FAST>(gt + (size_t)c * H * W, H, W, i2, j2, h1, w1, pb);
     Blk44 a, b;
-    load_blk44(pred + (size_t)c * H * W, H, W, i2, j2, h1, w1, a);
-    load_blk44(gt + (size_t)c * H * W, H, W, i2, j2, h1, w1, b);
+    bands_of(pa, a);
+    bands_of(pb, b);
     // level-2 adjoint -> gradient of the four LL1 inputs (padded duplicates fold onto the last sample)
     float dl[2][2];
     {
       float da, db, dc, dd;
       haar_block_adj(cf[4] * sgnf(a.l2[0] - b.l2[0]), cf[5] * sgnf(a.l2[1] - b.l2[1]), cf[6] * sgnf(a.l2[2] - b.l2[2]),
                      cf[7] * sgnf(a.l2[3] - b.l2[3]), da, db, dc, dd);
-      const bool pr = 2 * i2 + 1 >= h1, pc = 2 * j2 + 1 >= w1;
+      const bool pr = !FAST && 2 * i2 + 1 >= h1, pc = !FAST && 2 * j2 + 1 >= w1;
       dl[0][0] = da; dl[0][1] = db; dl[1][0] = dc; dl[1][1] = dd;
       if (pr && pc) { dl[0][0] = ((da + db) + dc) + dd; }
       else if (pr) { dl[0][0] = da + dc; dl[0][1] = db + dd; }
       else if (pc) { dl[0][0] = da + db; dl[1][0] = dc + dd; }
     }
     float* gp = grad + (size_t)c * H * W;
+    float out[4][4];
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
       for (int cc = 0; cc < 2; cc++) {
         const int r1 = 2 * i2 + r, c1 = 2 * j2 + cc;
-        if (r1 >= h1 || c1 >= w1) continue;
+        if (!FAST && (r1 >= h1 || c1 >= w1)) continue;
         float da, db, dc, dd;
         haar_block_adj(cf[0] * sgnf(a.l1[r][cc][0] - b.l1[r][cc][0]) + dl[r][cc], cf[1] * sgnf(a.l1[r][cc][1] - b.l1[r][cc][1]),
                        cf[2] * sgnf(a.l1[r][cc][2] - b.l1[r][cc][2]), cf[3] * sgnf(a.l1[r][cc][3] - b.l1[r][cc][3]), da, db,
                        dc, dd);
         const int y0 = 2 * r1, x0 = 2 * c1;
-        const bool py = y0 + 1 >= H, pxp = x0 + 1 >= W;
+        const bool py = !FAST && y0 + 1 >= H, pxp = !FAST && x0 + 1 >= W;
         float v00 = da, v01 = db, v10 = dc, v11 = dd;
         if (py && pxp) v00 = ((da + db) + dc) + dd;
         else if (py) { v00 = da + dc; v01 = db + dd; }
         else if (pxp) { v00 = da + db; v10 = dc + dd; }
-        float* q = gp + (size_t)y0 * W + x0;
-        if (accumulate) {
-          q[0] += v00;
-          if (!pxp) q[1] += v01;
-          if (!py) { q[W] += v10; if (!pxp) q[W + 1] += v11; }
+        // the plain-L1 gradient lands on the real pixels only (r1, c1 are not clamped here, so pa holds them)
+        v00 += c1l * sgnf(pa.v[2 * r][2 * cc] - pb.v[2 * r][2 * cc]);
+        v01 += c1l * sgnf(pa.v[2 * r][2 * cc + 1] - pb.v[2 * r][2 * cc + 1]);
+        v10 += c1l * sgnf(pa.v[2 * r + 1][2 * cc] - pb.v[2 * r + 1][2 * cc]);
+        v11 += c1l * sgnf(pa.v[2 * r + 1][2 * cc + 1] - pb.v[2 * r + 1][2 * cc + 1]);
+        if (FAST) {
+          out[2 * r][2 * cc] = v00; out[2 * r][2 * cc + 1] = v01; out[2 * r + 1][2 * cc] = v10; out[2 * r + 1][2 * cc + 1] = v11;
         } else {
-          q[0] = v00;
-          if (!pxp) q[1] = v01;
-          if (!py) { q[W] = v10; if (!pxp) q[W + 1] = v11; }
+          float* q = gp + (size_t)y0 * W + x0;
+          if (accumulate) {
+            q[0] += v00;
+            if (!pxp) q[1] += v01;
+            if (!py) { q[W] += v10; if (!pxp) q[W + 1] += v11; }
+          } else {
+            q[0] = v00;
+            if (!pxp) q[1] = v01;
+            if (!py) { q[W] = v10; if (!pxp) q[W + 1] = v11; }
+          }
         }
       }
+    if (FAST) {
+#pragma unroll
+      for (int y = 0; y < 4; y++) {
+        float4* q = reinterpret_cast<float4*>(gp + (size_t)(4 * i2 + y) * W) + j2;
+        float4 v = make_float4(out[y][0], out[y][1], out[y][2], out[y][3]);
+        if (accumulate) { const float4 old = *q; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+        *q = v;
+      }
+    }
   }
 }
 
@@ -556,16 +640,39 @@ int gs_dwt_haar_bwd(const float* dll, const float* dlh, const float* dhl, const 
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
+static inline bool dwt2_fast(const void* a, const void* b, const void* g, int H, int W) {
+  return (H % 4) == 0 && (W % 4) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)g) & 15) == 0);
+}
+static int dwt2_l1_fwd_launch(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* band_sums,
+                              float* l1_sum, hipStream_t s) {
+  const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
+  const dim3 grid(nblocks((int64_t)C * h2 * w2, GS_BLOCK, 4096));
+  if (dwt2_fast(pred, gt, nullptr, H, W))
+    hipLaunchKernelGGL(dwt2_l1_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum);
+  else
+    hipLaunchKernelGGL(dwt2_l1_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+static int dwt2_l1_bwd_launch(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* coef_dev,
+                              const float* l1_coef_dev, float* grad_pred, int32_t accumulate, hipStream_t s) {
+  const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
+  const dim3 grid(nblocks((int64_t)C * h2 * w2));
+  if (dwt2_fast(pred, gt, grad_pred, H, W))
+    hipLaunchKernelGGL(dwt2_l1_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, coef_dev, l1_coef_dev,
+                       grad_pred, accumulate);
+  else
+    hipLaunchKernelGGL(dwt2_l1_bwd_kernel<false>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, coef_dev, l1_coef_dev,
+                       grad_pred, accumulate);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
 int gs_dwt2_l1_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* band_sums, void* stream) {
   if (!pred || !gt || !band_sums) return GS_E_NULL;
   if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_DWT2_FWD, s);
-  const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
-  hipLaunchKernelGGL(dwt2_l1_fwd_kernel, dim3(nblocks((int64_t)C * h2 * w2, GS_BLOCK, 4096)), dim3(GS_BLOCK), 0, s, pred, gt,
-                     C, H, W, band_sums);
-  GS_LAUNCH_CHECK(s, 0);
-  return GS_OK;
+  return dwt2_l1_fwd_launch(pred, gt, C, H, W, band_sums, nullptr, s);
 }
 int gs_dwt2_l1_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* coef_dev,
                    float* grad_pred, int32_t accumulate, void* stream) {
@@ -573,11 +680,23 @@ int gs_dwt2_l1_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int
   if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_DWT2_BWD, s);
-  const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
-  hipLaunchKernelGGL(dwt2_l1_bwd_kernel, dim3(nblocks((int64_t)C * h2 * w2)), dim3(GS_BLOCK), 0, s, pred, gt, C, H, W,
-                     coef_dev, grad_pred, accumulate);
-  GS_LAUNCH_CHECK(s, 0);
-  return GS_OK;
+  return dwt2_l1_bwd_launch(pred, gt, C, H, W, coef_dev, nullptr, grad_pred, accumulate, s);
+}
+int gs_l1_dwt2_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* l1_sum, float* band_sums,
+                   void* stream) {
+  if (!pred || !gt || !band_sums || !l1_sum) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT2_FWD, s);
+  return dwt2_l1_fwd_launch(pred, gt, C, H, W, band_sums, l1_sum, s);
+}
+int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* l1_coef_dev,
+                   const float* coef_dev, float* grad_pred, int32_t accumulate, void* stream) {
+  if (!pred || !gt || !coef_dev || !l1_coef_dev || !grad_pred) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT2_BWD, s);
+  return dwt2_l1_bwd_launch(pred, gt, C, H, W, coef_dev, l1_coef_dev, grad_pred, accumulate, s);
 }
 int gs_elf_map(const float* img, int32_t C, int32_t H, int32_t W, float* elf_low, float* elf, void* stream) {
   if (!img || !elf || !elf_low) return GS_E_NULL;

@@ -236,7 +236,7 @@ class FusedLGDWTLoss(torch.autograd.Function):
 
     forward : clamp(0,1) -> L1 sum, SSIM sum (+ the three derivative maps), eight DWT band sums, three patch sums
               -> gs_lgdwt_combine (loss, running-mean DWT scale and the backward coefficients, all on the device)
-    backward: four kernels accumulate into ONE image-gradient buffer; the last one folds in the clamp mask.
+    backward: three kernels accumulate into ONE image-gradient buffer; the last one folds in the clamp mask.
     No torch elementwise pass over an image, no host synchronisation."""
 
     @staticmethod
@@ -248,11 +248,12 @@ class FusedLGDWTLoss(torch.autograd.Function):
         st = _stream(raw)
         sums = torch.zeros((16,), dtype=torch.float32, device=raw.device)
         d1, d2, d3 = torch.empty_like(raw), torch.empty_like(raw), torch.empty_like(raw)
-        api.call("l1_fwd", img.data_ptr(), gt.data_ptr(), img.numel(), sums.data_ptr(), st)
+        if params.dwt_enable:   # L1 and the eight band sums from one read of the two images
+            api.call("l1_dwt2_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, sums.data_ptr(), sums[2:].data_ptr(), st)
+        else:
+            api.call("l1_fwd", img.data_ptr(), gt.data_ptr(), img.numel(), sums.data_ptr(), st)
         api.call("ssim_fwd_sum", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, 0.01 ** 2, 0.03 ** 2,
                  sums[1:].data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), st)
-        if params.dwt_enable:
-            api.call("dwt2_l1_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, sums[2:].data_ptr(), st)
         if params.patch_enable:
             api.call("patch_dwt_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
                      sums[10:].data_ptr(), st)
@@ -262,19 +263,24 @@ class FusedLGDWTLoss(torch.autograd.Function):
         ctx.ops, ctx.params = ops, params
         ctx.save_for_backward(raw, img, gt, mask, d1, d2, d3, out)
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)   # no zero tensor for the unused gradient of `out`
         return out[0], out
 
     @staticmethod
     def backward(ctx, g, _gout):
         raw, img, gt, mask, d1, d2, d3, out = ctx.saved_tensors
+        if g is None:
+            return (None,) * 7
         api, params = ctx.ops.api, ctx.params
         Cc, H, W = raw.shape
         st = _stream(raw)
         coef = (out[8:24] * g).contiguous()   # [c_l1, c_ssim, c_band x8, c_patch x3, ...] x upstream
         grad = torch.empty_like(raw)
-        api.call("l1_bwd_dev", img.data_ptr(), gt.data_ptr(), img.numel(), coef.data_ptr(), grad.data_ptr(), 0, st)
         if params.dwt_enable:
-            api.call("dwt2_l1_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, coef[2:].data_ptr(), grad.data_ptr(), 1, st)
+            api.call("l1_dwt2_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, coef.data_ptr(), coef[2:].data_ptr(),
+                     grad.data_ptr(), 0, st)
+        else:
+            api.call("l1_bwd_dev", img.data_ptr(), gt.data_ptr(), img.numel(), coef.data_ptr(), grad.data_ptr(), 0, st)
         if params.patch_enable:
             api.call("patch_dwt_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
                      coef[10:].data_ptr(), grad.data_ptr(), 1, st)
@@ -335,6 +341,7 @@ class LGDWTCriterion:
     def elf_mask(self, gt_image):
         elf = self.ops.compute_elf_map(gt_image.unsqueeze(0))
         mask, _ = self.ops.patch_mask(elf, self.patch_size, self.patch_percentile)
+        mask._gs_n_sel = mask.sum().to(torch.float32).reshape(1)   # travels with the (per-camera, cached) mask
         return mask
 
     def fused_call(self, raw_image, gt_image, mask=None):

@@ -156,10 +156,13 @@ class RasterBackend:
         P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
         f32 = dict(dtype=torch.float32, device=device)
         u8 = dict(dtype=torch.uint8, device=device)
-        out_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
-        out_invdepth = torch.zeros((1, H, W), **f32)
-        radii = torch.zeros((P,), dtype=torch.int32, device=device)
-        out_extra = None if (extra is None and not fsgs) else torch.zeros((1, H, W), **f32)
+        # every pixel and every radius is written by the kernels (gs_forward_geometry / gs_forward_render): empty, not
+        # zeros - the reference's three fills (rasterize_points.cu:71-75) are only needed for P == 0
+        alloc = torch.empty if P != 0 else torch.zeros
+        out_color = alloc((NUM_CHANNELS, H, W), **f32)
+        out_invdepth = alloc((1, H, W), **f32)
+        radii = alloc((P,), dtype=torch.int32, device=device)
+        out_extra = None if (extra is None and not fsgs) else alloc((1, H, W), **f32)
         tail = () if out_extra is None else (out_extra,)
         if P == 0:  # rasterize_points.cu:88
             e = torch.empty((0,), **u8)

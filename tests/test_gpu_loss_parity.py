@@ -114,3 +114,25 @@ def test_fused_criterion_hip_vs_oracle(ops_pair, H, W):
         close(lh, lo, 1e-5, "fused loss")
         close(ph["dwt_scale"], po["dwt_scale"], 1e-5, "dwt scale")
         close(rh.grad, ro.grad, 5e-5, "fused dL/draw")
+
+
+@pytest.mark.parametrize("H,W,acc", [(64, 96, 0), (64, 96, 1), (37, 53, 1), (131, 260, 0), (1080, 1920, 0)])
+def test_l1_dwt2_one_pass_equals_the_two_kernels_and_the_oracle(hip, oracle, H, W, acc):
+    """gs_l1_dwt2_fwd / _bwd (one read of the images) against gs_l1_* + gs_dwt2_l1_* of the oracle, on the float4
+    path (sizes divisible by 4) and on the padded generic path."""
+    pred, gt = images(H, W, 3 * H + W)
+    g = torch.Generator().manual_seed(5)
+    coef = torch.rand((9,), generator=g) / (H * W)          # [c_l1, c_band x8]
+    g0 = torch.randn((3, H, W), generator=g) * 1e-6
+    out = {}
+    for name, api, dev in (("hip", hip.api, "cuda"), ("oracle", oracle.api, "cpu")):
+        p, t, c, gr = pred.to(dev), gt.to(dev), coef.to(dev), g0.to(dev).clone()
+        sums = torch.zeros((9,), device=dev)
+        st = torch.cuda.current_stream().cuda_stream if dev == "cuda" else None
+        api.call("l1_dwt2_fwd", p.data_ptr(), t.data_ptr(), 3, H, W, sums.data_ptr(), sums[1:].data_ptr(), st)
+        api.call("l1_dwt2_bwd", p.data_ptr(), t.data_ptr(), 3, H, W, c.data_ptr(), c[1:].data_ptr(), gr.data_ptr(), acc, st)
+        out[name] = (sums.cpu(), gr.cpu())
+    close(out["hip"][0], out["oracle"][0], 1e-5, "sums")
+    for k in range(9):
+        assert abs(float(out["hip"][0][k]) - float(out["oracle"][0][k])) <= 1e-5 * float(out["oracle"][0][k]), k
+    close(out["hip"][1], out["oracle"][1], 2e-5, "grad")
