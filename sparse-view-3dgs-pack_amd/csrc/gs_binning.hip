@@ -61,22 +61,6 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_hist_kernel(const uint32_t* __res
   hist[(size_t)tid * nblk + blockIdx.x] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
 }
 
-// generic exclusive scan of u32 data[n] (n known on host): reduce / scan-of-sums / downsweep
-__global__ void __launch_bounds__(GS_BLOCK) scan_reduce_kernel(const uint32_t* __restrict__ data, uint32_t n,
-                                                               uint32_t* __restrict__ sums) {
-  __shared__ uint32_t red[GS_BLOCK / 64];
-  const uint32_t t0 = blockIdx.x * RS_TILE;
-  uint32_t v = 0;
-  const uint32_t i0 = t0 + threadIdx.x * RS_ITEMS;
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++)
-    if (i0 + r < n) v += data[i0 + r];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
 // in-place exclusive scan of sums[nb] by ONE workgroup; total -> sums[nb]
 __global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t* sums, int nb) {
   __shared__ uint32_t wsum[16];
@@ -105,33 +89,44 @@ __global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t* sums, int nb)
   }
   if (tid == 0) sums[nb] = carry_s;
 }
-__global__ void __launch_bounds__(GS_BLOCK) scan_down_kernel(uint32_t* __restrict__ data, uint32_t n,
-                                                             const uint32_t* __restrict__ sums) {
+// (b) of a radix pass in ONE launch: workgroup d scans row d of the digit-major table in place (exclusive, over
+// the workgroups of the sort) and stores the row total; the scatter kernel adds the exclusive scan of the 256
+// totals itself.  (The generic three-kernel scan of the whole table cost two more launches per pass.)
+__global__ void __launch_bounds__(GS_BLOCK) rs_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblk,
+                                                              uint32_t* __restrict__ totals) {
+  constexpr int IT = 8;
   __shared__ uint32_t wsum[GS_BLOCK / 64];
+  uint32_t* row = hist + (size_t)blockIdx.x * nblk;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t i0 = blockIdx.x * RS_TILE + tid * RS_ITEMS;
-  uint32_t v[RS_ITEMS];
-  uint32_t tsum = 0;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nblk; base += GS_BLOCK * IT) {
+    const uint32_t i0 = base + tid * IT;
+    uint32_t v[IT];
+    uint32_t tsum = 0;
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    v[r] = (i0 + r < n) ? data[i0 + r] : 0u;
-    tsum += v[r];
-  }
-  uint32_t inc = tsum;
+    for (int r = 0; r < IT; r++) {
+      v[r] = (i0 + r < nblk) ? row[i0 + r] : 0u;
+      tsum += v[r];
+    }
+    uint32_t inc = tsum;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) wsum[wid] = inc;
-  __syncthreads();
-  uint32_t run = sums[blockIdx.x] + inc - tsum;
-  for (int w = 0; w < wid; w++) run += wsum[w];
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t run = carry + inc - tsum;
+    for (int w = 0; w < wid; w++) run += wsum[w];
+    carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    if (i0 + r < n) data[i0 + r] = run;
-    run += v[r];
+    for (int r = 0; r < IT; r++) {
+      if (i0 + r < nblk) row[i0 + r] = run;
+      run += v[r];
+    }
+    __syncthreads();
   }
+  if (tid == 0) totals[blockIdx.x] = carry;
 }
 
 // Stable scatter.  Phase 1: every wave ranks its 1024 keys in 16 rounds of 64 with wave-level
@@ -142,7 +137,8 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ vin,  // NULL: value = index
                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                               const uint32_t* n_dev, int shift,
-                                                              const uint32_t* __restrict__ hist, uint32_t nblk) {
+                                                              const uint32_t* __restrict__ hist, uint32_t nblk,
+                                                              const uint32_t* __restrict__ totals) {
   __shared__ uint32_t s_hist[GS_BLOCK / 64][RS_RADIX];  // phase 1: wave digit counts; phase 3: output bases
   const uint32_t n = *n_dev;
   const uint32_t t0 = blockIdx.x * RS_TILE;
@@ -180,21 +176,33 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __
   __shared__ uint32_t s_loc[RS_RADIX];    // local start of each digit's run inside the 4096-key tile
   __shared__ uint32_t s_delta[RS_RADIX];  // global start - local start
   __shared__ uint32_t s_wtot[GS_BLOCK / 64];
+  __shared__ uint32_t s_gtot[GS_BLOCK / 64];
   {
     const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid], c3 = s_hist[3][tid];
     const uint32_t tot = c0 + c1 + c2 + c3;
-    uint32_t inc = tot;
+    const uint32_t gt = totals[tid];  // keys of digit `tid` in the whole array -> start of the digit = scan over digits
+    uint32_t inc = tot, ginc = gt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
+      const uint32_t g = __shfl_up(ginc, off, 64);
+      if (lane >= off) {
+        inc += t;
+        ginc += g;
+      }
     }
-    if (lane == 63) s_wtot[wid] = inc;
+    if (lane == 63) {
+      s_wtot[wid] = inc;
+      s_gtot[wid] = ginc;
+    }
     __syncthreads();
-    uint32_t loc = inc - tot;
-    for (int w = 0; w < wid; w++) loc += s_wtot[w];
+    uint32_t loc = inc - tot, gbase = ginc - gt;
+    for (int w = 0; w < wid; w++) {
+      loc += s_wtot[w];
+      gbase += s_gtot[w];
+    }
     s_loc[tid] = loc;
-    s_delta[tid] = hist[(size_t)tid * nblk + blockIdx.x] - loc;
+    s_delta[tid] = gbase + hist[(size_t)tid * nblk + blockIdx.x] - loc;
     s_hist[0][tid] = loc;
     s_hist[1][tid] = loc + c0;
     s_hist[2][tid] = loc + c0 + c1;
@@ -403,60 +411,11 @@ int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T
   return 0;
 }
 
-// exclusive scan of a small table by ONE workgroup (1024 threads x 16 items per round): one launch instead of three
-__global__ void __launch_bounds__(1024) scan_small_kernel(uint32_t* __restrict__ data, uint32_t n) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n; base += 1024 * 16) {
-    const uint32_t i0 = base + tid * 16;
-    uint32_t v[16];
-    uint32_t tsum = 0;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      v[r] = (i0 + r < n) ? data[i0 + r] : 0u;
-      tsum += v[r];
-    }
-    uint32_t inc = tsum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    if (lane == 63) wsum[wid] = inc;
-    __syncthreads();
-    uint32_t run = carry_s + inc - tsum;
-    for (int w = 0; w < wid; w++) run += wsum[w];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      if (i0 + r < n) data[i0 + r] = run;
-      run += v[r];
-    }
-    __syncthreads();
-    if (tid == 1023) carry_s = run;
-    __syncthreads();
-  }
-}
-
-static void exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* tmp, hipStream_t s) {
-  if (n <= 1024 * 16) {  // one round of one workgroup (measured: at 4 rounds the three-kernel scan is already faster)
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, s, data, n);
-    return;
-  }
-  const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, data, n, tmp);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, tmp, (int)nb);
-  hipLaunchKernelGGL(scan_down_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, data, n, tmp);
-}
-
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound, int end_bit, int start_buf,
                       const uint32_t* first_keys, hipStream_t s, int debug) {
   int cur = start_buf;
   if (n_bound <= 0) return 0;
   const uint32_t nblk = (uint32_t)((n_bound + RS_TILE - 1) / RS_TILE);
-  const uint32_t hist_n = nblk * RS_RADIX;
   bool first = true;
   for (int shift = 0; shift < end_bit; shift += RS_BITS) {
     const bool ext = first && first_keys != nullptr;
@@ -464,10 +423,10 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
     const uint32_t* vin = ext ? nullptr : b.vals[cur];
     hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, n_dev, shift, b.hist, nblk);
     GS_LAUNCH_CHECK(s, debug);
-    exclusive_scan_u32(b.hist, hist_n, b.scan_tmp, s);
+    hipLaunchKernelGGL(rs_rowscan_kernel, dim3(RS_RADIX), dim3(GS_BLOCK), 0, s, b.hist, nblk, b.scan_tmp);
     GS_LAUNCH_CHECK(s, debug);
     hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, vin, b.keys[cur ^ 1],
-                       b.vals[cur ^ 1], n_dev, shift, b.hist, nblk);
+                       b.vals[cur ^ 1], n_dev, shift, b.hist, nblk, b.scan_tmp);
     GS_LAUNCH_CHECK(s, debug);
     cur ^= 1;
     first = false;

@@ -61,14 +61,13 @@ struct SortBufs {
   uint32_t* keys[2];
   uint32_t* vals[2];
   uint32_t* hist;      // [RS_RADIX][nblk] digit-major workgroup histograms
-  uint32_t* scan_tmp;  // workgroup sums of the histogram scan
+  uint32_t* scan_tmp;  // [RS_RADIX] digit totals of the current pass (rs_rowscan_kernel)
 };
 static inline __host__ __device__ size_t sort_bytes(size_t cap) {
   if (cap == 0) cap = 1;
   size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
   size_t hist_n = nblk * RS_RADIX;
-  size_t nscan = (hist_n + RS_TILE - 1) / RS_TILE;
-  return 4 * gs_align(4 * cap) + gs_align(4 * hist_n) + gs_align(4 * (nscan + 1));
+  return 4 * gs_align(4 * cap) + gs_align(4 * hist_n) + gs_align(4 * RS_RADIX);
 }
 static inline __host__ __device__ SortBufs sort_view(void* buf, size_t cap) {
   if (cap == 0) cap = 1;
@@ -76,13 +75,12 @@ static inline __host__ __device__ SortBufs sort_view(void* buf, size_t cap) {
   SortBufs b;
   size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
   size_t hist_n = nblk * RS_RADIX;
-  size_t nscan = (hist_n + RS_TILE - 1) / RS_TILE;
   b.keys[0] = (uint32_t*)p; p += gs_align(4 * cap);
   b.keys[1] = (uint32_t*)p; p += gs_align(4 * cap);
   b.vals[0] = (uint32_t*)p; p += gs_align(4 * cap);
   b.vals[1] = (uint32_t*)p; p += gs_align(4 * cap);
   b.hist = (uint32_t*)p; p += gs_align(4 * hist_n);
-  b.scan_tmp = (uint32_t*)p; p += gs_align(4 * (nscan + 1));
+  b.scan_tmp = (uint32_t*)p; p += gs_align(4 * RS_RADIX);
   return b;
 }
 
