@@ -434,6 +434,9 @@ __constant__ float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.03
 // column tid % 32.
 template <int NQ, bool FWD>
 __device__ __forceinline__ void ssim_conv_tile(const float (*tile)[SH][SH + 1], float (*hor)[SH][HS], float (&out)[4][NQ]) {
+  // the taps contract to FMAs here although the file is built with -ffp-contract=off: nvcc contracts the reference's
+  // `sum += G * val` (fused-ssim/ssim.cu:60-100) the same way, and the kernel is VALU-issue-bound (half the instructions)
+#pragma clang fp contract(fast)
   for (int item = threadIdx.x; item < SH * (ST / 4); item += GS_BLOCK) {
     const int r = item / (ST / 4), c0 = (item % (ST / 4)) * 4;
     float acc[4][NQ];
@@ -495,16 +498,29 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
   __shared__ float hor[5][SH][HS];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
-  for (int k = threadIdx.x; k < SH * SH; k += GS_BLOCK) {
-    const int r = k / SH, c = k % SH;
-    const int y = by + r - 5, x = bx + c - 5;
-    float a = 0.f, b = 0.f;
-    if (x >= 0 && x < W && y >= 0 && y < H) {
-      a = img1[plane + (size_t)y * W + x];
-      b = img2[plane + (size_t)y * W + x];
+  {  // all global loads of the halo tile are in flight before the first LDS store (a rolled loop waits per round)
+    constexpr int NIT = (SH * SH + GS_BLOCK - 1) / GS_BLOCK;
+    float a[NIT], b[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int k = threadIdx.x + it * GS_BLOCK;
+      const int r = k / SH, c = k % SH;
+      const int y = by + r - 5, x = bx + c - 5;
+      a[it] = 0.f;
+      b[it] = 0.f;
+      if (k < SH * SH && x >= 0 && x < W && y >= 0 && y < H) {
+        a[it] = img1[plane + (size_t)y * W + x];
+        b[it] = img2[plane + (size_t)y * W + x];
+      }
     }
-    tile[0][r][c] = a;
-    tile[1][r][c] = b;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int k = threadIdx.x + it * GS_BLOCK;
+      if (k < SH * SH) {
+        tile[0][k / SH][k % SH] = a[it];
+        tile[1][k / SH][k % SH] = b[it];
+      }
+    }
   }
   __syncthreads();
   float out[4][5];
@@ -525,14 +541,18 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
     const float A = (mu1_sq + mu2_sq + C1);
     const float B = (sigma1_sq + sigma2_sq + C2);
     const size_t o = plane + (size_t)y * W + x;
-    const float mval = (Cc * D) / (A * B);
+    // fused-ssim/ssim.cu:140-160 with ONE division: 1/(AB), 1/A = B/(AB), 1/B = A/(AB) (the reference divides seven
+    // times per pixel; an IEEE division is ~10 VALU instructions and this kernel is issue-bound) - a few ulp apart
+    const float inv_AB = 1.0f / (A * B);
+    const float inv_A = B * inv_AB, inv_B = A * inv_AB;
+    const float mval = (Cc * D) * inv_AB;
     msum += mval;
     if (ssim_map) ssim_map[o] = mval;
     if (dm_dmu1) {
-      dm_dmu1[o] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * Cc) / (A * B) - (mu1 * 2.0f * Cc * D) / (A * A * B) +
-                    (mu1 * 2.0f * Cc * D) / (A * B * B));
-      dm_dsigma1_sq[o] = ((-Cc * D) / (A * B * B));
-      dm_dsigma12[o] = ((2 * Cc) / (A * B));
+      dm_dmu1[o] = (mu2 * 2.0f * D) * inv_AB - (mu2 * 2.0f * Cc) * inv_AB - (mu1 * 2.0f * Cc * D) * inv_AB * inv_A +
+                   (mu1 * 2.0f * Cc * D) * inv_AB * inv_B;
+      dm_dsigma1_sq[o] = (-Cc * D) * inv_AB * inv_B;
+      dm_dsigma12[o] = (2 * Cc) * inv_AB;
     }
   }
   if (sum_out) {  // uniform branch: mean SSIM without a second pass over the map
@@ -554,20 +574,32 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
   __shared__ float hor[3][SH][HS];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
-  for (int k = threadIdx.x; k < SH * SH; k += GS_BLOCK) {
-    const int r = k / SH, c = k % SH;
-    const int y = by + r - 5, x = bx + c - 5;
-    float g = 0.f, a = 0.f, b = 0.f, d = 0.f;
-    if (x >= 0 && x < W && y >= 0 && y < H) {
-      const size_t o = plane + (size_t)y * W + x;
-      g = dL_dmap ? dL_dmap[o] : gu;
-      a = dm_dmu1[o];
-      b = dm_dsigma1_sq[o];
-      d = dm_dsigma12[o];
+  {
+    constexpr int NIT = (SH * SH + GS_BLOCK - 1) / GS_BLOCK;
+    float g[NIT], a[NIT], b[NIT], d[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int k = threadIdx.x + it * GS_BLOCK;
+      const int r = k / SH, c = k % SH;
+      const int y = by + r - 5, x = bx + c - 5;
+      g[it] = a[it] = b[it] = d[it] = 0.f;
+      if (k < SH * SH && x >= 0 && x < W && y >= 0 && y < H) {
+        const size_t o = plane + (size_t)y * W + x;
+        g[it] = dL_dmap ? dL_dmap[o] : gu;
+        a[it] = dm_dmu1[o];
+        b[it] = dm_dsigma1_sq[o];
+        d[it] = dm_dsigma12[o];
+      }
     }
-    tile[0][r][c] = a * g;
-    tile[1][r][c] = b * g;
-    tile[2][r][c] = d * g;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int k = threadIdx.x + it * GS_BLOCK;
+      if (k < SH * SH) {
+        tile[0][k / SH][k % SH] = a[it] * g[it];
+        tile[1][k / SH][k % SH] = b[it] * g[it];
+        tile[2][k / SH][k % SH] = d[it] * g[it];
+      }
+    }
   }
   __syncthreads();
   float out[4][3];
