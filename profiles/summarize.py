@@ -16,14 +16,14 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
 OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs_scatter_kernel", "scan_reduce_kernel",
-        "scan_sums_kernel", "scan_down_kernel", "sorted_block_sums_kernel", "duplicate_kernel", "tile_ranges_kernel",
+        "scan_sums_kernel", "scan_down_kernel", "rs_rowscan_kernel", "sorted_block_sums_kernel", "duplicate_kernel", "tile_ranges_kernel",
         "bin_prepare_kernel", "render_fwd_wave_kernel", "render_bwd_wave_kernel", "render_fwd_kernel", "render_bwd_kernel", "adam_kernel", "scan_small_kernel", "preprocess_bwd_kernel", "l1_fwd_kernel",
         "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
-        "patch_dwt_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel")
+        "patch_dwt_kernel", "lgdwt_combine_kernel", "act_fwd_kernel", "act_bwd_kernel", "densify_stats_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel")
 
 
 def short(name):
-    for o in OURS:
+    for o in sorted(OURS, key=len, reverse=True):   # longest first: dwt2_l1_fwd_kernel contains l1_fwd_kernel
         if o in name:
             return o
     return name.split("(")[0][-60:]

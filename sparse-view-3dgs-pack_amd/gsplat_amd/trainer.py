@@ -551,8 +551,9 @@ def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifie
         except Exception:
             pass
         act = (pc.get_scaling, pc.get_rotation, pc.get_opacity)
-    else:  # the step loop's lean form: a zero leaf carries the view-space gradient (no `+ 0` copy, one fill)
-        screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    else:  # the step loop's lean form: the leaf only carries the view-space gradient - the rasterizer never reads
+        # means2D (rasterize_points.cu takes no such argument) - so it is not even filled
+        screenspace_points = torch.empty_like(pc.get_xyz).requires_grad_(True)
     scales, rotations, opacities = act
     rs = Settings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
@@ -569,7 +570,9 @@ def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifie
     return {"render": rendered_image, "viewspace_points": screenspace_points,
             # the reference returns indices ((radii > 0).nonzero(): a host sync); the step loop asks for the
             # equivalent boolean mask instead and stays asynchronous
-            "visibility_filter": (radii > 0).nonzero() if filter_as_indices else (radii > 0),
+            # (filter_as_indices=None: not at all - the fused statistics kernel reads radii itself)
+            "visibility_filter": None if filter_as_indices is None else
+            ((radii > 0).nonzero() if filter_as_indices else (radii > 0)),
             "radii": radii, "depth": depth_image}
 
 
@@ -681,7 +684,7 @@ class Trainer:
         if backend is not None:
             m.arm_grad_arena(backend)
         fused = getattr(self.criterion, "fused", False)
-        pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=False,
+        pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
                      clamp=not fused, fused=True)
         mask = None if self.masks is None else self.masks[ci]
         if fused:

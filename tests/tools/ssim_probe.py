@@ -20,7 +20,8 @@ coef = torch.full((1,), 1e-6, device="cuda")
 st = None
 import ctypes as C  # noqa: E402
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for name in ("fwd", "bwd"):
+s9 = torch.zeros(16, device="cuda")
+for name in ("fwd", "bwd", "dwt"):
     for it in range(reps + 3):
         if it == 3:
             torch.cuda.synchronize()
@@ -28,6 +29,8 @@ for name in ("fwd", "bwd"):
         if name == "fwd":
             api.call("ssim_fwd_sum", a.data_ptr(), b.data_ptr(), 1, 3, H, W, 1e-4, 9e-4, s.data_ptr(), d1.data_ptr(),
                      d2.data_ptr(), d3.data_ptr(), st)
+        elif name == "dwt":
+            api.call("l1_dwt2_fwd", a.data_ptr(), b.data_ptr(), 3, H, W, s9.data_ptr(), s9[2:].data_ptr(), st)
         else:
             api.call("ssim_bwd_uniform", a.data_ptr(), b.data_ptr(), 1, 3, H, W, coef.data_ptr(), d1.data_ptr(),
                      d2.data_ptr(), d3.data_ptr(), grad.data_ptr(), 0, a.data_ptr(), st)
