@@ -20,15 +20,30 @@ struct ShRegsB {
   __device__ __forceinline__ V3 operator()(int k) const { return {f[3 * k], f[3 * k + 1], f[3 * k + 2]}; }
 };
 
-// Where sh_backward puts row k of dL_dsh: an LDS row (M == 16, leaves coalesced) or the global row itself.  (A
-// register array here ends up in scratch memory - the generic-M path indexes it dynamically - which showed up as
-// 384 B per Gaussian of extra HBM write traffic in the WRITE_SIZE counter.)
+// Where sh_backward puts row k of dL_dsh = basis_k(dir) * dL_dRGB.  M == 16: only the sixteen basis values and the
+// (clamp-masked) colour gradient go to an LDS row of 19 words, and the coalesced store phase forms the 48 products
+// (the full 48-word rows took 49 KB of LDS and held the kernel at 3 workgroups per CU).  Generic M: the products go
+// straight to the global row.  (A register array here ends up in scratch memory - the generic-M path indexes it
+// dynamically - which showed up as 384 B per Gaussian of extra HBM write traffic in the WRITE_SIZE counter.)
+#define SH_LDS_ROW 19
 struct ShSink {
   float* p;
-  __device__ __forceinline__ void set(int k, V3 v) const {
-    p[3 * k] = v.x;
-    p[3 * k + 1] = v.y;
-    p[3 * k + 2] = v.z;
+  bool basis_only;
+  __device__ __forceinline__ void rgb(V3 g) const {
+    if (basis_only) {
+      p[16] = g.x;
+      p[17] = g.y;
+      p[18] = g.z;
+    }
+  }
+  __device__ __forceinline__ void set(int k, float basis, V3 g) const {
+    if (basis_only) {
+      p[k] = basis;
+    } else {
+      p[3 * k] = basis * g.x;
+      p[3 * k + 1] = basis * g.y;
+      p[3 * k + 2] = basis * g.z;
+    }
   }
 };
 
@@ -40,17 +55,18 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
   dL_dRGB.x *= (clamped & 1u) ? 0 : 1;
   dL_dRGB.y *= (clamped & 2u) ? 0 : 1;
   dL_dRGB.z *= (clamped & 4u) ? 0 : 1;
+  dsh.rgb(dL_dRGB);
   V3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
   float x = dir.x, y = dir.y, z = dir.z;
   float dRGBdsh0 = SH_C0;
-  dsh.set(0, dRGBdsh0 * dL_dRGB);
+  dsh.set(0, dRGBdsh0, dL_dRGB);
   if (deg > 0) {
     float dRGBdsh1 = -SH_C1 * y;
     float dRGBdsh2 = SH_C1 * z;
     float dRGBdsh3 = -SH_C1 * x;
-    dsh.set(1, dRGBdsh1 * dL_dRGB);
-    dsh.set(2, dRGBdsh2 * dL_dRGB);
-    dsh.set(3, dRGBdsh3 * dL_dRGB);
+    dsh.set(1, dRGBdsh1, dL_dRGB);
+    dsh.set(2, dRGBdsh2, dL_dRGB);
+    dsh.set(3, dRGBdsh3, dL_dRGB);
     dRGBdx = -SH_C1 * sh(3);
     dRGBdy = -SH_C1 * sh(1);
     dRGBdz = SH_C1 * sh(2);
@@ -62,11 +78,11 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
       float dRGBdsh6 = SH_C2_2 * (2.f * zz - xx - yy);
       float dRGBdsh7 = SH_C2_3 * xz;
       float dRGBdsh8 = SH_C2_4 * (xx - yy);
-      dsh.set(4, dRGBdsh4 * dL_dRGB);
-      dsh.set(5, dRGBdsh5 * dL_dRGB);
-      dsh.set(6, dRGBdsh6 * dL_dRGB);
-      dsh.set(7, dRGBdsh7 * dL_dRGB);
-      dsh.set(8, dRGBdsh8 * dL_dRGB);
+      dsh.set(4, dRGBdsh4, dL_dRGB);
+      dsh.set(5, dRGBdsh5, dL_dRGB);
+      dsh.set(6, dRGBdsh6, dL_dRGB);
+      dsh.set(7, dRGBdsh7, dL_dRGB);
+      dsh.set(8, dRGBdsh8, dL_dRGB);
       dRGBdx = dRGBdx + (SH_C2_0 * y * sh(4) + SH_C2_2 * 2.f * -x * sh(6) + SH_C2_3 * z * sh(7) + SH_C2_4 * 2.f * x * sh(8));
       dRGBdy = dRGBdy + (SH_C2_0 * x * sh(4) + SH_C2_1 * z * sh(5) + SH_C2_2 * 2.f * -y * sh(6) + SH_C2_4 * 2.f * -y * sh(8));
       dRGBdz = dRGBdz + (SH_C2_1 * y * sh(5) + SH_C2_2 * 2.f * 2.f * z * sh(6) + SH_C2_3 * x * sh(7));
@@ -78,13 +94,13 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
         float dRGBdsh13 = SH_C3_4 * x * (4.f * zz - xx - yy);
         float dRGBdsh14 = SH_C3_5 * z * (xx - yy);
         float dRGBdsh15 = SH_C3_6 * x * (xx - 3.f * yy);
-        dsh.set(9, dRGBdsh9 * dL_dRGB);
-        dsh.set(10, dRGBdsh10 * dL_dRGB);
-        dsh.set(11, dRGBdsh11 * dL_dRGB);
-        dsh.set(12, dRGBdsh12 * dL_dRGB);
-        dsh.set(13, dRGBdsh13 * dL_dRGB);
-        dsh.set(14, dRGBdsh14 * dL_dRGB);
-        dsh.set(15, dRGBdsh15 * dL_dRGB);
+        dsh.set(9, dRGBdsh9, dL_dRGB);
+        dsh.set(10, dRGBdsh10, dL_dRGB);
+        dsh.set(11, dRGBdsh11, dL_dRGB);
+        dsh.set(12, dRGBdsh12, dL_dRGB);
+        dsh.set(13, dRGBdsh13, dL_dRGB);
+        dsh.set(14, dRGBdsh14, dL_dRGB);
+        dsh.set(15, dRGBdsh15, dL_dRGB);
         dRGBdx = dRGBdx + (SH_C3_0 * sh(9) * 3.f * 2.f * xy + SH_C3_1 * sh(10) * yz + SH_C3_2 * sh(11) * -2.f * xy +
                            SH_C3_3 * sh(12) * -3.f * 2.f * xz + SH_C3_4 * sh(13) * (-3.f * xx + 4.f * zz - yy) +
                            SH_C3_5 * sh(14) * 2.f * xz + SH_C3_6 * sh(15) * 3.f * (xx - yy));
@@ -101,11 +117,11 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
   return dnormvdv3(dir_orig, dL_ddir);
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+__global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_kernel(PreprocessBwdArgs a) {
   // dL_dsh rows (192 B per Gaussian) leave through LDS so that every store instruction of a wave covers 1 KiB of
   // consecutive addresses; written per lane (12 x 16 B at a 192-B stride) the same bytes cost 2.3x the HBM write
-  // traffic (rocprofv3 WRITE_SIZE, profiles/).  Row stride 49 words: conflict-free per-lane writes.
-  __shared__ float s_sh[GS_BLOCK * 49];
+  // traffic (rocprofv3 WRITE_SIZE, profiles/).  Row stride 19 words (odd): conflict-free per-lane writes.
+  __shared__ float s_sh[GS_BLOCK * SH_LDS_ROW];
   const int idx_raw = blockIdx.x * GS_BLOCK + threadIdx.x;
   const bool in_range = idx_raw < a.P;
   const int idx = in_range ? idx_raw : a.P - 1;  // out-of-range lanes shadow the last Gaussian and store nothing
@@ -121,9 +137,9 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
   // dL_dsh sink: zero row first (culled Gaussians and coefficients above the active degree stay 0)
   const bool sh_lds = a.shs && a.out.dL_dsh && a.M == 16;
   const bool sh_global = a.shs && a.out.dL_dsh && !sh_lds && in_range;  // generic M: straight to the global row
-  ShSink dsh{sh_global ? a.out.dL_dsh + (size_t)idx * a.M * 3 : s_sh + threadIdx.x * 49};
+  ShSink dsh{sh_global ? a.out.dL_dsh + (size_t)idx * a.M * 3 : s_sh + threadIdx.x * SH_LDS_ROW, !sh_global};
   {
-    const int nfl_row = sh_global ? a.M * 3 : 48;
+    const int nfl_row = sh_global ? a.M * 3 : SH_LDS_ROW;
     for (int k = 0; k < nfl_row; k++) dsh.p[k] = 0.f;
   }
 
@@ -316,8 +332,14 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_bwd_kernel(PreprocessBwdA
     float* dst = o.dL_dsh + (size_t)first * 48;
     for (int j = 4 * threadIdx.x; j < nfl; j += 4 * GS_BLOCK) {
       const int r = j / 48, c = j - r * 48;  // c is a multiple of 4: the four floats are in one row
-      const float* src = s_sh + r * 49 + c;
-      *reinterpret_cast<float4*>(dst + j) = make_float4(src[0], src[1], src[2], src[3]);
+      const float* src = s_sh + r * SH_LDS_ROW;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int k = (c + e) / 3, ch = (c + e) - 3 * k;
+        v[e] = src[k] * src[16 + ch];  // the very product sh_backward's generic path forms: basis_k * dL_dRGB[ch]
+      }
+      *reinterpret_cast<float4*>(dst + j) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
   if (!in_range) return;
