@@ -282,6 +282,13 @@ int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int
 int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1,
                     float C2, float* sum_out, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
                     void* stream);
+/* gs_ssim_fwd_sum without the atomic: workgroup w of the launch stores its share of sum(ssim_map) to partials[w]
+ * (gs_ssim_partials_count() of them, all written); gs_lgdwt_combine_p adds them to sums[1] in a fixed order.
+ * (One device-scope atomic per workgroup on ONE address is serialised at ~14 ns each on MI355X: 86 us at 1080p.) */
+int64_t gs_ssim_partials_count(int32_t B, int32_t C, int32_t H, int32_t W);
+int gs_ssim_fwd_partials(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1,
+                         float C2, float* partials, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                         void* stream);
 /* like gs_ssim_bwd with dL_dmap == coef_dev[0] everywhere; optionally adds to dL_dimg1 and then zeroes the
  * result where clamp_src (the un-clamped render) lies outside [0,1] */
 int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W,
@@ -303,6 +310,9 @@ typedef struct GsLgdwtParams {
  * 8 c_l1, 9 c_ssim, 10..17 c_band, 18..20 c_patch = dLoss/d(term sum). */
 int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* params /*host*/, float* out,
                      void* stream);
+/* the same with the SSIM sum given as sums[1] + sum(ssim_partials[0..n_partials)) */
+int gs_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_partials, float* running_mean,
+                       const GsLgdwtParams* params /*host*/, float* out, void* stream);
 
 /* ---- optimiser (caller side of the path): fused Adam over ONE flat fp32 parameter buffer.
  * Replaces torch.optim.Adam(lr=0, eps=1e-15) with per-group learning rates,

@@ -522,6 +522,18 @@ int gso_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_
   }
   return GS_OK;
 }
+/* per-workgroup partial sums of the HIP kernel: the checker puts the whole sum into partials[0] */
+int64_t gso_ssim_partials_count(int32_t B, int32_t C, int32_t H, int32_t W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return (int64_t)((W + 31) / 32) * ((H + 31) / 32) * B * C;
+}
+int gso_ssim_fwd_partials(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1, float C2,
+                          float* partials, float* d1, float* d2, float* d3, void*) {
+  if (!partials) return GS_E_NULL;
+  const int64_t n = gso_ssim_partials_count(B, C, H, W);
+  for (int64_t i = 0; i < n; i++) partials[i] = 0.f;
+  return gso_ssim_fwd_sum(img1, img2, B, C, H, W, C1, C2, partials, d1, d2, d3, nullptr);
+}
 /* LGDWT-GS/train.py:188-202 */
 int gso_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* pp, float* out, void*) {
   if (!sums || !running_mean || !pp || !out) return GS_E_NULL;
@@ -552,5 +564,16 @@ int gso_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParam
   out[8] = (1.0f - p.lambda_dssim) / p.n_pix;
   out[9] = -p.lambda_dssim / p.n_pix;
   return GS_OK;
+}
+int gso_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_partials, float* running_mean,
+                        const GsLgdwtParams* pp, float* out, void*) {
+  if (!sums) return GS_E_NULL;
+  if (n_partials < 0 || (n_partials > 0 && !ssim_partials)) return GS_E_SHAPE;
+  float s2[16];
+  for (int k = 0; k < 16; k++) s2[k] = sums[k];
+  double add = 0;
+  for (int64_t i = 0; i < n_partials; i++) add += (double)ssim_partials[i];
+  s2[1] += (float)add;
+  return gso_lgdwt_combine(s2, running_mean, pp, out, nullptr);
 }
 }

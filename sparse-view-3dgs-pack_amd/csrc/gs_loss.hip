@@ -423,8 +423,8 @@ __constant__ float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.03
 #define ST 32
 #define SH (ST + 10)
 
-#define HS 40  // row stride of the horizontal-pass buffer: 4 rows apart = 160 words = 32 banks, so the two half-waves
-               // of the vertical pass (rows 4 ly0 .. and 4 (ly0 + 1) ..) read disjoint halves of the 64 banks
+#define HS 33  // row stride of the horizontal-pass buffer (odd): the 32 lanes of a store group (8 column groups x 4 rows)
+               // and of a vertical-pass load group (one row) each fall on 32 different banks
 
 // Separable 11-tap convolution of NQ quantities over the 42x42 halo tile.  Register-blocked: a thread produces 4
 // adjacent outputs along the pass direction from 14 inputs (sliding window), i.e. 3.5 LDS reads per output and
@@ -432,41 +432,57 @@ __constant__ float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.03
 // planes on the fly, so only those two are staged.  Every output is still the sum over t = 0..10 in ascending
 // order (the order of fused-ssim/ssim.cu:60-100 and of the checker).  out[j] belongs to tile row 4 * (tid / 32) + j,
 // column tid % 32.
+// `tile` and `hor` SHARE their LDS (the horizontal results are held in registers across a barrier and then overwrite
+// the input tile): 27.7 KB per workgroup in the forward instead of 48 KB, i.e. 5 workgroups per CU instead of 3.
 template <int NQ, bool FWD>
 __device__ __forceinline__ void ssim_conv_tile(const float (*tile)[SH][SH + 1], float (*hor)[SH][HS], float (&out)[4][NQ]) {
   // the taps contract to FMAs here although the file is built with -ffp-contract=off: nvcc contracts the reference's
   // `sum += G * val` (fused-ssim/ssim.cu:60-100) the same way, and the kernel is VALU-issue-bound (half the instructions)
 #pragma clang fp contract(fast)
-  for (int item = threadIdx.x; item < SH * (ST / 4); item += GS_BLOCK) {
-    const int r = item / (ST / 4), c0 = (item % (ST / 4)) * 4;
-    float acc[4][NQ];
+  constexpr int NITEM = SH * (ST / 4);                      // 336 (row, 4-column group) items
+  constexpr int NR = (NITEM + GS_BLOCK - 1) / GS_BLOCK;     // 2 rounds
+  float acc[NR][4][NQ];
+#pragma unroll
+  for (int rd = 0; rd < NR; rd++) {
+    const int item = threadIdx.x + rd * GS_BLOCK;
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int q = 0; q < NQ; q++) acc[j][q] = 0.f;
+      for (int q = 0; q < NQ; q++) acc[rd][j][q] = 0.f;
+    if (item < NITEM) {
+      const int r = item / (ST / 4), c0 = (item % (ST / 4)) * 4;
 #pragma unroll
-    for (int e = 0; e < 14; e++) {
-      float val[NQ];
-      if (FWD) {
-        const float a = tile[0][r][c0 + e], b = tile[1][r][c0 + e];
-        val[0] = a; val[1] = a * a; val[2] = b; val[3 % NQ] = b * b; val[4 % NQ] = a * b;
-      } else {
+      for (int e = 0; e < 14; e++) {
+        float val[NQ];
+        if (FWD) {
+          const float a = tile[0][r][c0 + e], b = tile[1][r][c0 + e];
+          val[0] = a; val[1] = a * a; val[2] = b; val[3 % NQ] = b * b; val[4 % NQ] = a * b;
+        } else {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) val[q] = tile[q][r][c0 + e];
-      }
+          for (int q = 0; q < NQ; q++) val[q] = tile[q][r][c0 + e];
+        }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int t = e - j;
-        if (t >= 0 && t < 11) {
+        for (int j = 0; j < 4; j++) {
+          const int t = e - j;
+          if (t >= 0 && t < 11) {
 #pragma unroll
-          for (int q = 0; q < NQ; q++) acc[j][q] += GW[t] * val[q];
+            for (int q = 0; q < NQ; q++) acc[rd][j][q] += GW[t] * val[q];
+          }
         }
       }
     }
+  }
+  __syncthreads();  // every read of `tile` is done: `hor` may overwrite it
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+  for (int rd = 0; rd < NR; rd++) {
+    const int item = threadIdx.x + rd * GS_BLOCK;
+    if (item < NITEM) {
+      const int r = item / (ST / 4), c0 = (item % (ST / 4)) * 4;
 #pragma unroll
-      for (int q = 0; q < NQ; q++) hor[q][r][c0 + j] = acc[j][q];
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) hor[q][r][c0 + j] = acc[rd][j][q];
+    }
   }
   __syncthreads();
   const int lx = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;
@@ -493,9 +509,11 @@ __device__ __forceinline__ void ssim_conv_tile(const float (*tile)[SH][SH + 1], 
 __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                             int H, int W, float C1, float C2, float* __restrict__ ssim_map,
                                                             float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
-                                                            float* __restrict__ dm_dsigma12, float* sum_out) {
-  __shared__ float tile[2][SH][SH + 1];
-  __shared__ float hor[5][SH][HS];
+                                                            float* __restrict__ dm_dsigma12, float* sum_out, float* __restrict__ partials) {
+  constexpr int LDS_WORDS = (2 * SH * (SH + 1) > 5 * SH * HS) ? 2 * SH * (SH + 1) : 5 * SH * HS;
+  __shared__ float lds_buf[LDS_WORDS];
+  float (*tile)[SH][SH + 1] = reinterpret_cast<float (*)[SH][SH + 1]>(lds_buf);
+  float (*hor)[SH][HS] = reinterpret_cast<float (*)[SH][HS]>(lds_buf);
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
   {  // all global loads of the halo tile are in flight before the first LDS store (a rolled loop waits per round)
@@ -555,7 +573,19 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
       dm_dsigma12[o] = (2 * Cc) * inv_AB;
     }
   }
-  if (sum_out) {  // uniform branch: mean SSIM without a second pass over the map
+  if (partials) {
+    // one plain store per workgroup; gs_lgdwt_combine_p adds them up.  (An atomic on ONE address per workgroup is
+    // serialised device-wide at ~14 ns each on this 8-XCD part: 6120 of them took 86 us of a 98-us kernel.)
+    __shared__ float red[GS_BLOCK / 64];
+    float x = msum;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  } else if (sum_out) {  // uniform branch: mean SSIM without a second pass over the map
     float acc[1] = {msum};
     __syncthreads();
     block_sum_atomic<1>(acc, sum_out);
@@ -569,9 +599,11 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dm_dsigma12,
                                                             float* __restrict__ dL_dimg1, const float* __restrict__ coef_dev,
                                                             int accumulate, const float* __restrict__ clamp_src) {
-  __shared__ float tile[3][SH][SH + 1];
+  constexpr int LDS_WORDS = (3 * SH * (SH + 1) > 3 * SH * HS) ? 3 * SH * (SH + 1) : 3 * SH * HS;
+  __shared__ float lds_buf[LDS_WORDS];
+  float (*tile)[SH][SH + 1] = reinterpret_cast<float (*)[SH][SH + 1]>(lds_buf);
+  float (*hor)[SH][HS] = reinterpret_cast<float (*)[SH][HS]>(lds_buf);
   const float gu = coef_dev ? coef_dev[0] : 0.f;  // uniform dL/dssim_map (mean reduction upstream)
-  __shared__ float hor[3][SH][HS];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
   {
@@ -787,7 +819,7 @@ int gs_ssim_fwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_FWD, s);
   hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr);
+                     C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, (float*)nullptr);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -829,7 +861,25 @@ int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, 
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_FWD, s);
   hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, sum_out);
+                     C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, sum_out, (float*)nullptr);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+
+int64_t gs_ssim_partials_count(int32_t B, int32_t C, int32_t H, int32_t W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return (int64_t)((W + ST - 1) / ST) * ((H + ST - 1) / ST) * B * C;
+}
+
+int gs_ssim_fwd_partials(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1, float C2,
+                         float* partials, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream) {
+  if (!img1 || !img2 || !partials) return GS_E_NULL;
+  if (dm_dmu1 && (!dm_dsigma1_sq || !dm_dsigma12)) return GS_E_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_SSIM_FWD, s);
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, partials);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -853,11 +903,20 @@ int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t
 //   sums[16] : 0 l1_sum | 1 ssim_sum | 2..9 band_sums | 10..12 patch_sums | 13 n_selected_patches
 //   out[24]  : 0 loss | 1 base | 2 dwt | 3 patch | 4 dwt_scale | 5 l1 | 6 ssim |
 //              8 c_l1 | 9 c_ssim | 10..17 c_band[8] | 18..20 c_patch[3]      (dL/d term-sum, for upstream grad 1)
-__global__ void lgdwt_combine_kernel(const float* __restrict__ sums, float* running_mean, GsLgdwtParams p,
-                                     float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(GS_BLOCK) lgdwt_combine_kernel(const float* __restrict__ sums, float* running_mean,
+                                                                 GsLgdwtParams p, float* __restrict__ out,
+                                                                 const float* __restrict__ ssim_partials, int n_partials) {
+  // SSIM sum = sums[1] + the per-workgroup partials of gs_ssim_fwd_partials, added in a fixed order
+  __shared__ float red[GS_BLOCK / 64];
+  float part = 0.f;
+  for (int i = threadIdx.x; i < n_partials; i += GS_BLOCK) part += ssim_partials[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   const float l1 = sums[0] / p.n_pix;
-  const float ssim = sums[1] / p.n_pix;
+  const float ssim = (sums[1] + ((red[0] + red[1]) + (red[2] + red[3]))) / p.n_pix;
   const float base = (1.0f - p.lambda_dssim) * l1 + p.lambda_dssim * (1.0f - ssim);
   float loss = base;
   float dwt = 0.f, scale = 0.f, patch = 0.f;
@@ -887,12 +946,18 @@ __global__ void lgdwt_combine_kernel(const float* __restrict__ sums, float* runn
   out[9] = -p.lambda_dssim / p.n_pix;
 }
 
-int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* p, float* out, void* stream) {
+int gs_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_partials, float* running_mean,
+                       const GsLgdwtParams* p, float* out, void* stream) {
   if (!sums || !running_mean || !p || !out) return GS_E_NULL;
+  if (n_partials < 0 || n_partials > 0x7FFFFFFF || (n_partials > 0 && !ssim_partials)) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(lgdwt_combine_kernel, dim3(1), dim3(64), 0, s, sums, running_mean, *p, out);
+  hipLaunchKernelGGL(lgdwt_combine_kernel, dim3(1), dim3(GS_BLOCK), 0, s, sums, running_mean, *p, out, ssim_partials,
+                     (int)n_partials);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
+}
+int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* p, float* out, void* stream) {
+  return gs_lgdwt_combine_p(sums, nullptr, 0, running_mean, p, out, stream);
 }
 }

@@ -129,6 +129,9 @@ PROTOTYPES = {
     "ssim_fwd_sum": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "ssim_bwd_uniform": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "lgdwt_combine": (C.c_int, [_P, _P, C.POINTER(GsLgdwtParams), _P, _P]),
+    "lgdwt_combine_p": (C.c_int, [_P, _P, _I64, _P, C.POINTER(GsLgdwtParams), _P, _P]),
+    "ssim_partials_count": (C.c_int64, [_I32, _I32, _I32, _I32]),
+    "ssim_fwd_partials": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "adam_step": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P]),
     "activations_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P]),
     "activations_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),

@@ -252,14 +252,17 @@ class FusedLGDWTLoss(torch.autograd.Function):
             api.call("l1_dwt2_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, sums.data_ptr(), sums[2:].data_ptr(), st)
         else:
             api.call("l1_fwd", img.data_ptr(), gt.data_ptr(), img.numel(), sums.data_ptr(), st)
-        api.call("ssim_fwd_sum", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, 0.01 ** 2, 0.03 ** 2,
-                 sums[1:].data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), st)
+        # SSIM sum as per-workgroup partials (no atomics; lgdwt_combine_p adds them up in a fixed order)
+        partials = torch.empty((params.n_ssim_partials,), dtype=torch.float32, device=raw.device)
+        api.call("ssim_fwd_partials", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, 0.01 ** 2, 0.03 ** 2,
+                 partials.data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), st)
         if params.patch_enable:
             api.call("patch_dwt_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
                      sums[10:].data_ptr(), st)
             sums[13:14].copy_(n_sel)
         out = torch.empty((24,), dtype=torch.float32, device=raw.device)
-        api.call("lgdwt_combine", sums.data_ptr(), running_mean.data_ptr(), C.byref(params.c), out.data_ptr(), st)
+        api.call("lgdwt_combine_p", sums.data_ptr(), partials.data_ptr(), partials.numel(), running_mean.data_ptr(),
+                 C.byref(params.c), out.data_ptr(), st)
         ctx.ops, ctx.params = ops, params
         ctx.save_for_backward(raw, img, gt, mask, d1, d2, d3, out)
         ctx.mark_non_differentiable(out)
@@ -316,6 +319,7 @@ class _FusedParams:
         c.dwt_enable, c.patch_enable = int(self.dwt_enable), int(self.patch_enable)
         self.c = c
         self.patch_size = crit.patch_size
+        self.n_ssim_partials = int(crit.ops.api.raw("ssim_partials_count")(1, Cc, H, W))
 
 
 class LGDWTCriterion:

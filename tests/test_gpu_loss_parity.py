@@ -136,3 +136,43 @@ def test_l1_dwt2_one_pass_equals_the_two_kernels_and_the_oracle(hip, oracle, H, 
     for k in range(9):
         assert abs(float(out["hip"][0][k]) - float(out["oracle"][0][k])) <= 1e-5 * float(out["oracle"][0][k]), k
     close(out["hip"][1], out["oracle"][1], 2e-5, "grad")
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (131, 260), (33, 40)])
+def test_ssim_partials_equal_the_atomic_sum_and_the_oracle(hip, oracle, H, W):
+    """gs_ssim_fwd_partials (one plain store per workgroup) + gs_lgdwt_combine_p against gs_ssim_fwd_sum +
+    gs_lgdwt_combine, on the device and in the oracle."""
+    import ctypes as C
+    from gsplat_amd.losses import _FusedParams
+    pred, gt = images(H, W, 7 * H + W)
+    res = {}
+    for name, api, dev in (("hip", hip.api, "cuda"), ("oracle", oracle.api, "cpu")):
+        p, t = pred.to(dev), gt.to(dev)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev == "cuda" else None
+        n = int(api.raw("ssim_partials_count")(1, 3, H, W))
+        assert n == ((W + 31) // 32) * ((H + 31) // 32) * 3
+        part = torch.full((n,), float("nan"), device=dev)
+        d = [torch.empty_like(p) for _ in range(6)]
+        s_atomic = torch.zeros((16,), device=dev)
+        api.call("ssim_fwd_partials", p.data_ptr(), t.data_ptr(), 1, 3, H, W, 1e-4, 9e-4, part.data_ptr(), d[0].data_ptr(),
+                 d[1].data_ptr(), d[2].data_ptr(), st)
+        api.call("ssim_fwd_sum", p.data_ptr(), t.data_ptr(), 1, 3, H, W, 1e-4, 9e-4, s_atomic[1:].data_ptr(), d[3].data_ptr(),
+                 d[4].data_ptr(), d[5].data_ptr(), st)
+        assert bool(torch.isfinite(part).all())
+        for k in range(3):
+            assert torch.equal(d[k], d[k + 3])
+        fp = _FusedParams(LGDWTCriterion(LossOps(api)), 3, H, W)
+        s_atomic[0] = 0.1 * 3 * H * W
+        s_part = s_atomic.clone()
+        s_part[1] = 0.0
+        rm1, rm2 = torch.ones(1, device=dev), torch.ones(1, device=dev)
+        o1, o2 = torch.empty(24, device=dev), torch.empty(24, device=dev)
+        api.call("lgdwt_combine", s_atomic.data_ptr(), rm1.data_ptr(), C.byref(fp.c), o1.data_ptr(), st)
+        api.call("lgdwt_combine_p", s_part.data_ptr(), part.data_ptr(), n, rm2.data_ptr(), C.byref(fp.c), o2.data_ptr(), st)
+        res[name] = (float(part.double().sum()), float(s_atomic[1]), o1.cpu(), o2.cpu())
+    for name in res:
+        ps, at, o1, o2 = res[name]
+        assert abs(ps - at) <= 1e-5 * abs(at), (name, ps, at)
+        close(o2, o1, 1e-5, name + " combine_p vs combine")
+    assert abs(res["hip"][0] - res["oracle"][0]) <= 1e-5 * abs(res["oracle"][0])
+    close(res["hip"][3], res["oracle"][3], 1e-5, "combine_p hip vs oracle")

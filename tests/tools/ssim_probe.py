@@ -21,7 +21,8 @@ st = None
 import ctypes as C  # noqa: E402
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 s9 = torch.zeros(16, device="cuda")
-for name in ("fwd", "bwd", "dwt"):
+part = torch.empty(int(api.raw("ssim_partials_count")(1, 3, H, W)), device="cuda")
+for name in ("fwd", "fwdmap", "fwdpart", "bwd", "dwt"):
     for it in range(reps + 3):
         if it == 3:
             torch.cuda.synchronize()
@@ -29,6 +30,12 @@ for name in ("fwd", "bwd", "dwt"):
         if name == "fwd":
             api.call("ssim_fwd_sum", a.data_ptr(), b.data_ptr(), 1, 3, H, W, 1e-4, 9e-4, s.data_ptr(), d1.data_ptr(),
                      d2.data_ptr(), d3.data_ptr(), st)
+        elif name == "fwdmap":  # the same kernel without the per-workgroup atomic (writes the map instead)
+            api.call("ssim_fwd", a.data_ptr(), b.data_ptr(), 1, 3, H, W, 1e-4, 9e-4, grad.data_ptr(), d1.data_ptr(),
+                     d2.data_ptr(), d3.data_ptr(), st)
+        elif name == "fwdpart":
+            api.call("ssim_fwd_partials", a.data_ptr(), b.data_ptr(), 1, 3, H, W, 1e-4, 9e-4, part.data_ptr(),
+                     d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), st)
         elif name == "dwt":
             api.call("l1_dwt2_fwd", a.data_ptr(), b.data_ptr(), 3, H, W, s9.data_ptr(), s9[2:].data_ptr(), st)
         else:
