@@ -88,3 +88,28 @@ if "rs_scatter_kernel" in traffic:  # the sort stage = all passes of hist + scat
 json.dump(out, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(here, "%s_step_timeline.txt" % tag)).read())
 print(open(os.path.join(here, "%s_pmc_traffic.csv" % tag)).read())
+
+# SQ counters -> <tag>_sq_counters.csv (per kernel: instructions per wave, VALU-busy share of the SIMD cycles, wait shares)
+sq = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(src, "sq*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if sq:
+    with open(os.path.join(here, "%s_sq_counters.csv" % tag), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "waves", "VALU_insts_per_wave", "LDS_insts_per_wave", "SALU_insts_per_wave", "VMEM_rd_per_wave",
+                    "VMEM_wr_per_wave", "VALU_busy_pct_of_SIMD_cycles", "wait_any_pct_of_wave_cycles",
+                    "wait_inst_pct_of_wave_cycles", "waves_per_SIMD", "LDS_bank_conflict_pct_of_LDS_cycles"])
+        for k, v in sorted(sq.items()):
+            m = {c: sum(x) / len(x) for c, x in v.items()}
+            if k not in OURS or "GRBM_GUI_ACTIVE" not in m or m.get("SQ_WAVES", 0) == 0:
+                continue
+            simd_cycles = m["GRBM_GUI_ACTIVE"] / 8 * 1024          # 8 XCDs counted; 256 CUs x 4 SIMDs
+            wc = max(1.0, m.get("SQ_WAVE_CYCLES", 0))
+            w.writerow([k, int(m["SQ_WAVES"]), round(m.get("SQ_INSTS_VALU", 0) / m["SQ_WAVES"], 1),
+                        round(m.get("SQ_INSTS_LDS", 0) / m["SQ_WAVES"], 1), round(m.get("SQ_INSTS_SALU", 0) / m["SQ_WAVES"], 1),
+                        round(m.get("SQ_INSTS_VMEM_RD", 0) / m["SQ_WAVES"], 1), round(m.get("SQ_INSTS_VMEM_WR", 0) / m["SQ_WAVES"], 1),
+                        round(100 * m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles, 1),   # quad-cycles -> cycles
+                        round(100 * m.get("SQ_WAIT_ANY", 0) / wc, 1), round(100 * m.get("SQ_WAIT_INST_ANY", 0) / wc, 1),
+                        round(wc * 4 / simd_cycles, 2),
+                        round(100 * m.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, m.get("SQ_LDS_IDX_ACTIVE", 0)), 1)])

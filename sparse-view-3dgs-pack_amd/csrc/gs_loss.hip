@@ -903,20 +903,22 @@ int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t
 //   sums[16] : 0 l1_sum | 1 ssim_sum | 2..9 band_sums | 10..12 patch_sums | 13 n_selected_patches
 //   out[24]  : 0 loss | 1 base | 2 dwt | 3 patch | 4 dwt_scale | 5 l1 | 6 ssim |
 //              8 c_l1 | 9 c_ssim | 10..17 c_band[8] | 18..20 c_patch[3]      (dL/d term-sum, for upstream grad 1)
-__global__ void __launch_bounds__(GS_BLOCK) lgdwt_combine_kernel(const float* __restrict__ sums, float* running_mean,
-                                                                 GsLgdwtParams p, float* __restrict__ out,
-                                                                 const float* __restrict__ ssim_partials, int n_partials) {
+__global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __restrict__ sums, float* running_mean,
+                                                             GsLgdwtParams p, float* __restrict__ out,
+                                                             const float* __restrict__ ssim_partials, int n_partials) {
   // SSIM sum = sums[1] + the per-workgroup partials of gs_ssim_fwd_partials, added in a fixed order
-  __shared__ float red[GS_BLOCK / 64];
+  __shared__ float red[16];
   float part = 0.f;
-  for (int i = threadIdx.x; i < n_partials; i += GS_BLOCK) part += ssim_partials[i];
+  for (int i = threadIdx.x; i < n_partials; i += 1024) part += ssim_partials[i];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_down(part, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
   if (threadIdx.x != 0) return;
   const float l1 = sums[0] / p.n_pix;
-  const float ssim = (sums[1] + ((red[0] + red[1]) + (red[2] + red[3]))) / p.n_pix;
+  float ptot = 0.f;
+  for (int w = 0; w < 16; w++) ptot += red[w];
+  const float ssim = (sums[1] + ptot) / p.n_pix;
   const float base = (1.0f - p.lambda_dssim) * l1 + p.lambda_dssim * (1.0f - ssim);
   float loss = base;
   float dwt = 0.f, scale = 0.f, patch = 0.f;
@@ -952,7 +954,7 @@ int gs_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_
   if (n_partials < 0 || n_partials > 0x7FFFFFFF || (n_partials > 0 && !ssim_partials)) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(lgdwt_combine_kernel, dim3(1), dim3(GS_BLOCK), 0, s, sums, running_mean, *p, out, ssim_partials,
+  hipLaunchKernelGGL(lgdwt_combine_kernel, dim3(1), dim3(1024), 0, s, sums, running_mean, *p, out, ssim_partials,
                      (int)n_partials);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
