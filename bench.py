@@ -260,7 +260,9 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": sb[dom], "ms_per_launch": stages[dom]["ms_per_launch"],
-                        "note": "blend kernels are VALU/LDS-bound by construction (SURVEY 8d); "
+                        "note": "blend kernels are VALU-bound by construction (SURVEY 8d): render_bwd keeps the VALU "
+                                "busy 86 %% of all SIMD cycles (SQ_ACTIVE_INST_VALU, profiles/r01_sq_counters.csv) and "
+                                "moves 150 MB of HBM traffic for 875 MB of algorithmic bytes; "
                                 "step-level algorithmic bytes %.3f GB/view -> %.1f GB/s" % (
                                     (902 * P + 172 * R_last + 84 * N) / 1e9,
                                     (902 * P + 172 * R_last + 84 * N) / 1e9 * value / world)}
