@@ -41,24 +41,40 @@ __global__ void __launch_bounds__(GS_BLOCK) bin_prepare_kernel(GeomHeader* hdr, 
 // Per pass: (a) per-workgroup digit histograms (digit-major table), (b) exclusive scan, (c) scatter.
 // A workgroup owns a 4096-key tile; wave w owns the contiguous quarter [w*1024, (w+1)*1024).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GS_BLOCK) rs_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* n_dev,
-                                                           int shift, uint32_t* __restrict__ hist, uint32_t nblk) {
-  __shared__ uint32_t h[GS_BLOCK / 64][RS_RADIX];  // one private histogram per wave
+// 1024 threads per 4096-key tile: a wave counts 256 keys in 4 rounds.  The kernel is latency-bound (one workgroup's
+// chain: global load -> LDS atomics, serialised where lanes share a digit -> barrier -> store), so the chain is made
+// short rather than the workgroup small: with 256 threads (16 rounds per wave) a pass took 18 us at 9.8 M keys.
+#define RS_HIST_THREADS 1024
+__global__ void __launch_bounds__(RS_HIST_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* n_dev,
+                                                                  int shift, uint32_t* __restrict__ hist, uint32_t nblk) {
+  __shared__ uint32_t h[RS_HIST_THREADS / 64][RS_RADIX];  // one private histogram per wave
   const uint32_t n = *n_dev;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int NW = RS_HIST_THREADS / 64, PER_WAVE = RS_TILE / NW, ROUNDS = PER_WAVE / 64;
 #pragma unroll
-  for (int w = 0; w < GS_BLOCK / 64; w++) h[w][tid] = 0;
+  for (int k = tid; k < NW * RS_RADIX; k += RS_HIST_THREADS) (&h[0][0])[k] = 0;
   __syncthreads();
-  const uint32_t w0 = blockIdx.x * RS_TILE + wid * (RS_TILE / 4);
+  const uint32_t w0 = blockIdx.x * RS_TILE + wid * PER_WAVE;
   if (w0 < n) {
+    uint32_t k[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
       const uint32_t i = w0 + r * 64 + lane;
-      if (i < n) atomicAdd(&h[wid][(keys[i] >> shift) & 0xFFu], 1u);
+      k[r] = i < n ? keys[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+      const uint32_t i = w0 + r * 64 + lane;
+      if (i < n) atomicAdd(&h[wid][(k[r] >> shift) & 0xFFu], 1u);
     }
   }
   __syncthreads();
-  hist[(size_t)tid * nblk + blockIdx.x] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+  if (tid < RS_RADIX) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) t += h[w][tid];
+    hist[(size_t)tid * nblk + blockIdx.x] = t;
+  }
 }
 
 // in-place exclusive scan of sums[nb] by ONE workgroup; total -> sums[nb]
@@ -129,33 +145,43 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_rowscan_kernel(uint32_t* __restri
   if (tid == 0) totals[blockIdx.x] = carry;
 }
 
-// Stable scatter.  Phase 1: every wave ranks its 1024 keys in 16 rounds of 64 with wave-level
+// Stable scatter.  Phase 1: every wave ranks its RS_TILE / NW keys in rounds of 64 with wave-level
 // match-any (8 ballots per round; no barrier, LDS traffic stays inside the wave) and builds its private
-// digit histogram.  Phase 2: 256 threads turn the four wave histograms into per-wave offsets inside the tile.
+// digit histogram.  Phase 2: 256 threads turn the NW wave histograms into per-wave offsets inside the tile.
 // Phase 3: keys/values are exchanged through LDS into digit order and stored as contiguous runs.
-__global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __restrict__ kin,
-                                                              const uint32_t* __restrict__ vin,  // NULL: value = index
-                                                              uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                              const uint32_t* n_dev, int shift,
-                                                              const uint32_t* __restrict__ hist, uint32_t nblk,
-                                                              const uint32_t* __restrict__ totals) {
-  __shared__ uint32_t s_hist[GS_BLOCK / 64][RS_RADIX];  // phase 1: wave digit counts; phase 3: output bases
+#define RS_SCATTER_THREADS 512
+template <int NT>
+__global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restrict__ kin,
+                                                        const uint32_t* __restrict__ vin,  // NULL: value = index
+                                                        uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                        const uint32_t* n_dev, int shift,
+                                                        const uint32_t* __restrict__ hist, uint32_t nblk,
+                                                        const uint32_t* __restrict__ totals) {
+  constexpr int NW = NT / 64;               // waves; wave w ranks the contiguous RS_TILE / NW keys [w0, w0 + ...)
+  constexpr int ITEMS = RS_TILE / NT;       // keys per thread = ranking rounds per wave
+  static_assert(NT >= RS_RADIX && RS_TILE % NT == 0, "one thread per digit in phase 2");
+  __shared__ uint32_t s_hist[NW][RS_RADIX];  // phase 1: wave digit counts; phase 3: output bases
   const uint32_t n = *n_dev;
   const uint32_t t0 = blockIdx.x * RS_TILE;
   if (t0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #pragma unroll
-  for (int w = 0; w < GS_BLOCK / 64; w++) s_hist[w][tid] = 0;
+  for (int k = tid; k < NW * RS_RADIX; k += NT) (&s_hist[0][0])[k] = 0;
   __syncthreads();
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const uint32_t w0 = t0 + wid * (RS_TILE / 4);
-  uint32_t key[RS_ITEMS], val[RS_ITEMS], pre[RS_ITEMS];  // pre = same-digit keys of my wave before me
+  const uint32_t w0 = t0 + wid * (RS_TILE / NW);
+  uint32_t key[ITEMS], val[ITEMS], pre[ITEMS];  // pre = same-digit keys of my wave before me
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = w0 + r * 64 + lane;
     const bool valid = i < n;
     key[r] = valid ? kin[i] : 0xFFFFFFFFu;
     val[r] = valid ? (vin ? vin[i] : i) : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = w0 + r * 64 + lane;
+    const bool valid = i < n;
     const uint32_t d = (key[r] >> shift) & 0xFFu;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -171,42 +197,50 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __
     if (valid && rank == 0) s_hist[wid][d] = before + (uint32_t)__popcll(peers);
   }
   __syncthreads();
-  // Phase 2: digit `tid`: wave prefixes, workgroup-local exclusive digit offset (scan over the 256 digit totals)
-  // and the distance from the local to the global position of that digit's run.
-  __shared__ uint32_t s_loc[RS_RADIX];    // local start of each digit's run inside the 4096-key tile
+  // Phase 2: thread d < 256 owns digit d: wave prefixes, workgroup-local exclusive digit offset (scan over the 256
+  // digit totals) and the distance from the local to the global position of that digit's run.
   __shared__ uint32_t s_delta[RS_RADIX];  // global start - local start
-  __shared__ uint32_t s_wtot[GS_BLOCK / 64];
-  __shared__ uint32_t s_gtot[GS_BLOCK / 64];
-  {
-    const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid], c3 = s_hist[3][tid];
-    const uint32_t tot = c0 + c1 + c2 + c3;
-    const uint32_t gt = totals[tid];  // keys of digit `tid` in the whole array -> start of the digit = scan over digits
-    uint32_t inc = tot, ginc = gt;
+  __shared__ uint32_t s_wtot[RS_RADIX / 64];
+  __shared__ uint32_t s_gtot[RS_RADIX / 64];
+  const bool digit_thread = tid < RS_RADIX;
+  uint32_t cw[NW];
+  uint32_t tot = 0, gt = 0;
+  if (digit_thread) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, 64);
-      const uint32_t g = __shfl_up(ginc, off, 64);
-      if (lane >= off) {
-        inc += t;
-        ginc += g;
-      }
+    for (int w = 0; w < NW; w++) {
+      cw[w] = s_hist[w][tid];
+      tot += cw[w];
     }
-    if (lane == 63) {
-      s_wtot[wid] = inc;
-      s_gtot[wid] = ginc;
+    gt = totals[tid];  // keys of digit `tid` in the whole array -> start of the digit = scan over digits
+  }
+  uint32_t inc = tot, ginc = gt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    const uint32_t g = __shfl_up(ginc, off, 64);
+    if (lane >= off) {
+      inc += t;
+      ginc += g;
     }
-    __syncthreads();
+  }
+  if (digit_thread && lane == 63) {
+    s_wtot[wid] = inc;
+    s_gtot[wid] = ginc;
+  }
+  __syncthreads();
+  if (digit_thread) {
     uint32_t loc = inc - tot, gbase = ginc - gt;
     for (int w = 0; w < wid; w++) {
       loc += s_wtot[w];
       gbase += s_gtot[w];
     }
-    s_loc[tid] = loc;
     s_delta[tid] = gbase + hist[(size_t)tid * nblk + blockIdx.x] - loc;
-    s_hist[0][tid] = loc;
-    s_hist[1][tid] = loc + c0;
-    s_hist[2][tid] = loc + c0 + c1;
-    s_hist[3][tid] = loc + c0 + c1 + c2;
+    uint32_t run = loc;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      s_hist[w][tid] = run;
+      run += cw[w];
+    }
   }
   __syncthreads();
   // Phase 3: exchange through LDS so that every digit's keys are contiguous, then store: consecutive lanes write
@@ -215,7 +249,7 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __
   __shared__ uint32_t s_key[RS_TILE];
   __shared__ uint32_t s_val[RS_TILE];
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS; r++) {
     if (pre[r] != 0xFFFFFFFFu) {
       const uint32_t lp = s_hist[wid][(key[r] >> shift) & 0xFFu] + pre[r];
       s_key[lp] = key[r];
@@ -225,8 +259,8 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_scatter_kernel(const uint32_t* __
   __syncthreads();
   const uint32_t cnt = min((uint32_t)RS_TILE, n - t0);
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    const uint32_t i = r * GS_BLOCK + tid;
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = r * NT + tid;
     if (i < cnt) {
       const uint32_t k = s_key[i];
       const uint32_t pos = i + s_delta[(k >> shift) & 0xFFu];
@@ -421,12 +455,14 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
     const bool ext = first && first_keys != nullptr;
     const uint32_t* kin = ext ? first_keys : b.keys[cur];
     const uint32_t* vin = ext ? nullptr : b.vals[cur];
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, n_dev, shift, b.hist, nblk);
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, kin, n_dev, shift, b.hist, nblk);
     GS_LAUNCH_CHECK(s, debug);
     hipLaunchKernelGGL(rs_rowscan_kernel, dim3(RS_RADIX), dim3(GS_BLOCK), 0, s, b.hist, nblk, b.scan_tmp);
     GS_LAUNCH_CHECK(s, debug);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, vin, b.keys[cur ^ 1],
-                       b.vals[cur ^ 1], n_dev, shift, b.hist, nblk, b.scan_tmp);
+    // 512 threads per 4096-key tile (8 ranking rounds per wave): 0.213 ms for the two instance passes against 0.226 with
+    // 256 threads and 0.217 with 1024 - the pass is bound by one workgroup's dependent chain, not by throughput
+    hipLaunchKernelGGL(rs_scatter_kernel<RS_SCATTER_THREADS>, dim3(nblk), dim3(RS_SCATTER_THREADS), 0, s, kin, vin,
+                       b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, shift, b.hist, nblk, b.scan_tmp);
     GS_LAUNCH_CHECK(s, debug);
     cur ^= 1;
     first = false;
