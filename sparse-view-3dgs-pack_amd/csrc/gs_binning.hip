@@ -421,20 +421,33 @@ __global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, 
 // rasterizer_impl.cu:116-138 (keys hold the tile id only)
 __global__ void __launch_bounds__(GS_BLOCK) tile_ranges_kernel(const uint32_t* __restrict__ tkeys, const uint32_t* n_dev,
                                                                uint2* __restrict__ ranges) {
+  // four keys per thread (one 16-byte load + the key in front of them)
   const uint32_t L = *n_dev;
-  const uint32_t idx = blockIdx.x * GS_BLOCK + threadIdx.x;
-  if (idx >= L) return;
-  const uint32_t currtile = tkeys[idx];
-  if (idx == 0)
-    ranges[currtile].x = 0;
-  else {
-    const uint32_t prevtile = tkeys[idx - 1];
-    if (currtile != prevtile) {
-      ranges[prevtile].y = idx;
-      ranges[currtile].x = idx;
-    }
+  const uint32_t i0 = (blockIdx.x * GS_BLOCK + threadIdx.x) * 4u;
+  if (i0 >= L) return;
+  uint32_t k[4];
+  if (i0 + 3 < L) {
+    const uint4 q = reinterpret_cast<const uint4*>(tkeys)[i0 >> 2];
+    k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e++) k[e] = (i0 + e < L) ? tkeys[i0 + e] : 0u;
   }
-  if (idx == L - 1) ranges[currtile].y = L;
+  uint32_t prev = i0 ? tkeys[i0 - 1] : 0u;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const uint32_t idx = i0 + e;
+    if (idx >= L) break;
+    const uint32_t cur = k[e];
+    if (idx == 0) {
+      ranges[cur].x = 0;
+    } else if (cur != prev) {
+      ranges[prev].y = idx;
+      ranges[cur].x = idx;
+    }
+    if (idx == L - 1) ranges[cur].y = L;
+    prev = cur;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,7 +499,7 @@ int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_b
                        hipStream_t s) {
   // `ranges` was zeroed by launch_bin_prepare at the start of the phase
   if (n_bound > 0)
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((uint32_t)((n_bound + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, s,
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((uint32_t)((n_bound + 4 * GS_BLOCK - 1) / (4 * GS_BLOCK))), dim3(GS_BLOCK), 0, s,
                        tkeys, n_dev, ranges);
   return 0;
 }
