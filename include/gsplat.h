@@ -278,7 +278,8 @@ int gs_l1_dwt2_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int
 int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
                    const float* l1_coef_dev /*[1]*/, const float* coef_dev /*[8]*/, float* grad_pred,
                    int32_t accumulate, void* stream);
-/* like gs_ssim_fwd but returns sum(ssim_map) (+=, zero it first) instead of the map */
+/* like gs_ssim_fwd but returns sum(ssim_map) (+=, zero it first) instead of the map.  One atomic per workgroup on
+ * sum_out: prefer gs_ssim_fwd_partials below for large images (the atomics serialise: 98 vs 59 us at 1080p). */
 int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1,
                     float C2, float* sum_out, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
                     void* stream);
