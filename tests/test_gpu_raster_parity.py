@@ -161,10 +161,12 @@ def test_small_scenes_forward_state_and_gradients(hip, oracle, case):
 
 
 @pytest.mark.parametrize("kind,P,W,H,deg", [("init", 10000, 400, 400, 0), ("trained", 10000, 400, 400, 3),
-                                           ("trained", 60000, 800, 800, 3), ("trained", 30000, 1920, 1080, 2)])
+                                           ("trained", 60000, 800, 800, 3), ("trained", 30000, 1920, 1080, 2),
+                                           ("trained", 20000, 3840, 2160, 1), ("trained", 15000, 1921, 1081, 3)])
 def test_config_sized_scenes(hip, oracle, kind, P, W, H, deg):
     """BASELINE config-1 size (10 k Gaussians, 400x400) and larger images, incl. a 1080p tile grid
-    (120x68 tiles, last tile row half empty, 45-bit sort keys)."""
+    (120x68 tiles, last tile row half empty, 45-bit sort keys), a 4K grid (240x135 = 32 400 tiles: 15 tile bits, the
+    XCD-padded launch) and a size that is a multiple of nothing (1921x1081: partial tiles on both edges)."""
     gen = synthetic.init_like if kind == "init" else synthetic.trained_like
     sc = gen(P, seed=0, sh_degree=deg)
     cam = synthetic.orbit_cameras(W, H)[3]
