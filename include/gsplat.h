@@ -291,7 +291,8 @@ int gs_ssim_fwd_partials(const float* img1, const float* img2, int32_t B, int32_
                          float C2, float* partials, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
                          void* stream);
 /* like gs_ssim_bwd with dL_dmap == coef_dev[0] everywhere; optionally adds to dL_dimg1 and then zeroes the
- * result where clamp_src (the un-clamped render) lies outside [0,1] */
+ * result where clamp_src (the un-clamped render) lies outside [0,1].  With clamp_src given, img1 must be
+ * clamp(clamp_src, 0, 1) - the kernel then forms it from clamp_src instead of reading img1. */
 int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W,
                         const float* coef_dev, const float* dm_dmu1, const float* dm_dsigma1_sq,
                         const float* dm_dsigma12, float* dL_dimg1, int32_t accumulate, const float* clamp_src,

@@ -642,15 +642,16 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
     const int x = bx + lx, y = by + 4 * ly0 + m;
     if (x >= W || y >= H) continue;
     const size_t o = plane + (size_t)y * W + x;
+    // with clamp_src, img1 IS clamp(clamp_src, 0, 1) (gsplat.h): formed here instead of read (25 MB less at 1080p)
+    const float r = clamp_src ? clamp_src[o] : 0.f;
+    const float a1 = clamp_src ? (r < 0.f ? 0.f : (r > 1.f ? 1.f : r)) : img1[o];
     float dL = 0.0f;
     dL += out[m][0];
-    dL += img1[o] * 2.0f * out[m][1];
+    dL += a1 * 2.0f * out[m][1];
     dL += img2[o] * out[m][2];
     if (accumulate) dL += dL_dimg1[o];
-    if (clamp_src) {  // gradient of clamp(x, 0, 1) folded in: zero where the un-clamped source was outside [0, 1]
-      const float r = clamp_src[o];
-      if (r < 0.f || r > 1.f) dL = 0.f;
-    }
+    // gradient of clamp(x, 0, 1) folded in: zero where the un-clamped source was outside [0, 1]
+    if (clamp_src && (r < 0.f || r > 1.f)) dL = 0.f;
     dL_dimg1[o] = dL;
   }
 }
