@@ -127,7 +127,9 @@ extern "C" int gs_adam_step(float* params, const float* grads, float* exp_avg, f
   }
   const long long n4 = (n + 3) / 4;
   long long blocks = (n4 + GS_BLOCK - 1) / GS_BLOCK;
-  if (blocks > 8192) blocks = 8192;
+  // one float4 per thread up to 2^20 workgroups: 0.292 ms at 59 M elements against 0.315 with an 8192-workgroup
+  // grid-stride loop (and 0.331 with 2048) - short-lived workgroups keep more requests in flight
+  if (blocks > (1ll << 20)) blocks = 1ll << 20;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(GS_BLOCK), 0, s, params, grads, exp_avg, exp_avg_sq,
                      (long long)n, a, beta1, beta2, eps);
   GS_LAUNCH_CHECK(s, 0);
