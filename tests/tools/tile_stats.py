@@ -29,3 +29,33 @@ print("tiles %d  R %d" % (len(n), n.sum()))
 for name, a in (("list length", n), ("entries visited by bwd (max last contributor)", lmax)):
     print("%-48s mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %d  sum/4096 slots %.0f" %
           (name, a.mean(), np.percentile(a, 50), np.percentile(a, 90), np.percentile(a, 99), a.max(), a.sum() / 4096))
+
+# What a two-chunk emission would process: chunk A = the nearest f*P Gaussians of the depth order,
+# chunk B = the rest, only for tiles some pixel of which is not saturated when A's part of the list ends.
+pl = st["point_list"].long()
+depth = st["depths"].float()
+vis = st["radii"] > 0
+key = torch.where(vis, depth, torch.full_like(depth, float("inf")))
+order = torch.argsort(key, stable=True)
+rank = torch.empty_like(order)
+rank[order] = torch.arange(P)
+inst_rank = rank[pl]                                   # depth rank of every instance, in list order
+tile_of = torch.repeat_interleave(torch.arange(len(n)), torch.from_numpy(n))
+T = st["final_T"].reshape(H, W)
+padT = torch.zeros(((H + 15) // 16 * 16, gx * 16))
+padT[:H, :W] = T
+# a tile is "open-ended" if a pixel never saturated (it consumes its whole list).  final_T is the transmittance BEFORE
+# the entry that would have pushed it below 1e-4 (alpha <= 0.99), so a stopped pixel has final_T < 1e-2
+tile_maxT = padT.reshape(-1, 16, gx, 16).permute(0, 2, 1, 3).reshape(-1, 256).max(dim=1).values
+R = int(n.sum())
+for f in (0.05, 0.1, 0.2, 0.3, 0.5):
+    K = int(f * P)
+    in_a = inst_rank < K
+    a_len = torch.zeros(len(n), dtype=torch.long).index_add_(0, tile_of, in_a.long())
+    complete = (torch.from_numpy(lmax) <= a_len) & (tile_maxT < 1e-2)
+    complete |= a_len == torch.from_numpy(n)             # nothing left for B anyway
+    r_a = int(in_a.sum())
+    r_b = int((torch.from_numpy(n) - a_len)[~complete].sum())
+    print("f=%.2f  R_A %.2f M (%.0f %%)  tiles needing B %d of %d  R_B %.2f M (%.0f %%)  A+B %.0f %% of R" %
+          (f, r_a / 1e6, 100 * r_a / R, int((~complete).sum()), len(n), r_b / 1e6, 100 * r_b / R, 100 * (r_a + r_b) / R))
+print("tiles with an unsaturated pixel: %d of %d" % (int((tile_maxT >= 1e-2).sum()), len(n)))
