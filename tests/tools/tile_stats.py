@@ -59,3 +59,15 @@ for f in (0.05, 0.1, 0.2, 0.3, 0.5):
     print("f=%.2f  R_A %.2f M (%.0f %%)  tiles needing B %d of %d  R_B %.2f M (%.0f %%)  A+B %.0f %% of R" %
           (f, r_a / 1e6, 100 * r_a / R, int((~complete).sum()), len(n), r_b / 1e6, 100 * r_b / R, 100 * (r_a + r_b) / R))
 print("tiles with an unsaturated pixel: %d of %d" % (int((tile_maxT >= 1e-2).sum()), len(n)))
+
+# load balance of the one-wave-per-tile kernels over the 8 XCDs (work ~ entries visited per tile)
+gy = (H + 15) // 16
+work = torch.from_numpy(lmax).double().reshape(gy, gx)
+ntile = gx * gy
+per = (ntile + 7) // 8
+flat = work.reshape(-1)
+band = [float(flat[x * per:(x + 1) * per].sum()) for x in range(8)]
+rows = [float(work[x::8].sum()) for x in range(8)]
+cols = [float(flat[x::8].sum()) for x in range(8)]
+for name, v in (("contiguous bands (current)", band), ("tile rows interleaved", rows), ("tiles interleaved", cols)):
+    print("XCD work, %-28s max/mean %.3f   %s" % (name, max(v) / (sum(v) / 8), " ".join("%.0f" % (x / 1e3) for x in v)))
