@@ -92,6 +92,23 @@ def run_table(api, device):
     assert api.raw("knn_mean_dist2")(None, 8, buf.data_ptr(), buf.data_ptr(), 64, st) == E_NULL
     assert api.raw("knn_mean_dist2")(t["means"].data_ptr(), -1, buf.data_ptr(), buf.data_ptr(), 64, st) == E_SHAPE
     assert api.raw("knn_mean_dist2")(t["means"].data_ptr(), 0, buf.data_ptr(), buf.data_ptr(), 64, st) == 0
+    # fused-criterion entry points
+    img = torch.rand(3, 32, 32, device=device)
+    nine = torch.zeros(16, device=device)
+    from gsplat_amd.capi import GsLgdwtParams
+    lp = GsLgdwtParams()
+    lp.n_pix, lp.n_band1, lp.n_band2 = 3072.0, 768.0, 192.0
+    f = api.raw
+    assert f("l1_dwt2_fwd")(img.data_ptr(), img.data_ptr(), 3, 32, 32, None, nine.data_ptr(), st) == E_NULL
+    assert f("l1_dwt2_fwd")(img.data_ptr(), img.data_ptr(), 3, 0, 32, nine.data_ptr(), nine[1:].data_ptr(), st) == E_SHAPE
+    assert f("l1_dwt2_bwd")(img.data_ptr(), img.data_ptr(), 3, 32, 32, None, nine.data_ptr(), img.data_ptr(), 0, st) == E_NULL
+    assert f("l1_dwt2_bwd")(img.data_ptr(), img.data_ptr(), 0, 32, 32, nine.data_ptr(), nine.data_ptr(), img.data_ptr(), 0, st) == E_SHAPE
+    assert f("ssim_partials_count")(1, 3, 32, 32) == 3 and f("ssim_partials_count")(1, 3, 33, 65) == 3 * 2 * 3
+    assert f("ssim_partials_count")(0, 3, 32, 32) == 0
+    assert f("ssim_fwd_partials")(img.data_ptr(), img.data_ptr(), 1, 3, 32, 32, 1e-4, 9e-4, None, None, None, None, st) == E_NULL
+    assert f("lgdwt_combine_p")(None, None, 0, nine.data_ptr(), C.byref(lp), nine.data_ptr(), st) == E_NULL
+    assert f("lgdwt_combine_p")(nine.data_ptr(), None, 5, nine.data_ptr(), C.byref(lp), nine.data_ptr(), st) == E_SHAPE
+    assert f("lgdwt_combine_p")(nine.data_ptr(), None, -1, nine.data_ptr(), C.byref(lp), nine.data_ptr(), st) == E_SHAPE
     return t, v, g, s, bufs, wsb
 
 
