@@ -374,7 +374,7 @@ int gso_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R, size_t out[3],
   out[0] = geom_bytes((size_t)P);
   out[1] = img_bytes((size_t)W * H, T);
   out[2] = binning_bytes((size_t)std::max<int64_t>(R, 1));
-  if (bwd_ws) *bwd_ws = 128;
+  if (bwd_ws) *bwd_ws = 256 + (size_t)P * 16 * sizeof(float); /* receives the blend-backward sums (parity probe) */
   return GS_OK;
 }
 
@@ -950,12 +950,13 @@ static void preprocess_bwd_one(int idx, int D, int M, const GsView* v, const GsG
 
 static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
                          int64_t num_rendered, const float* dL_dcolor_img, const float* dL_dinvdepth_img,
-                         const float* fs_dL_ddepth, const float* fs_dL_dalpha, const GsGrads* out);
+                         const float* fs_dL_ddepth, const float* fs_dL_dalpha, const GsGrads* out,
+                         void* ws = nullptr, size_t ws_bytes = 0);
 
 int gso_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
                  int64_t num_rendered, const float* dL_dcolor_img, const float* dL_dinvdepth_img,
-                 const GsGrads* out, void* /*ws*/, size_t /*ws_bytes*/, void* /*stream*/) {
-  return backward_impl(v, g, radii, s, num_rendered, dL_dcolor_img, dL_dinvdepth_img, nullptr, nullptr, out);
+                 const GsGrads* out, void* ws, size_t ws_bytes, void* /*stream*/) {
+  return backward_impl(v, g, radii, s, num_rendered, dL_dcolor_img, dL_dinvdepth_img, nullptr, nullptr, out, ws, ws_bytes);
 }
 
 /* dgr_fsgs `rasterize_gaussians_backward`: image gradients of colour, depth and alpha. */
@@ -970,7 +971,8 @@ int gso_backward_fsgs(const GsView* v, const GsGaussians* g, const int32_t* radi
 
 static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
                          int64_t num_rendered, const float* dL_dcolor_img, const float* dL_dinvdepth_img,
-                         const float* fs_dL_ddepth, const float* fs_dL_dalpha, const GsGrads* out) {
+                         const float* fs_dL_ddepth, const float* fs_dL_dalpha, const GsGrads* out, void* ws,
+                         size_t ws_bytes) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!s || !out || !dL_dcolor_img) return GS_E_NULL;
@@ -1027,6 +1029,15 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     dL_dcolors[3 * i + 1] = (float)a[A_CG];
     dL_dcolors[3 * i + 2] = (float)a[A_CB];
     dL_dinvd[i] = (float)a[A_ID];
+  }
+  /* parity probe: the per-Gaussian sums of the blend backward (the double accumulators rounded once) in the product's
+   * 16-float gradient-row layout, so a test can compare this intermediate with the product's workspace */
+  if (ws && ws_bytes >= (size_t)P * 16 * sizeof(float)) {
+    float* rows = (float*)ws;
+    for (int i = 0; i < P; i++) {
+      const double* a = &acc[(size_t)i * A_N];
+      for (int k = 0; k < 16; k++) rows[(size_t)i * 16 + k] = k < A_N ? (float)a[k] : 0.f;
+    }
   }
   const float* cov3D_ptr = g->cov3D_precomp ? g->cov3D_precomp : gs.cov3D;
   const float* dinvd_ptr = dL_dinvdepth_img ? dL_dinvd.data() : nullptr;
@@ -1120,6 +1131,37 @@ int gso_test_sh_bwd(int32_t P, int32_t deg, int32_t M, const float* means, const
                     const uint8_t* clamped, const float* dL_dcolor, float* dL_dmeans /* += */, float* dL_dsh) {
   V3 cp = {campos[0], campos[1], campos[2]};
   for (int i = 0; i < P; i++) computeColorFromSH_bwd(i, deg, M, means, cp, shs, clamped, dL_dcolor, dL_dmeans, dL_dsh);
+  return GS_OK;
+}
+
+/* computeCov3D forward / backward (forward.cu:114-148, backward.cu:330-393) and the homogeneous projection of
+ * preprocessCUDA (forward.cu:193-195) on their own: pinned by tests/golden/geometry.npz, which the reference's python
+ * covariance path (utils/general_utils.py:64-110, scene/gaussian_model.py:33-37) and geom_transform_points
+ * (utils/graphics_utils.py:22-29) produced. */
+int gso_test_cov3d_fwd(int32_t P, const float* scales, float mod, const float* rots, float* cov3D) {
+  for (int i = 0; i < P; i++) {
+    V3 sc = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    V4 rq = {rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]};
+    computeCov3D(sc, mod, rq, cov3D + 6 * (size_t)i);
+  }
+  return GS_OK;
+}
+int gso_test_cov3d_bwd(int32_t P, const float* scales, float mod, const float* rots, const float* dL_dcov3D,
+                       float* dL_dscales, float* dL_drots) {
+  for (int i = 0; i < P; i++) {
+    V3 sc = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    V4 rq = {rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]};
+    computeCov3D_bwd(i, sc, mod, rq, dL_dcov3D, dL_dscales, dL_drots);
+  }
+  return GS_OK;
+}
+int gso_test_project(int32_t P, const float* means, const float* projmatrix, float* p_proj) {
+  for (int i = 0; i < P; i++) {
+    V3 p = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    V4 h = transformPoint4x4(p, projmatrix);
+    float p_w = 1.0f / (h.w + 0.0000001f);
+    p_proj[3 * i] = h.x * p_w; p_proj[3 * i + 1] = h.y * p_w; p_proj[3 * i + 2] = h.z * p_w;
+  }
   return GS_OK;
 }
 

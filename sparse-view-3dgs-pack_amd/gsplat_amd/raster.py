@@ -53,6 +53,9 @@ class RasterBackend:
         # one-shot output arena for the next backward: {"means3D": [P,3], "sh": [P,M,3]} fp32 tensors to write
         # dL_dmeans3D / dL_dsh INTO (e.g. views of a flat gradient buffer) instead of fresh allocations
         self.grad_arena = None
+        # parity probes: keep the backward workspace (the per-Gaussian 16-float gradient rows of the blend backward)
+        self.keep_workspace = False
+        self.last_workspace = None
 
     # ------------------------------------------------------------------ helpers
     def _stream(self, device):
@@ -290,6 +293,8 @@ class RasterBackend:
         radii = radii.contiguous()
         _, _, _, wsb = self.scratch_bytes(P, W, H, R)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
+        if self.keep_workspace:
+            self.last_workspace = ws
         cap = R if binningBuffer.numel() == 0 else self._capacity_of(P, W, H, binningBuffer.numel(), R)
         s = self._scratch(geomBuffer, imgBuffer, binningBuffer, cap)
         grads = GsGrads()

@@ -17,6 +17,14 @@ Fixtures are data only (inputs + the reference's outputs); no reference source i
   nir_loss.npz    the multispectral step's loss (mult-dwtgs/train_nir.py:88-104) from the reference's own functions
                   (mult-dwtgs/utils/loss_utils.py: l1_loss, ssim, combined_nir_loss) with autograd gradients
                   -> pins gsplat_amd.trainer.NirCriterion
+  geometry.npz    the reference's python covariance path - build_scaling_rotation / build_rotation / strip_symmetric
+                  (LGDWT-GS/utils/general_utils.py:64-110; their hard-coded device="cuda" is redirected to the CPU) composed
+                  as build_covariance_from_scaling_rotation does (LGDWT-GS/scene/gaussian_model.py:33-37: L = R S,
+                  Sigma = L L^T, upper triangle), with autograd gradients w.r.t. scales and (unit) quaternions, and
+                  geom_transform_points (LGDWT-GS/utils/graphics_utils.py:22-29: the "+1e-7" homogeneous divide)
+                  -> pins computeCov3D forward (forward.cu:114-148) and backward (backward.cu:330-393), the projection
+                  of preprocessCUDA (forward.cu:193-195), and - rendered with cov3D_precomp - the python-cov path of
+                  LGDWT-GS/gaussian_renderer/__init__.py:64-68
   colmap/         a small COLMAP model (cameras.bin, images.bin, points3D.bin + the .txt forms) written by
                   gsplat_amd.io.write_colmap_binary from seeded data, and colmap_expected.npz = what the REFERENCE's
                   own readers (LGDWT-GS/scene/colmap_loader.py) return for those files, plus its qvec2rotmat /
@@ -45,6 +53,63 @@ graphics = load(REF + "/LGDWT-GS/utils/graphics_utils.py", "ref_graphics_utils")
 image_utils = load(REF + "/LGDWT-GS/utils/image_utils.py", "ref_image_utils")
 general = load(REF + "/LGDWT-GS/utils/general_utils.py", "ref_general_utils")
 loss_utils = load(REF + "/gaussian-splatting/utils/loss_utils.py", "ref_loss_utils")
+
+
+class _CpuTorch:
+    """`torch` as seen by the reference's general_utils: three helpers there hard-code device="cuda"
+    (general_utils.py:65,83,102); the same calls, with the tensors created on the CPU."""
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    @staticmethod
+    def zeros(*a, **k):
+        k.pop("device", None)
+        return torch.zeros(*a, **k)
+
+
+def gen_geometry():
+    general.torch = _CpuTorch()
+    try:
+        g = torch.Generator().manual_seed(4321)
+        P = 128
+        scales = torch.exp(torch.randn((P, 3), generator=g) * 0.9 - 2.5)
+        q = torch.randn((P, 4), generator=g)
+        q = q / q.norm(dim=1, keepdim=True)  # the caller hands F.normalize(_rotation) to the rasterizer
+        w6 = torch.randn((P, 6), generator=g)
+        out = dict(scales=scales.numpy(), quats=q.numpy(), w6=w6.numpy())
+        for tag, mod in (("m10", 1.0), ("m07", 0.7)):
+            s = scales.clone().requires_grad_(True)
+            r = q.clone().requires_grad_(True)
+            L = general.build_scaling_rotation(mod * s, r)          # gaussian_model.py:34
+            actual_covariance = L @ L.transpose(1, 2)               # :35
+            symm = general.strip_symmetric(actual_covariance)       # :36
+            (symm * w6).sum().backward()
+            out["cov6_" + tag] = symm.detach().numpy()
+            out["dscales_" + tag] = s.grad.numpy()
+            out["dquats_" + tag] = r.grad.numpy()  # through build_rotation's own normalisation: tangential part only
+        out["mods"] = np.array([1.0, 0.7])
+        # homogeneous projection with the camera conventions of cameras.py:86-89
+        rng = np.random.RandomState(11)
+        R = np.linalg.qr(rng.randn(3, 3))[0]
+        if np.linalg.det(R) < 0:
+            R[:, 0] = -R[:, 0]
+        t = np.array([0.3, -0.2, 4.0])
+        W, H = 1237, 822
+        FoVx = 0.69
+        FoVy = graphics.focal2fov(graphics.fov2focal(FoVx, W), H)
+        wvt = torch.tensor(graphics.getWorld2View2(R, t)).transpose(0, 1)
+        proj = graphics.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=FoVx, fovY=FoVy).transpose(0, 1)
+        full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+        pts = torch.rand((P, 3), generator=g) * 2.6 - 1.3
+        out["points"] = pts.numpy()
+        out["full_proj_transform"] = full.numpy()
+        out["world_view_transform"] = wvt.numpy()
+        out["p_proj"] = graphics.geom_transform_points(pts, full).numpy()
+        out["p_view"] = graphics.geom_transform_points(pts, wvt).numpy()
+        np.savez(os.path.join(HERE, "geometry.npz"), **out)
+    finally:
+        general.torch = torch
 
 
 def gen_nir_loss():
@@ -219,4 +284,5 @@ if __name__ == "__main__":
     gen_schedule()
     gen_colmap()
     gen_nir_loss()
+    gen_geometry()
     print("golden fixtures written to", HERE)

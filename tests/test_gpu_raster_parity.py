@@ -283,3 +283,36 @@ def test_two_contexts_alive_rgb_plus_nir_pass(hip, oracle):
     assert float((outs["hip"]["img"] - outs["oracle"]["img"]).abs().max()) < 1e-5
     grads_close({k: v for k, v in outs["hip"].items() if k != "img"}, {k: v for k, v in outs["oracle"].items() if k != "img"},
                 "rgb+nir")
+
+
+def test_reference_python_geometry_fixture_on_the_gpu(hip):
+    """tests/golden/geometry.npz (the reference's python covariance path and geom_transform_points, see
+    make_golden.gen_geometry) against the HIP library's own state: cov3D of gs_export_geom == the python covariance,
+    the pixel mean == ndc2Pix of geom_transform_points, and the python-cov render path (cov3D_precomp,
+    gaussian_renderer/__init__.py:64-68) == the scale / rotation path."""
+    import os
+
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geometry.npz"))
+    dev = torch.device("cuda")
+    P = z["scales"].shape[0]
+    W, H, FoVx = 1237, 822, 0.69
+    FoVy = synthetic.focal2fov(synthetic.fov2focal(FoVx, W), H)
+    wvt, full = torch.tensor(z["world_view_transform"]), torch.tensor(z["full_proj_transform"])
+    cam = synthetic.Camera(H, W, FoVx, FoVy, wvt, full, wvt.inverse()[3, :3].contiguous())
+    g = torch.Generator().manual_seed(5)
+    base = dict(means3D=torch.tensor(z["points"]), opacities=torch.sigmoid(torch.randn((P, 1), generator=g)),
+                colors_precomp=torch.rand((P, 3), generator=g), sh_degree=0)
+    sr = dict(base, scales=torch.tensor(z["scales"]) * 6.0, rotations=torch.tensor(z["quats"]))
+    st = forward_state(hip, sr, cam, dev, torch.zeros(3), False)
+    vis = st["radii"] > 0
+    assert int(vis.sum()) > P // 2
+    ref_cov = torch.tensor(z["cov6_m10"]) * 36.0
+    assert float((st["cov3D"][vis] - ref_cov[vis]).abs().max()) <= 2e-6 * float(ref_cov.abs().max())
+    pp = torch.tensor(z["p_proj"]).double()
+    px = torch.stack([((pp[:, 0] + 1.0) * W - 1.0) * 0.5, ((pp[:, 1] + 1.0) * H - 1.0) * 0.5], dim=1)
+    assert float((st["means2D"][vis].double() - px[vis]).abs().max()) <= 5e-4  # pixels; fp32 at |x| ~ 1e3
+    assert float((st["depths"][vis].double() - torch.tensor(z["p_view"]).double()[vis, 2]).abs().max()) <= 1e-5
+    pc = forward_state(hip, dict(base, cov3D_precomp=ref_cov), cam, dev, torch.zeros(3), False)
+    assert int((pc["radii"] != st["radii"]).sum()) <= 1
+    assert float((pc["color"] - st["color"]).abs().max()) < 2e-5
