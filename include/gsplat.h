@@ -199,6 +199,16 @@ int gs_export_binning(const GsScratch* scratch, int64_t num_rendered, uint64_t* 
 int gs_export_img(const GsScratch* scratch, int32_t W, int32_t H, float* final_T,
                   uint32_t* n_contrib, uint32_t* ranges /*[T,2]*/, void* stream);
 
+/* Stage 2 of gs_backward on its own (parity export): the per-Gaussian chain rule from given sums of the blend
+ * backward.  rows [P,16] (device): mean2D.x, mean2D.y, conic.xx, conic.xy, conic.yy, opacity, r, g, b, depth slot,
+ * 4th channel, 5 pad - what stage 1 leaves in the workspace (backward.cu:593-635 accumulates the same ten sums with
+ * atomics).  depth_mode: 0 none, 1 the depth slot is dL/d(inverse depth) (dr_aa), 2 dL/d(depth) (FSGS generation).
+ * Lets a test feed both implementations the SAME sums and so separate the (ill-conditioned)
+ * conic -> scale / rotation chain from the accumulation that precedes it. */
+int gs_backward_from_rows(const GsView* view, const GsGaussians* g, const int32_t* radii,
+                          const GsScratch* scratch, const float* rows, int32_t depth_mode,
+                          const GsGrads* grads, void* stream);
+
 /* ---- simple-knn ---- */
 /* out[i] = mean of the 3 smallest squared distances from point i to the other points.
  * tmp: >= gs_knn_tmp_bytes(P) bytes of device scratch. */

@@ -948,6 +948,64 @@ static void preprocess_bwd_one(int idx, int D, int M, const GsView* v, const GsG
   }
 }
 
+/* Stage 2 of the backward: computeCov2DCUDA + preprocessCUDA backward (backward.cu:147-449) from the per-Gaussian sums
+ * of the blend backward, rows [P][16] = mean2D.x, mean2D.y, conic.xx, conic.xy, conic.yy, opacity, r, g, b, depth slot.
+ * depth_mode: 0 none, 1 inverse depth (dr_aa), 2 depth (FSGS generation). */
+static void stage2_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const Geom& gs,
+                             const float* rows, int depth_mode, const GsGrads* out) {
+  const int P = g->P, W = v->image_width, H = v->image_height, M = g->M;
+  const float focal_y = H / (2.0f * v->tanfovy);
+  const float focal_x = W / (2.0f * v->tanfovx);
+  std::vector<float> dL_dmean2D((size_t)P * 3, 0.f), dL_dconic((size_t)P * 3, 0.f), dL_dopacity(P, 0.f),
+      dL_dcolors((size_t)P * 3, 0.f), dL_dinvd(P, 0.f), dL_dmeans3D((size_t)P * 3, 0.f), dL_dcov3D((size_t)P * 6, 0.f),
+      dL_dsh((size_t)P * std::max(M, 1) * 3, 0.f), dL_dscales((size_t)P * 3, 0.f), dL_drot((size_t)P * 4, 0.f);
+  for (int i = 0; i < P; i++) {
+    const float* a = rows + (size_t)i * 16;
+    dL_dmean2D[3 * i] = a[A_MX];
+    dL_dmean2D[3 * i + 1] = a[A_MY];
+    dL_dconic[3 * i] = a[A_CXX];
+    dL_dconic[3 * i + 1] = a[A_CXY];
+    dL_dconic[3 * i + 2] = a[A_CYY];
+    dL_dopacity[i] = a[A_OP];
+    dL_dcolors[3 * i] = a[A_CR];
+    dL_dcolors[3 * i + 1] = a[A_CG];
+    dL_dcolors[3 * i + 2] = a[A_CB];
+    dL_dinvd[i] = a[A_ID];
+  }
+  const float* cov3D_ptr = g->cov3D_precomp ? g->cov3D_precomp : gs.cov3D;
+  const float* dinvd_ptr = depth_mode == 1 ? dL_dinvd.data() : nullptr;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < P; i++)
+    computeCov2D_bwd(i, v, g->means3D, radii, cov3D_ptr, focal_x, focal_y, g->opacities, dL_dconic.data(),
+                     dL_dopacity.data(), dinvd_ptr, dL_dmeans3D.data(), dL_dcov3D.data());
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < P; i++)
+    preprocess_bwd_one(i, v->sh_degree, M, v, g, radii, gs.clamped, dL_dmean2D.data(), dL_dmeans3D.data(),
+                       dL_dcolors.data(), dL_dcov3D.data(), dL_dsh.data(), dL_dscales.data(), dL_drot.data(),
+                       depth_mode == 2 ? dL_dinvd.data() : nullptr);
+  if (out->dL_dmeans3D) memcpy(out->dL_dmeans3D, dL_dmeans3D.data(), 12 * (size_t)P);
+  if (out->dL_dmeans2D) memcpy(out->dL_dmeans2D, dL_dmean2D.data(), 12 * (size_t)P);
+  if (out->dL_dsh && M > 0) memcpy(out->dL_dsh, dL_dsh.data(), 12 * (size_t)P * M);
+  if (out->dL_dcolors) memcpy(out->dL_dcolors, dL_dcolors.data(), 12 * (size_t)P);
+  if (out->dL_dopacity) memcpy(out->dL_dopacity, dL_dopacity.data(), 4 * (size_t)P);
+  if (out->dL_dscales) memcpy(out->dL_dscales, dL_dscales.data(), 12 * (size_t)P);
+  if (out->dL_drotations) memcpy(out->dL_drotations, dL_drot.data(), 16 * (size_t)P);
+  if (out->dL_dcov3D) memcpy(out->dL_dcov3D, dL_dcov3D.data(), 24 * (size_t)P);
+}
+
+int gso_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
+                           const float* rows, int32_t depth_mode, const GsGrads* out, void* /*stream*/) {
+  int rc = check_args(v, g);
+  if (rc) return rc;
+  if (!s || !out) return GS_E_NULL;
+  if (depth_mode < 0 || depth_mode > 2) return GS_E_SHAPE;
+  if (g->P == 0) return GS_OK;
+  if (!radii || !s->geom || !rows) return GS_E_NULL;
+  Geom gs = geom_from(s->geom, g->P);
+  stage2_from_rows(v, g, radii, gs, rows, depth_mode, out);
+  return GS_OK;
+}
+
 static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
                          int64_t num_rendered, const float* dL_dcolor_img, const float* dL_dinvdepth_img,
                          const float* fs_dL_ddepth, const float* fs_dL_dalpha, const GsGrads* out,
@@ -976,7 +1034,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!s || !out || !dL_dcolor_img) return GS_E_NULL;
-  const int P = g->P, W = v->image_width, H = v->image_height, M = g->M;
+  const int P = g->P, W = v->image_width, H = v->image_height;
   if (P == 0) return GS_OK;
   if (!radii || !s->geom || !s->img) return GS_E_NULL;
   const uint32_t gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
@@ -985,8 +1043,6 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   Img im = img_from(s->img, N, T);
   if (gs.hdr->num_rendered != num_rendered) return GS_E_SHAPE;
   Binning b = binning_from(s->binning, (size_t)std::max<int64_t>(s->binning_capacity, 1));
-  const float focal_y = H / (2.0f * v->tanfovy);
-  const float focal_x = W / (2.0f * v->tanfovx);
   const float* color_ptr = g->colors_precomp ? g->colors_precomp : gs.rgb;
 
   /* zero-initialised gradient tensors, rasterize_points.cu:163-178 */
@@ -1014,50 +1070,20 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
         }
     }
   }
-  std::vector<float> dL_dmean2D((size_t)P * 3, 0.f), dL_dconic((size_t)P * 3, 0.f), dL_dopacity(P, 0.f),
-      dL_dcolors((size_t)P * 3, 0.f), dL_dinvd(P, 0.f), dL_dmeans3D((size_t)P * 3, 0.f), dL_dcov3D((size_t)P * 6, 0.f),
-      dL_dsh((size_t)P * std::max(M, 1) * 3, 0.f), dL_dscales((size_t)P * 3, 0.f), dL_drot((size_t)P * 4, 0.f);
+  /* the per-Gaussian sums (double accumulators rounded once) in the product's 16-float row layout */
+  std::vector<float> rows_own;
+  float* rows = nullptr;
+  if (ws && ws_bytes >= (size_t)P * 16 * sizeof(float)) {
+    rows = (float*)ws; /* parity probe: a test can compare this intermediate with the product's workspace */
+  } else {
+    rows_own.resize((size_t)P * 16);
+    rows = rows_own.data();
+  }
   for (int i = 0; i < P; i++) {
     const double* a = &acc[(size_t)i * A_N];
-    dL_dmean2D[3 * i] = (float)a[A_MX];
-    dL_dmean2D[3 * i + 1] = (float)a[A_MY];
-    dL_dconic[3 * i] = (float)a[A_CXX];
-    dL_dconic[3 * i + 1] = (float)a[A_CXY];
-    dL_dconic[3 * i + 2] = (float)a[A_CYY];
-    dL_dopacity[i] = (float)a[A_OP];
-    dL_dcolors[3 * i] = (float)a[A_CR];
-    dL_dcolors[3 * i + 1] = (float)a[A_CG];
-    dL_dcolors[3 * i + 2] = (float)a[A_CB];
-    dL_dinvd[i] = (float)a[A_ID];
+    for (int k = 0; k < 16; k++) rows[(size_t)i * 16 + k] = k < A_N ? (float)a[k] : 0.f;
   }
-  /* parity probe: the per-Gaussian sums of the blend backward (the double accumulators rounded once) in the product's
-   * 16-float gradient-row layout, so a test can compare this intermediate with the product's workspace */
-  if (ws && ws_bytes >= (size_t)P * 16 * sizeof(float)) {
-    float* rows = (float*)ws;
-    for (int i = 0; i < P; i++) {
-      const double* a = &acc[(size_t)i * A_N];
-      for (int k = 0; k < 16; k++) rows[(size_t)i * 16 + k] = k < A_N ? (float)a[k] : 0.f;
-    }
-  }
-  const float* cov3D_ptr = g->cov3D_precomp ? g->cov3D_precomp : gs.cov3D;
-  const float* dinvd_ptr = dL_dinvdepth_img ? dL_dinvd.data() : nullptr;
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < P; i++)
-    computeCov2D_bwd(i, v, g->means3D, radii, cov3D_ptr, focal_x, focal_y, g->opacities, dL_dconic.data(),
-                     dL_dopacity.data(), dinvd_ptr, dL_dmeans3D.data(), dL_dcov3D.data());
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < P; i++)
-    preprocess_bwd_one(i, v->sh_degree, M, v, g, radii, gs.clamped, dL_dmean2D.data(), dL_dmeans3D.data(),
-                       dL_dcolors.data(), dL_dcov3D.data(), dL_dsh.data(), dL_dscales.data(), dL_drot.data(),
-                       fs_dL_dalpha ? dL_dinvd.data() : nullptr);
-  if (out->dL_dmeans3D) memcpy(out->dL_dmeans3D, dL_dmeans3D.data(), 12 * (size_t)P);
-  if (out->dL_dmeans2D) memcpy(out->dL_dmeans2D, dL_dmean2D.data(), 12 * (size_t)P);
-  if (out->dL_dsh && M > 0) memcpy(out->dL_dsh, dL_dsh.data(), 12 * (size_t)P * M);
-  if (out->dL_dcolors) memcpy(out->dL_dcolors, dL_dcolors.data(), 12 * (size_t)P);
-  if (out->dL_dopacity) memcpy(out->dL_dopacity, dL_dopacity.data(), 4 * (size_t)P);
-  if (out->dL_dscales) memcpy(out->dL_dscales, dL_dscales.data(), 12 * (size_t)P);
-  if (out->dL_drotations) memcpy(out->dL_drotations, dL_drot.data(), 16 * (size_t)P);
-  if (out->dL_dcov3D) memcpy(out->dL_dcov3D, dL_dcov3D.data(), 24 * (size_t)P);
+  stage2_from_rows(v, g, radii, gs, rows, fs_dL_dalpha ? 2 : (dL_dinvdepth_img ? 1 : 0), out);
   return GS_OK;
 }
 

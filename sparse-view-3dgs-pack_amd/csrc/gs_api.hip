@@ -219,6 +219,36 @@ int gs_backward_fsgs(const GsView* v, const GsGaussians* g, const int32_t* radii
                        workspace_bytes, stream);
 }
 
+static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians* g, const int32_t* radii, const GeomView& gv,
+                                             int depth_mode, const float* rows, const GsGrads* grads) {
+  PreprocessBwdArgs a;
+  a.P = g->P;
+  a.D = v->sh_degree;
+  a.M = g->M;
+  a.means3D = g->means3D;
+  a.radii = radii;
+  a.shs = g->shs;
+  a.scales = g->scales;
+  a.rotations = g->rotations;
+  a.opacities = g->opacities;
+  a.colors_precomp = g->colors_precomp;
+  a.scale_modifier = v->scale_modifier;
+  a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : gv.cov3D;
+  a.viewmatrix = v->viewmatrix;
+  a.projmatrix = v->projmatrix;
+  a.campos = v->campos;
+  a.focal_y = v->image_height / (2.0f * v->tanfovy);
+  a.focal_x = v->image_width / (2.0f * v->tanfovx);
+  a.tan_fovx = v->tanfovx;
+  a.tan_fovy = v->tanfovy;
+  a.antialiasing = v->antialiasing;
+  a.has_invdepth = depth_mode;
+  a.grad_rows = rows;
+  a.splat = gv.splat;
+  a.out = *grads;
+  return a;
+}
+
 static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
                          int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra,
                          int fsgs, const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream) {
@@ -251,35 +281,30 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     }
     GS_LAUNCH_CHECK(s, v->debug);
   }
-  PreprocessBwdArgs a;
-  a.P = P;
-  a.D = v->sh_degree;
-  a.M = g->M;
-  a.means3D = g->means3D;
-  a.radii = radii;
-  a.shs = g->shs;
-  a.scales = g->scales;
-  a.rotations = g->rotations;
-  a.opacities = g->opacities;
-  a.colors_precomp = g->colors_precomp;
-  a.scale_modifier = v->scale_modifier;
-  a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : gv.cov3D;
-  a.viewmatrix = v->viewmatrix;
-  a.projmatrix = v->projmatrix;
-  a.campos = v->campos;
-  a.focal_y = H / (2.0f * v->tanfovy);
-  a.focal_x = W / (2.0f * v->tanfovx);
-  a.tan_fovx = v->tanfovx;
-  a.tan_fovy = v->tanfovy;
-  a.antialiasing = v->antialiasing;
-  a.has_invdepth = fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0);
-  a.grad_rows = rows;
-  a.splat = gv.splat;
-  a.out = *grads;
+  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, grads);
   {
     GS_PROF(ST_PREPROCESS_BWD, s);
     launch_preprocess_bwd(a, s);
   }
+  GS_LAUNCH_CHECK(s, v->debug);
+  return GS_OK;
+}
+
+int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, const float* rows,
+                          int32_t depth_mode, const GsGrads* grads, void* stream) {
+  int rc = check_args(v, g);
+  if (rc) return rc;
+  if (!sc || !grads) return GS_E_NULL;
+  if (depth_mode < 0 || depth_mode > 2) return GS_E_SHAPE;
+  const int P = g->P;
+  if (P == 0) return GS_OK;
+  if (!radii || !sc->geom || !rows) return GS_E_NULL;
+  if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
+  hipStream_t s = (hipStream_t)stream;
+  GeomView gv = geom_view(sc->geom, (size_t)P);
+  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, depth_mode, rows, grads);
+  (void)hipGetLastError();
+  launch_preprocess_bwd(a, s);
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
 }

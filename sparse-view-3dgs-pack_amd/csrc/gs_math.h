@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define GS_DEV static __device__ __forceinline__
+#define GS_DEV static __host__ __device__ __forceinline__
 
 struct V3 {
   float x, y, z;

@@ -329,6 +329,40 @@ class RasterBackend:
                           _ptr(ws), ws.numel(), stream)
         return ret
 
+    def backward_from_rows(self, rows, bg, means3D, radii, colors_precomp, opacities, scales, rotations, scale_modifier,
+                           cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, H, W, sh, degree, campos, geomBuffer,
+                           antialiasing, depth_mode=0):
+        """Stage 2 of the backward alone (gs_backward_from_rows): the per-Gaussian chain rule applied to GIVEN sums of the
+        blend backward, rows [P,16].  Same return tuple as rasterize_gaussians_backward.  Parity tests only."""
+        self._check_device(means3D)
+        device = means3D.device
+        P = int(means3D.shape[0])
+        M = int(sh.shape[1]) if (sh is not None and sh.numel() != 0) else 0
+        f32 = dict(dtype=torch.float32, device=device)
+        has_colors = colors_precomp is not None and colors_precomp.numel() != 0
+        has_cov = cov3D_precomp is not None and cov3D_precomp.numel() != 0
+        out = dict(means2D=torch.empty((P, 3), **f32), colors=torch.empty((P, 3), **f32) if has_colors else None,
+                   opacity=torch.empty((P, 1), **f32), means3D=torch.empty((P, 3), **f32),
+                   cov3D=torch.empty((P, 6), **f32) if has_cov else None,
+                   sh=torch.empty((P, M, 3), **f32) if M else None, scales=torch.zeros((P, 3), **f32),
+                   rotations=torch.zeros((P, 4), **f32))
+        keep = []
+        view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier, degree,
+                          False, antialiasing, False)
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+        grads = GsGrads()
+        grads.dL_dmeans3D, grads.dL_dmeans2D = out["means3D"].data_ptr(), out["means2D"].data_ptr()
+        grads.dL_dsh, grads.dL_dcolors, grads.dL_dopacity = _ptr(out["sh"]), _ptr(out["colors"]), out["opacity"].data_ptr()
+        grads.dL_dscales, grads.dL_drotations = out["scales"].data_ptr(), out["rotations"].data_ptr()
+        grads.dL_dcov3D = _ptr(out["cov3D"])
+        rows = _prep(rows, device)
+        s = self._scratch(geomBuffer, torch.empty(0, dtype=torch.uint8, device=device),
+                          torch.empty(0, dtype=torch.uint8, device=device), 0)
+        self.api.call("backward_from_rows", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),
+                      rows.data_ptr(), int(depth_mode), C.byref(grads), self._stream(device))
+        return (out["means2D"], out["colors"], out["opacity"], out["means3D"], out["cov3D"], out["sh"], out["scales"],
+                out["rotations"])
+
     # ------------------------------------------------------------------ markVisible
     def mark_visible(self, means3D, viewmatrix, projmatrix):
         """= markVisible (rasterize_points.cu:225-244)."""

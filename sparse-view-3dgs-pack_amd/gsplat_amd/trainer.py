@@ -283,7 +283,9 @@ class GaussianModelLite:
                     exp_avg=opt.exp_avg.cpu().clone(), exp_avg_sq=opt.exp_avg_sq.cpu().clone(), t=opt.t,
                     seg_steps=dict(opt.seg_steps), lr=dict(opt.lr), xyz_gradient_accum=self.xyz_gradient_accum.cpu().clone(),
                     denom=self.denom.cpu().clone(), max_radii2D=self.max_radii2D.cpu().clone(),
-                    spatial_lr_scale=self.spatial_lr_scale)
+                    spatial_lr_scale=self.spatial_lr_scale,
+                    nir_gain=None if self.nir_gain is None else self.nir_gain.detach().cpu().clone(),
+                    nir_gain_optimizer=None if self.nir_gain is None else self.nir_gain_optimizer.state_dict())
 
     def restore(self, state):
         opt = self.optimizer
@@ -298,6 +300,10 @@ class GaussianModelLite:
         self.denom = state["denom"].to(self.device).clone()
         self.max_radii2D = state["max_radii2D"].to(self.device).clone()
         self.spatial_lr_scale = state["spatial_lr_scale"]
+        if self.nir_gain is not None and state.get("nir_gain") is not None:
+            with torch.no_grad():
+                self.nir_gain.copy_(state["nir_gain"])
+            self.nir_gain_optimizer.load_state_dict(state["nir_gain_optimizer"])
 
     def oneupSHdegree(self):
         """gaussian_model.py:145-147"""
@@ -674,6 +680,7 @@ class Trainer:
                 reset = True
         if iteration < opt.iterations and not skip_all:
             m.optimizer.step(skip=("opacity",) if reset else ())
+            self._after_optimizer_step()
         return dict(loss=loss, densified=densified, reset=reset, P=m.P, camera=ci)
 
     def _step_camera(self, ci, optimizer_step, skip):
@@ -699,6 +706,9 @@ class Trainer:
             self.exchange_and_step(optimizer_step, skip)
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
+
+    def _after_optimizer_step(self):
+        """Hook of train_iteration: parameters that live outside the flat buffer are stepped here."""
 
     DP_CHUNKS = 4
 
@@ -823,3 +833,8 @@ class TrainerNIR(Trainer):
                 m.nir_gain_optimizer.step()
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
+
+    def _after_optimizer_step(self):
+        # the reference keeps the global gain in the main Adam (mult-dwtgs/scene/gaussian_model.py:266-280), so it is
+        # stepped whenever optimizer.step() runs - and, like every group, not on a densification iteration
+        self.model.nir_gain_optimizer.step()

@@ -36,8 +36,22 @@ def test_nir_step_on_the_oracle_with_two_passes(oracle):
     nc, ns, npr = m.densify_and_prune(2e-4, 0.005, 4.4, None, None, generator=torch.Generator().manual_seed(1))
     assert nc + ns > 0 and m.flat.numel() == m.P * 60 and m.params["nir_albedo"].shape == (m.P, 1)
     opt = TrainOptions(iterations=10, densify_from_iter=100, cameras_extent=4.4)
+    gain0 = float(m.nir_gain)
     out = tr.train_iteration(1, opt)
     assert out["P"] == m.P and torch.isfinite(out["loss"])
+    assert float(m.nir_gain) != gain0  # the schedule loop steps the global gain with the main optimizer
+    # ... but not on an iteration that densifies (the reference's optimizer.step() then changes nothing)
+    m.xyz_gradient_accum += 1e-3
+    gain1 = float(m.nir_gain)
+    out = tr.train_iteration(200, TrainOptions(iterations=1000, densify_from_iter=100, cameras_extent=4.4))
+    assert out["densified"] is not None and float(m.nir_gain) == gain1
+    # checkpoints carry the gain and its Adam moments
+    state = m.capture()
+    tr.train_iteration(201, TrainOptions(iterations=1000, densify_from_iter=100, cameras_extent=4.4))
+    assert float(m.nir_gain) != gain1
+    m.restore(state)
+    assert float(m.nir_gain) == gain1
+    assert float(m.nir_gain_optimizer.state_dict()["state"][0]["exp_avg"]) == float(state["nir_gain_optimizer"]["state"][0]["exp_avg"])
 
 
 @pytest.mark.gpu
