@@ -184,8 +184,9 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
   GS_LAUNCH_CHECK(s, v->debug);
   {
     GS_PROF(ST_RENDER_FWD, s);
-    launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, out_color,
-                             out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
+    launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, iv.tile_work,
+                           out_color, out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
+    launch_tile_order(iv.tile_work, iv.tile_order, (int)T, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
@@ -276,8 +277,8 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   if (num_rendered > 0) {
     {
       GS_PROF(ST_RENDER_BWD, s);
-      launch_render_bwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, dL_dcolor,
-                               dL_dinvdepth, dL_dextra, rows, fsgs, s);
+      launch_render_bwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, iv.tile_work,
+                             iv.tile_order, dL_dcolor, dL_dinvdepth, dL_dextra, rows, fsgs, s);
     }
     GS_LAUNCH_CHECK(s, v->debug);
   }

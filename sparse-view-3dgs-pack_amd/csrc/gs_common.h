@@ -8,7 +8,7 @@
 //           tiles_touched[P] u32
 //           block_sums / sorted_sums [ceil(P/256)+1] u32   workgroup sums of tiles_touched (index / depth order)
 //           gsort            radix-sort buffers of the per-Gaussian depth sort (16 B x P + histograms)
-//  img    : final_T[N] f32 | n_contrib[N] u32 | ranges[T] uint2
+//  img    : final_T[N] f32 | n_contrib[N] u32 | ranges[T] uint2 | tile_work[T] u32 | tile_order[T] u32
 //  binning: tile keys[2][cap] u32 | Gaussian ids[2][cap] u32 | radix histograms   (16 B per instance)
 //
 // All sub-arrays start on 256-byte boundaries.
@@ -118,17 +118,20 @@ struct ImgView {
   float* final_T;
   uint32_t* n_contrib;
   uint2* ranges;
+  uint32_t* tile_work;   // [T] list entries the backward blend will visit in this tile = max last contributor (forward)
+  uint32_t* tile_order;  // [T] tiles by decreasing tile_work: launch order of the backward blend
 };
 static inline __host__ __device__ size_t img_bytes(size_t N, size_t T) {
-  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T);
+  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T) + 2 * gs_align(4 * T);
 }
 static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T) {
   char* p = (char*)buf;
   ImgView v;
   v.final_T = (float*)p; p += gs_align(4 * N);
   v.n_contrib = (uint32_t*)p; p += gs_align(4 * N);
-  v.ranges = (uint2*)p;
-  (void)T;
+  v.ranges = (uint2*)p; p += gs_align(8 * T);
+  v.tile_work = (uint32_t*)p; p += gs_align(4 * T);
+  v.tile_order = (uint32_t*)p;
   return v;
 }
 
@@ -212,12 +215,14 @@ int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_h
 
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
-                           const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                           float* out_invdepth, float* out_extra, int fsgs, int cull, hipStream_t s);
+                           const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_work,
+                           float* out_color, float* out_invdepth, float* out_extra, int fsgs, int cull, hipStream_t s);
+// tile_order[] = the T tiles by decreasing tile_work[] (one small workgroup; order inside a bucket of equal work is free)
+int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                           const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs,
-                           hipStream_t s);
+                           const uint32_t* tile_work, const uint32_t* tile_order, const float* dL_dpix,
+                           const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs, hipStream_t s);
 
 struct PreprocessBwdArgs {
   int P, D, M;

@@ -55,20 +55,19 @@ template <bool HAS_INVDEPTH, bool HAS_EXTRA, bool FSGS>
 __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) render_bwd_wave_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const Splat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_work,
+    const uint32_t* __restrict__ tile_order, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_invdepths, const float* __restrict__ dL_dextra, float* __restrict__ grad_rows) {
   __shared__ float4 s_a[WB];  // x, y, invdepth, -
   __shared__ float4 s_c[WB];  // conic, opacity
   __shared__ float4 s_k[WB];  // rgb, 4th channel
   __shared__ uint32_t s_id[WB];
 
-  // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so tile
-  // t = xcd * ceil(T/8) + id/8 keeps a contiguous band of the image - whose tiles share splat records - on one L2
-  const int n_tiles = grid_x * ((H + TILE_Y - 1) / TILE_Y);
-  const int per_xcd = (int)(gridDim.x >> 3);  // the grid is padded to a multiple of 8 workgroups
-  const int tile_sw = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (tile_sw >= n_tiles) return;
-  const int tile = tile_sw;
+  // longest tile first (tile_order_kernel in gs_render_fwd_wave.hip): the hardware hands workgroups to free wave slots
+  // in index order, so this is list scheduling by decreasing work - 64 % -> 97 % of the wave slots busy
+  const int tile = (int)tile_order[blockIdx.x];
+  const uint32_t lmax = tile_work[tile];  // deepest last contributor of the tile's pixels
+  if (lmax == 0) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int lane = threadIdx.x;
   const uint2 range = ranges[tile];
@@ -80,10 +79,17 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
   const float pixfx0 = (float)px0, pixfy0 = (float)py0;
   const size_t HW = (size_t)H * W;
 
+  // Per pixel the reference runs one "colour behind me" recurrence per channel (accum_rec[ch], last_color[ch],
+  // backward.cu:573-591) and then contracts with dL_dpixel[ch].  The contraction commutes with the recurrence (it is
+  // linear in the colour), so ONE scalar recurrence per pixel carries the same information:
+  //   kd = sum_ch c_ch dL_dpixel_ch            (this contributor's colour, seen through the pixel's cotangent)
+  //   A  = last_alpha * (kd_prev - A) + A      (= sum_ch accum_rec[ch] dL_dpixel_ch)
+  //   dL_dalpha = kd - A
+  // 6 VALU ops instead of 15 per (pixel, Gaussian) and 2 state registers instead of 6 (8 with depth + 4th channel),
+  // which the depth and 4th channels join for one fma each.
   float T[4], Tbg[4], dLp0[4], dLp1[4], dLp2[4], dLinv[4], dLpX[4];  // Tbg = T_final * (bg . dL_dpixel)
-  float acc0[4], acc1[4], acc2[4], accD[4], accX[4], lastc0[4], lastc1[4], lastc2[4], lastD[4], lastX[4], last_alpha[4];
+  float A[4], kd_prev[4], last_alpha[4];
   uint32_t lastc[4];
-  uint32_t lmax = 0;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const int px = px0 + (s & 1) * 8, py = py0 + (s >> 1) * 8;
@@ -91,7 +97,6 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
     const int pix_id = W * py + px;
     T[s] = inside ? final_Ts[pix_id] : 0.f;
     lastc[s] = inside ? n_contrib[pix_id] : 0u;
-    lmax = max(lmax, lastc[s]);
     dLp0[s] = inside ? dL_dpixels[pix_id] : 0.f;
     dLp1[s] = inside ? dL_dpixels[HW + pix_id] : 0.f;
     dLp2[s] = inside ? dL_dpixels[2 * HW + pix_id] : 0.f;
@@ -103,14 +108,8 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
     b += bg[1] * dLp1[s];
     b += bg[2] * dLp2[s];
     Tbg[s] = T[s] * b;
-    acc0[s] = acc1[s] = acc2[s] = accD[s] = accX[s] = 0.f;
-    lastc0[s] = lastc1[s] = lastc2[s] = lastD[s] = lastX[s] = last_alpha[s] = 0.f;
+    A[s] = kd_prev[s] = last_alpha[s] = 0.f;
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, off, 64));
-  lmax = __builtin_amdgcn_readfirstlane(lmax);
-  if (lmax == 0) return;
-
   // per-row factors applied after the reduction (lane 15 of row q carries value q of t0 / 4+q of t1)
   const int rq = lane >> 4;
   const float rowscale0 = rq == 0 ? (0.5f * W) / GS_LOG2E : (rq == 1 ? (0.5f * H) / GS_LOG2E : -0.5f);
@@ -185,32 +184,23 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
           rinv = fmaf(rinv, fmaf(-om, rinv, 1.0f), rinv);
           T[s] = T[s] * rinv;
           const float w = alpha[s] * T[s];  // dchannel_dcolor
-          const float la = last_alpha[s];
-          acc0[s] = fmaf(la, lastc0[s] - acc0[s], acc0[s]);
-          acc1[s] = fmaf(la, lastc1[s] - acc1[s], acc1[s]);
-          acc2[s] = fmaf(la, lastc2[s] - acc2[s], acc2[s]);
-          lastc0[s] = k.x;
-          lastc1[s] = k.y;
-          lastc2[s] = k.z;
-          float dL_dalpha = (k.x - acc0[s]) * dLp0[s];
-          dL_dalpha = fmaf(k.y - acc1[s], dLp1[s], dL_dalpha);
-          dL_dalpha = fmaf(k.z - acc2[s], dLp2[s], dL_dalpha);
+          A[s] = fmaf(last_alpha[s], kd_prev[s] - A[s], A[s]);
+          float kd = k.x * dLp0[s];
+          kd = fmaf(k.y, dLp1[s], kd);
+          kd = fmaf(k.z, dLp2[s], kd);
           v_c0 = fmaf(w, dLp0[s], v_c0);
           v_c1 = fmaf(w, dLp1[s], v_c1);
           v_c2 = fmaf(w, dLp2[s], v_c2);
           if (HAS_INVDEPTH) {
-            accD[s] = fmaf(la, lastD[s] - accD[s], accD[s]);
-            lastD[s] = a.z;
-            dL_dalpha = fmaf(a.z - accD[s], dLinv[s], dL_dalpha);
+            kd = fmaf(a.z, dLinv[s], kd);
             v_id = fmaf(w, dLinv[s], v_id);
           }
           if (HAS_EXTRA) {
-            accX[s] = fmaf(la, lastX[s] - accX[s], accX[s]);
-            lastX[s] = k.w;
-            dL_dalpha = fmaf(k.w - accX[s], dLpX[s], dL_dalpha);
+            kd = fmaf(k.w, dLpX[s], kd);
             v_x = fmaf(w, dLpX[s], v_x);
           }
-          dL_dalpha = fmaf(dL_dalpha, T[s], -Tbg[s] * rinv);  // *T, then + (-T_final/(1-alpha)) * bg_dot_dpixel
+          kd_prev[s] = kd;
+          const float dL_dalpha = fmaf(kd - A[s], T[s], -Tbg[s] * rinv);  // *T, then + (-T_final/(1-alpha)) * bg_dot_dpixel
           last_alpha[s] = alpha[s];
           v_op = fmaf(G[s], dL_dalpha, v_op);
           const float h = co.w * G[s] * dL_dalpha;
@@ -250,11 +240,11 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
 
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                           const float* dL_dpix, const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows,
-                           int fsgs, hipStream_t s) {
+                           const uint32_t* tile_work, const uint32_t* tile_order, const float* dL_dpix,
+                           const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs, hipStream_t s) {
 #define GS_BWD_WAVE(ID, EX, FS)                                                                                           \
-  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX, FS>), dim3(((grid_x * grid_y + 7) / 8) * 8), dim3(64), 0, s, ranges, point_list, W, H, \
-                     grid_x, splat, bg, final_T, n_contrib, dL_dpix, dL_dinvdepth, dL_dextra, grad_rows)
+  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX, FS>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, \
+                     grid_x, splat, bg, final_T, n_contrib, tile_work, tile_order, dL_dpix, dL_dinvdepth, dL_dextra, grad_rows)
   if (fsgs) GS_BWD_WAVE(true, true, true);
   else if (dL_dinvdepth && dL_dextra) GS_BWD_WAVE(true, true, false);
   else if (dL_dinvdepth) GS_BWD_WAVE(true, false, false);

@@ -50,6 +50,8 @@ class RasterBackend:
         # reference's bounding-square lists, bit-identical point_list / ranges / num_rendered
         self.tile_cull = os.environ.get("GS_TILE_CULL", "1") != "0"
         self._cap_memo = {}
+        self._cap_by_buffer = {}
+        self._pinned_by_device = {}
         # one-shot output arena for the next backward: {"means3D": [P,3], "sh": [P,M,3]} fp32 tensors to write
         # dL_dmeans3D / dL_dsh INTO (e.g. views of a flat gradient buffer) instead of fresh allocations
         self.grad_arena = None
@@ -99,12 +101,22 @@ class RasterBackend:
 
     def _update_hint(self, num_rendered):
         # 25 % head-room over the largest recent instance count; decays slowly so one huge view does not pin
-        # the capacity (and the 16 B/instance buffer) forever
-        want = int(num_rendered * 1.25) + 4096
-        self._capacity_hint = max(want, int(self._capacity_hint * 0.98))
+        # the capacity (and the 16 B/instance buffer) forever.  Quantised to 1/8-octave steps so that consecutive steps
+        # ask for the SAME number of bytes: the caching allocator then hands back the same block every step.
+        import math
+        want = max(int(num_rendered * 1.25) + 4096, int(self._capacity_hint * 0.98))
+        self._capacity_hint = int(2.0 ** (math.ceil(math.log2(want) * 8.0) / 8.0))
+
+    def _remember_capacity(self, binning, cap):
+        """The binning buffer travels through autograd as a bare byte tensor; its capacity (instances) is kept here, keyed
+        by the buffer's address and length, so backward need not recover it by search."""
+        if len(self._cap_by_buffer) > 256:
+            self._cap_by_buffer.clear()
+        self._cap_by_buffer[(binning.data_ptr(), binning.numel())] = int(cap)
 
     def _capacity_of(self, P, W, H, nbytes, at_least):
-        """Instances the binning buffer of `nbytes` bytes was sized for (largest cap with bytes(cap) <= nbytes)."""
+        """Instances the binning buffer of `nbytes` bytes was sized for (largest cap with bytes(cap) <= nbytes); only
+        reached for buffers this backend did not allocate itself (see _remember_capacity)."""
         key = (P, W, H, nbytes)
         cap = self._cap_memo.get(key)
         if cap is None:
@@ -122,6 +134,14 @@ class RasterBackend:
                 self._cap_memo.clear()
             self._cap_memo[key] = cap
         return cap
+
+    def _capacity_for(self, binning, P, W, H, R):
+        if binning.numel() == 0:
+            return R
+        cap = self._cap_by_buffer.get((binning.data_ptr(), binning.numel()))
+        if cap is not None and cap >= R:
+            return cap
+        return self._capacity_of(P, W, H, binning.numel(), R)
 
     def scratch_bytes(self, P, W, H, R):
         out = (C.c_size_t * 3)()
@@ -195,9 +215,12 @@ class RasterBackend:
         s = self._scratch(geom, img, empty, 0)
 
         if device.type == "cuda":
-            if self._pinned is None:
-                self._pinned = torch.empty((1,), dtype=torch.int32).pin_memory()
-            nr_host = self._pinned
+            # one pinned counter per device AND stream: two forwards in flight on different streams must not share it
+            pkey = (device.index, torch.cuda.current_stream(device).cuda_stream)
+            nr_host = self._pinned_by_device.get(pkey)
+            if nr_host is None:
+                nr_host = self._pinned_by_device[pkey] = torch.empty((1,), dtype=torch.int32).pin_memory()
+            self._pinned = nr_host  # (last used: read by bench.py for the instance count of the last view)
             cur = torch.cuda.current_stream(device)
             self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(),
                           nr_host.data_ptr(), stream)
@@ -213,6 +236,7 @@ class RasterBackend:
                 ev.record(cur)
                 _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
                 binning = torch.empty((bb,), **u8)
+                self._remember_capacity(binning, cap)
                 s2 = self._scratch(geom, img, binning, cap)
                 render(s2)
                 ev.synchronize()
@@ -233,6 +257,7 @@ class RasterBackend:
 
         _, _, bb, _ = self.scratch_bytes(P, W, H, num_rendered)
         binning = torch.empty((bb,), **u8)
+        self._remember_capacity(binning, num_rendered)
         s = self._scratch(geom, img, binning, num_rendered)
         render(s)
         return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
@@ -295,7 +320,7 @@ class RasterBackend:
         ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
         if self.keep_workspace:
             self.last_workspace = ws
-        cap = R if binningBuffer.numel() == 0 else self._capacity_of(P, W, H, binningBuffer.numel(), R)
+        cap = self._capacity_for(binningBuffer, P, W, H, R)
         s = self._scratch(geomBuffer, imgBuffer, binningBuffer, cap)
         grads = GsGrads()
         grads.dL_dmeans3D, grads.dL_dmeans2D = dL_dmeans3D.data_ptr(), dL_dmeans2D.data_ptr()
@@ -380,7 +405,7 @@ class RasterBackend:
     def export_state(self, P, W, H, R, geom, binning, img):
         """Plain-array copies of the forward's internal state (tests / debugging only)."""
         device = geom.device
-        cap = R if binning.numel() == 0 else self._capacity_of(P, W, H, binning.numel(), R)
+        cap = self._capacity_for(binning, P, W, H, R)
         s = self._scratch(geom, img, binning, cap)
         f32 = dict(dtype=torch.float32, device=device)
         T = ((W + 15) // 16) * ((H + 15) // 16)

@@ -76,3 +76,42 @@ def compare_rows(hr, orow, has_invdepth=False):
             continue
         out[name] = err_stats(hr[:, s], orow[:, s])
     return out
+
+
+def exact_scale_rot_chain(scene, cam, rows, radii):
+    """Float64 image of the conic sums under stage 2: (dL_dscales, dL_drotations) = d/d(scales, quaternions) of
+    sum_i <rows_i[conic], conic_i(scales_i, q_i)>, by autograd over the closed-form EWA projection (non-anti-aliased
+    path; the reference's 1/(det^2 + 1e-7) regulariser, backward.cu:252, is applied to the upstream).  Stage 2 is
+    LINEAR in the rows, so  chain(rows_a) - chain(rows_b) = chain(rows_a - rows_b): what a difference of the blend sums
+    becomes in the scale / rotation gradients when nothing else goes wrong."""
+    from dense_reference import quat_to_rot
+    f64 = torch.float64
+    vis = radii.cpu() > 0
+    means = scene["means3D"].to(f64)
+    s = scene["scales"].to(f64).clone().requires_grad_(True)
+    q = scene["rotations"].to(f64).clone().requires_grad_(True)
+    mod = float(scene.get("scale_modifier", 1.0))
+    V = cam.world_view_transform.to(f64).cpu()
+    H, W = cam.image_height, cam.image_width
+    fx, fy = W / (2 * cam.tanfovx), H / (2 * cam.tanfovy)
+    P = means.shape[0]
+    p_view = torch.cat([means, torch.ones((P, 1), dtype=f64)], dim=1) @ V
+    tz = p_view[:, 2]
+    tz = torch.where(vis, tz, torch.ones_like(tz))  # culled rows carry zero sums; keep their arithmetic finite
+    limx, limy = 1.3 * cam.tanfovx, 1.3 * cam.tanfovy
+    tx = (p_view[:, 0] / tz).clamp(-limx, limx) * tz
+    ty = (p_view[:, 1] / tz).clamp(-limy, limy) * tz
+    zero = torch.zeros_like(tz)
+    J = torch.stack([fx / tz, zero, -(fx * tx) / (tz * tz), zero, fy / tz, -(fy * ty) / (tz * tz)], dim=1).reshape(P, 2, 3)
+    M = J @ V[:3, :3].transpose(0, 1)
+    R = quat_to_rot(q)
+    S = torch.diag_embed(mod * s)
+    Sigma = R @ S @ S @ R.transpose(1, 2)
+    cov = M @ Sigma @ M.transpose(1, 2)
+    a, b, c = cov[:, 0, 0] + 0.3, cov[:, 0, 1], cov[:, 1, 1] + 0.3
+    det = a * c - b * b
+    reg = (det * det / (det * det + 1e-7)).detach()
+    g = rows.to(f64)
+    L = (reg * (g[:, 2] * (c / det) + 2.0 * g[:, 3] * (-b / det) + g[:, 4] * (a / det)))[vis].sum()
+    ds, dq = torch.autograd.grad(L, [s, q])
+    return ds / mod, dq  # the kernel returns dL/d(mod * scale) (backward.cu:372-375)

@@ -54,11 +54,13 @@ def test_fsgs_generation_matches_oracle(hip, oracle, exact_T, cull, kind, P, W, 
             h = fsgs_run(dgr_fsgs.GaussianRasterizer, dgr_fsgs.GaussianRasterizationSettings, sc, cam, bg,
                          torch.device("cuda"), *dL, confidence=conf)
             o = fsgs_run(oracle.FsgsRasterizer, oracle.FsgsSettings, sc, cam, bg, torch.device("cpu"), *dL, confidence=conf)
-        tol = 2 * TOL if exact_T else 5e-3
-        for k in LEAVES + ("means2D",):
-            a, b = h["grads"][k].double(), o["grads"][k].double()
-            s = max(1e-12, float(b.abs().max()))
-            assert float((a - b).abs().max()) <= tol * s, (k, float((a - b).abs().max()) / s)
+        from helpers import check_grads
+        keys = LEAVES + ("means2D",)
+        # against the reference's literal `T_final = 1 - alpha` read-back (fp32 cancellation on saturated pixels) the
+        # product's exact transmittance product differs by ~1e-3: that form only gets the loose bound
+        check_grads({k: h["grads"][k].cpu() for k in keys}, {k: o["grads"][k] for k in keys},
+                    "fsgs_%s_%d_%dx%d_cull%d_exactT%d" % (kind, P, W, H, int(cull), int(exact_T)),
+                    **({} if exact_T else dict(tol=5e-3, chain_tol=5e-3)))
     finally:
         hip.tile_cull = old
 

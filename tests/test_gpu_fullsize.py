@@ -1,5 +1,10 @@
-"""BASELINE full size (config 3: 1 M Gaussians, 1920x1080) on the GPU, checked through size-independent properties -
-the oracle needs ~2 s per view at this size, so it is used here only on a crop-free statistic (radii, instance count):
+"""BASELINE full sizes on the GPU: configs[1] (500 k Gaussians, 800x800), configs[2] (1 M, 1920x1080) and the per-GPU
+half of configs[3] (2 M, 1920x1080).  Two kinds of checks:
+
+(a) HIP against the CPU oracle on the same inputs (`check_view_against_oracle`, one view costs the oracle ~2 s): forward
+state bit for bit in reference-list mode, image, every gradient tensor, the intermediate per-Gaussian sums of the blend
+backward, and the conic -> scale / rotation chain on its own;
+(b) size-independent properties:
 
   * binning: keys sorted, ranges = the runs of equal tile ids, every list entry's tile lies inside its Gaussian's
     bounding rectangle, lists hold no duplicate (tile, Gaussian) pair, reference-list mode reproduces the oracle's
@@ -14,6 +19,7 @@ import pytest
 import torch
 
 import diff_gaussian_rasterization as dgr
+import fullsize_parity as fp
 from gsplat_amd import synthetic
 from helpers import run_scene
 from test_gpu_raster_parity import forward_state
@@ -95,6 +101,164 @@ def test_binning_invariants_at_full_size(hip, oracle, scene):
         hip.tile_cull = old
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# (a) HIP vs oracle at full size
+# ----------------------------------------------------------------------------------------------------------------
+TOL = 1e-4          # north_star: renders and gradients within 1e-4 relative (to the tensor's largest entry), fp32
+# dL_dscales / dL_drotations: the chain conic -> cov2D -> cov3D -> (scale, quaternion) (backward.cu:248-275, 330-393)
+# amplifies fp32 rounding by the footprint's anisotropy^2: for a needle-shaped splat the conic sums are nearly rank one
+# along the needle and -conic Gc conic cancels to 3-4 digits.  Measured at C3 (profiles/r02_parity_fullsize_c3.json): the
+# oracle's fp32 evaluation of the REFERENCE'S formula sits 1e-3 (scales) / 2e-3 (rotations) of the tensor's max away from
+# the exact (float64) image of its own inputs; the product's formulation (csrc/gs_backward_math.h) 2.5e-4 / 5e-4.  A bar
+# of 1e-4 against the oracle is therefore below the reference's own rounding noise for these two tensors, and the test
+# asserts instead what is well defined (and prints everything):
+#   * the sums entering the chain agree to TOL (stage 1, where backward.cu:593-635 has its atomics);
+#   * HIP is at least as close to the exact image of ITS sums as the oracle is to the exact image of its own (+ TOL);
+#   * |HIP - oracle| is covered by those two distances plus the exact image of the stage-1 difference (+ TOL);
+#   * a plain end-to-end cap CHAIN_CAP with the rms far below it.
+# Every other tensor is held to TOL end to end, and to TOL with stage 2 alone fed the oracle's sums.
+CHAIN_TENSORS = ("scales", "rotations")
+CHAIN_CAP, CHAIN_RMS_CAP = 1e-2, 3e-3
+
+
+def _loss_cotangent(hip, sc, gt_sc, cam, dev, bg):
+    """dL/dimage of the LGDWT criterion (L1 + SSIM + global DWT + patch DWT) against a quantised render of another scene"""
+    import lgdwt_loss
+    gt = fp.forward(hip, gt_sc, cam, dev, bg)["color"]
+    gt = (torch.round(gt.clamp(0, 1) * 255.0) / 255.0).contiguous()
+    patch = min(cam.image_height, cam.image_width) >= 128
+    crit = lgdwt_loss.criterion(dwt_enable=True, patch_dwt_enable=patch)
+    mask = crit.elf_mask(gt) if patch else None
+    img = fp.forward(hip, sc, cam, dev, bg)["color"].clone().requires_grad_(True)
+    loss, _ = crit(img.clamp(0, 1), gt, mask=mask)
+    loss.backward()
+    return img.grad.detach().cpu()
+
+
+def check_view_against_oracle(hip, oracle, tag, P, W, H, cam_i=3, cotangents=("noise", "loss")):
+    import json
+    import os
+    from simple_knn._C import distCUDA2
+    dev, cpu = torch.device("cuda"), torch.device("cpu")
+    knn = lambda x: distCUDA2(x.to(dev)).cpu()  # noqa: E731
+    sc = synthetic.trained_like(P, seed=0, sh_degree=3, knn=knn)
+    cam = synthetic.orbit_cameras(W, H)[cam_i]
+    bg = torch.zeros(3)
+    ofw = fp.forward(oracle.backend, sc, cam, cpu, bg)
+    cots = {}
+    if "noise" in cotangents:
+        cots["noise"] = torch.randn((3, H, W), generator=torch.Generator().manual_seed(3))
+    old = hip.tile_cull
+    report = dict(P=P, W=W, H=H, camera=cam_i)
+    try:
+        if "loss" in cotangents:
+            hip.tile_cull = True
+            cots["loss"] = _loss_cotangent(hip, sc, synthetic.trained_like(P, seed=1, sh_degree=3, knn=knn), cam, dev, bg)
+        for cull in (False, True):
+            hip.tile_cull = cull
+            hfw = fp.forward(hip, sc, cam, dev, bg)
+            rep = report["cull%d" % int(cull)] = dict(num_rendered=hfw["R"])
+            # ---- forward
+            assert torch.equal(hfw["radii"].cpu(), ofw["radii"])
+            if not cull:
+                assert hfw["R"] == ofw["R"]
+                hs = hip.export_state(P, W, H, hfw["R"], hfw["geom"], hfw["binning"], hfw["img"])
+                os_ = oracle.backend.export_state(P, W, H, ofw["R"], ofw["geom"], ofw["binning"], ofw["img"])
+                for k in ("tiles_touched", "point_offsets", "keys_sorted", "point_list", "ranges", "clamped"):
+                    assert torch.equal(hs[k].cpu(), os_[k]), k
+                for k in ("depths", "means2D", "conic_opacity", "rgb", "cov3D"):
+                    assert torch.equal(hs[k].cpu().view(torch.int32), os_[k].view(torch.int32)), k
+                del hs, os_
+            else:
+                assert hfw["R"] < ofw["R"]
+            dc = (hfw["color"].cpu() - ofw["color"]).abs().amax(dim=0)
+            scale = max(1.0, float(ofw["color"].abs().max()))
+            rep["color_max_abs_err"] = float(dc.max())
+            rep["pixels_over_tol"] = int((dc > TOL * scale).sum())
+            flip = dc > 0.2 * TOL * scale  # a threshold decision (alpha < 1/255, T < 1e-4) that went the other way
+            rep["flipped_pixels"] = int(flip.sum())
+            assert rep["pixels_over_tol"] <= max(2, dc.numel() // 20000), rep
+            assert rep["flipped_pixels"] <= max(2, dc.numel() // 2000), rep
+            for cname, cot in cots.items():
+                cot = cot.clone()
+                cot[:, flip] = 0  # for both sides (test_gpu_raster_parity.flip_mask explains why)
+                og, orows = fp.backward(oracle.backend, ofw, cot)
+                hg, hrows = fp.backward(hip, hfw, cot)
+                r = rep[cname] = dict(grads=fp.compare_grads(hg, og), rows=fp.compare_rows(hrows, orows))
+                # ---- stage 2 alone, on the oracle's sums
+                a = hfw["args"]
+                h2 = dict(zip(fp.GRAD_NAMES, hip.backward_from_rows(
+                    orows.to(dev), a["bg"], a["means3D"], hfw["radii"], a["colors"], a["opacities"], a["scales"],
+                    a["rotations"], a["mod"], a["cov"], a["view"], a["proj"], a["tx"], a["ty"], H, W, a["sh"], a["deg"],
+                    a["campos"], hfw["geom"], False)))
+                torch.cuda.synchronize()
+                r["stage2_on_oracle_rows"] = fp.compare_grads({k: (None if v is None else v.cpu()) for k, v in h2.items()}, og)
+                # ---- the exact image of the sums
+                ex_h = fp.exact_scale_rot_chain(sc, cam, hrows, ofw["radii"])
+                ex_o = fp.exact_scale_rot_chain(sc, cam, orows, ofw["radii"])
+                for i, name in enumerate(CHAIN_TENSORS):
+                    ref_max = max(float(og[name].abs().max()), 1e-30)
+                    d = hg[name].double() - og[name].double()
+                    r["chain_" + name] = dict(
+                        end_to_end=float(d.abs().max()) / ref_max,
+                        stage1_image=float((ex_h[i] - ex_o[i]).abs().max()) / ref_max,
+                        hip_vs_exact=float((hg[name].double() - ex_h[i]).abs().max()) / ref_max,
+                        oracle_vs_exact=float((og[name].double() - ex_o[i]).abs().max()) / ref_max)
+                print("== %s cull=%d cotangent=%s" % (tag, cull, cname))
+                for k, v in r["grads"].items():
+                    print("   dL_d%-15s max %.2e rms %.2e | stage 2 alone max %.2e" % (
+                        k, v["max_rel"], v["rms_rel"], r["stage2_on_oracle_rows"][k]["max_rel"]))
+                for k, v in r["rows"].items():
+                    print("   sums %-17s max %.2e rms %.2e" % (k, v["max_rel"], v["rms_rel"]))
+                for name in CHAIN_TENSORS:
+                    print("   chain %-10s %s" % (name, {k: "%.2e" % v for k, v in r["chain_" + name].items()}))
+        # ---- assertions (after everything has been printed)
+        for cull in ("cull0", "cull1"):
+            for cname in cots:
+                r = report[cull][cname]
+                for k, v in r["rows"].items():
+                    assert v["max_rel"] <= TOL, (tag, cull, cname, "sums", k, v)
+                for k, v in r["grads"].items():
+                    s2 = r["stage2_on_oracle_rows"][k]["max_rel"]
+                    if k in CHAIN_TENSORS:
+                        c = r["chain_" + k]
+                        assert c["hip_vs_exact"] <= c["oracle_vs_exact"] + TOL, (tag, cull, cname, k, c)
+                        assert c["end_to_end"] <= c["hip_vs_exact"] + c["oracle_vs_exact"] + c["stage1_image"] + TOL, \
+                            (tag, cull, cname, k, c)
+                        assert v["max_rel"] <= CHAIN_CAP and v["rms_rel"] <= CHAIN_RMS_CAP, (tag, cull, cname, k, v)
+                    else:
+                        assert v["max_rel"] <= TOL, (tag, cull, cname, k, v)
+                        assert s2 <= TOL, (tag, cull, cname, k, "stage 2 alone", s2)
+    finally:
+        hip.tile_cull = old
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        try:
+            os.makedirs(out, exist_ok=True)
+            json.dump(report, open(os.path.join(out, "parity_fullsize_%s.json" % tag), "w"), indent=1)
+        except OSError:
+            pass
+    return report
+
+
+def test_c3_every_gradient_against_the_oracle(hip, oracle):
+    """BASELINE configs[2], the size the metric is quoted on: 1 M Gaussians at 1920x1080, both list modes, noise and loss
+    cotangents."""
+    check_view_against_oracle(hip, oracle, "c3", P, W, H)
+
+
+def test_c2_every_gradient_against_the_oracle(hip, oracle):
+    """BASELINE configs[1]: 500 k Gaussians at 800x800, global DWT in the loss cotangent."""
+    check_view_against_oracle(hip, oracle, "c2", 500_000, 800, 800, cam_i=5)
+
+
+def test_c4_every_gradient_against_the_oracle(hip, oracle):
+    """Per-GPU half of BASELINE configs[3]: 2 M Gaussians at 1920x1080 (one of the 8 cameras of a step)."""
+    check_view_against_oracle(hip, oracle, "c4", 2_000_000, 1920, 1080, cam_i=9, cotangents=("loss",))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# (b) size-independent properties
+# ----------------------------------------------------------------------------------------------------------------
 def test_backward_is_linear_in_the_cotangent_at_full_size(hip, scene):
     sc, cam = scene
     dev = torch.device("cuda")
@@ -113,9 +277,10 @@ def test_backward_is_linear_in_the_cotangent_at_full_size(hip, scene):
         want = 0.75 * a - 1.5 * b
         err = float((c - want).abs().max()) / max(1e-12, float(want.abs().max()))
         rms = float((c - want).pow(2).mean().sqrt()) / max(1e-20, float(want.pow(2).mean().sqrt()))
-        # dL_dscales / dL_drotations are differences of large per-pixel terms (the conic gradient changes sign across a
-        # splat) accumulated with float atomics in a run-dependent order: single entries of three separately rounded
-        # accumulations differ by up to a few 1e-3 of the largest entry, the population agrees much better
+        # dL_dscales / dL_drotations: three separately rounded accumulations (float atomics in a run-dependent order, a
+        # few 1e-7 of the sums - measured run to run) pass through the ill-conditioned conic -> scale / rotation chain
+        # (see CHAIN_TENSORS above: established with tests/tools/c3_grad_probe.py, profiles/r02_c3_grad_probe.json):
+        # single entries differ by up to a few 1e-3 of the largest entry, the population agrees much better
         if k in ("scales", "rotations"):
             assert err <= 2e-2 and rms <= 2e-3, (k, err, rms)
         else:
