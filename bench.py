@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """bench.py - train-step views/s (fwd+bwd) of the MI355X rasterizer + LGDWT loss path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1|c5|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4|c2|c1|c5|tiny]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
               --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one camera per GPU: activations -> GaussianRasterizer forward -> clamp -> LGDWT loss
 (0.8 L1 + 0.2 (1-SSIM) + running-mean-scaled global 2-level DWT + 0.1 patch DWT) -> backward to the
-six parameter tensors -> (N>1: one RCCL all-reduce of the 59-float/Gaussian gradient buffer + the
-densification statistics) -> Adam.  Synthetic "trained-like" Gaussians, NeRF-synthetic-
+six parameter tensors -> densification statistics -> Adam (N = 1: all of the last three inside the
+backward's per-Gaussian kernel, gs_backward_step; N > 1: one RCCL all-reduce of the 59-float/Gaussian
+gradient buffer + the statistics, then the fused Adam kernel).  The timed step therefore INCLUDES the
+optimizer; the metric's "(fwd+bwd)" is BASELINE.json's wording.  Synthetic "trained-like" Gaussians, NeRF-synthetic-
 like orbit cameras, inputs resident in HBM before the timed region.  Cameras are sharded over ranks
 and per-GPU work is fixed, so scaling is "weak".
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     for the dominant kernel: algorithmic bytes per launch / mean launch duration measured
-               with HIP events on the launch stream (library profiler, include/gsplat.h gs_profile_*)
-  cpu_baseline the CPU oracle ("port") timed on this box's host cores on ONE view of the same workload
+               with HIP events on the launch stream (library profiler, include/gsplat.h gs_profile_*);
+               for the blend kernels (VALU-bound) additionally the VALU-issue fraction, from the instruction
+               counts of the committed SQ-counter profile (labelled with its tag) and this run's duration
+  cpu_baseline the CPU oracle ("port") timed on this box's host cores on the same workload: all cores
+               (2 warm-up views, median of 5) and one thread (one view)
+  reference_lists  the same step on the reference's bounding-square instance lists (tile_cull = 0)
 """
 import argparse
 import json
@@ -32,6 +38,8 @@ import torch.distributed as dist  # noqa: E402
 CONFIGS = {
     # name: (P, W, H, dwt, patch, description)
     "c3": (1_000_000, 1920, 1080, True, True, "BASELINE configs[2]: 1M Gaussians, 1080p, global+patch DWT"),
+    # the per-GPU share of configs[3] (8 cameras / step over 8 GPUs = one camera per GPU per step, full replica)
+    "c4": (2_000_000, 1920, 1080, True, True, "BASELINE configs[3]: 2M Gaussians, 1080p, one camera per GPU per step"),
     "c2": (500_000, 800, 800, True, False, "BASELINE configs[1]: 500k Gaussians, 800x800, global DWT"),
     "c1": (10_000, 400, 400, False, False, "BASELINE configs[0]: 10k Gaussians, 400x400, DWT off"),
     "tiny": (2_000, 256, 160, True, True, "plumbing check"),
@@ -49,6 +57,10 @@ def stage_bytes(P, R, N):
         "preprocess_fwd": 311 * P, "scan": 8 * P, "duplicate": 20 * P + 12 * R, "sort": 24 * R,
         "tile_ranges": 8 * R, "render_fwd": 44 * R + 24 * N, "render_bwd": 84 * R + 24 * N,
         "preprocess_bwd": 563 * P,
+        # gs_backward_step: the same stage without its 248 B of gradient writes (307 B read), plus the raw rotation /
+        # scaling / opacity rows (32 B), both Adam moments read and written, the parameters written (3 x 236 + 472 B ...)
+        "preprocess_bwd_step": (307 + 32 + 2 * 236 + 3 * 236 + 24) * P,
+        "adam": 28 * 59 * P,
     }
 
 
@@ -111,11 +123,15 @@ def host_cpu_share():
     return max(1, min(n, int(os.environ.get("GS_CPU_THREADS", n))))
 
 
-def cpu_baseline(cfg, scene, cam, gt, log, views=5):
-    """The CPU oracle (C++ restatement of the reference kernels, OpenMP) on a bounded sample of the same
-    workload: `views` x (forward + loss + backward) of one camera on the host cores (~10 s at C3).  Reported, never
-    the thing measured above."""
+def cpu_baseline(cfg, scene, cam, gt, log, views=5, warmups=2):
+    """The CPU oracle (C++ restatement of the reference kernels, OpenMP) on a bounded sample of the same workload,
+    protocol of SURVEY 8(d): forward + loss + backward of one camera on the host cores, (i) all cores this process may
+    use (OMP threads pinned by OMP_PROC_BIND when the caller sets it), `warmups` untimed views then the MEDIAN of
+    `views` timed ones (~15 s at C3), (ii) one thread, one view (~25 s at C3; GS_CPU_BASELINE_1T=0 skips it).
+    Reported, never the thing measured above."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import statistics
+
     import oracle_lib
     from gsplat_amd.losses import LGDWTCriterion, LossOps
     from gsplat_amd.trainer import GaussianModelLite, camera_to, render
@@ -127,21 +143,57 @@ def cpu_baseline(cfg, scene, cam, gt, log, views=5):
     crit = LGDWTCriterion(LossOps(orc.api), dwt_enable=dwt, patch_dwt_enable=patch)
     cam = camera_to(cam, cpu)
     gt = gt.cpu()
-    cores = host_cpu_share()
     orc.lib.gso_set_num_threads.restype = int
-    cores = int(orc.lib.gso_set_num_threads(cores))
-    torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    for _ in range(views):
+
+    def one_view():
+        t0 = time.perf_counter()
         model.zero_grad()
         pkg = render(cam, model, orc.Rasterizer, orc.Settings, torch.zeros(3), filter_as_indices=False)
         loss, _ = crit(pkg["render"], gt)
         loss.backward()
-    dt = (time.perf_counter() - t0) / views
-    log("cpu_baseline: %d views, %.2f s each on %d threads (loss %.5f)" % (views, dt, cores, float(loss.detach())))
-    return {"value": 1.0 / dt, "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": "%d views (fwd + loss + bwd each, no Adam) of the same %s workload through the CPU oracle "
-                      "(oracle/libgs_oracle.so, OpenMP over Gaussians / tiles), no warm-up" % (views, cfg)}
+        return time.perf_counter() - t0, float(loss.detach())
+
+    cores = int(orc.lib.gso_set_num_threads(host_cpu_share()))
+    torch.set_num_threads(cores)
+    for _ in range(warmups):
+        one_view()
+    times = [one_view()[0] for _ in range(views)]
+    dt = statistics.median(times)
+    log("cpu_baseline: %d threads, %d warm-ups, %d views: median %.2f s (min %.2f, max %.2f)" % (
+        cores, warmups, views, dt, min(times), max(times)))
+    out = {"value": 1.0 / dt, "unit": "views/s", "cores": cores, "kind": "port",
+           "sample": "%d warm-up + %d timed views (median; fwd + loss + bwd each, no Adam) of the same %s workload through "
+                     "the CPU oracle (oracle/libgs_oracle.so, OpenMP over Gaussians / tiles)" % (warmups, views, cfg),
+           "seconds_per_view": {"median": dt, "min": min(times), "max": max(times)}}
+    if os.environ.get("GS_CPU_BASELINE_1T", "1") != "0":
+        orc.lib.gso_set_num_threads(1)
+        torch.set_num_threads(1)
+        t1, _ = one_view()
+        log("cpu_baseline: 1 thread, 1 view: %.2f s" % t1)
+        out["one_thread"] = {"value": 1.0 / t1, "unit": "views/s", "cores": 1, "sample": "1 view, no warm-up"}
+        orc.lib.gso_set_num_threads(cores)
+        torch.set_num_threads(cores)
+    return out
+
+
+# wave64 VALU issue peak: 1 024 SIMDs, one instruction per 2 cycles each, 2.4 GHz (MI355X_MICROARCH.md cycle constants)
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0
+
+
+def valu_roofline(kernel, ms_per_launch):
+    """VALU-issue fraction of a blend kernel: wave-instructions per launch (SQ_INSTS_VALU of the committed SQ-counter
+    profile, profiles/sq_insts.json: {"tag": ..., "<kernel>": insts per launch}) / this run's launch duration / peak."""
+    f = os.path.join(ROOT, "profiles", "sq_insts.json")
+    try:
+        d = json.load(open(f))
+        insts = float(d[kernel])
+    except Exception:
+        return None
+    ach = insts / (ms_per_launch * 1e-3) / 1e9
+    return {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+            "frac": ach / VALU_PEAK_GINST, "insts_per_launch": insts, "cycles_at_peak": insts * 2.0 / 1024,
+            "insts_from": "profiles/sq_insts.json (tag %s): SQ_INSTS_VALU per launch on the C3 workload; duration measured "
+                          "in this run" % d.get("tag", "?")}
 
 
 def main():
@@ -198,26 +250,11 @@ def main():
         tr.step(k)
         k += 1
     barrier()
-    # HIP-event timers (library profiler) bracket ONLY the dominant kernel inside the timed region: every event
-    # pair drains the pipeline for ~10 us, 17 stages would cost ~6 % of the step.  The full per-stage table comes
-    # from a second, untimed pass below.
+    # HIP-event timers (library profiler).  Every event pair drains the pipeline for ~10 us, so the timed region carries
+    # them around ONE kernel only - the dominant one, found by an untimed pass with every stage instrumented first.
     names = [api.raw("profile_stage_name")(i).decode() for i in range(api.raw("profile_stage_count")())]
-    dom_stage = os.environ.get("GS_BENCH_DOMINANT", "render_bwd")
+    prof, prof_timed, dom_stage = {}, {}, os.environ.get("GS_BENCH_DOMINANT", "")
     if not args.no_stage_timers:
-        api.call("profile_reset")
-        api.call("profile_only", names.index(dom_stage))
-        api.call("profile_enable", 1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step(k)
-        k += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    prof, prof_timed = {}, {}
-    if not args.no_stage_timers:
-        api.call("profile_enable", 0)
-        prof_timed = read_profile(api)
-        # untimed pass with every stage instrumented
         api.call("profile_reset")
         api.call("profile_only", -1)
         api.call("profile_enable", 1)
@@ -227,8 +264,54 @@ def main():
         barrier()
         api.call("profile_enable", 0)
         prof = read_profile(api)
+        if not dom_stage:
+            timed_kernels = [n for n in prof if n in stage_bytes(1, 1, 1)]
+            dom_stage = max(timed_kernels, key=lambda n: prof[n][0] / prof[n][1]) if timed_kernels else "render_bwd"
+        api.call("profile_reset")
+        api.call("profile_only", names.index(dom_stage))
+        api.call("profile_enable", 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(k)
+        k += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if not args.no_stage_timers:
+        api.call("profile_enable", 0)
+        prof_timed = read_profile(api)
+        api.call("profile_only", -1)
         if dom_stage in prof_timed:
             prof[dom_stage] = prof_timed[dom_stage]  # the timed region's own measurement of the dominant kernel
+    # the same step on the reference's bounding-square instance lists (GsView.tile_cull = 0: point_list / ranges /
+    # num_rendered bit-identical to the reference's), outside the timed region
+    ref_lists = None
+    if world == 1 and os.environ.get("GS_BENCH_REFERENCE_LISTS", "1") != "0":
+        from gsplat_amd import hip_backend as _hb
+        be = _hb()
+        old_cull = be.tile_cull
+        be.tile_cull = False
+        try:
+            for _ in range(2):
+                tr.step(k)
+                k += 1
+            barrier()
+            nref = min(args.steps, 10)
+            t1 = time.perf_counter()
+            for _ in range(nref):
+                tr.step(k)
+                k += 1
+            barrier()
+            dref = (time.perf_counter() - t1) / nref
+            ref_lists = {"ms_per_step": dref * 1e3, "views_per_s": 1.0 / dref, "steps": nref,
+                         "num_rendered_last_view": int(be._pinned[0]) if be._pinned is not None else None,
+                         "what": "the identical step with GsView.tile_cull = 0: the instance lists (num_rendered, point_list, "
+                                 "ranges) are the reference's, bit for bit; untimed by the driver"}
+        finally:
+            be.tile_cull = old_cull
+        for _ in range(2):  # restore the capacity hint / last-view counter of the culled mode
+            tr.step(k)
+            k += 1
+        barrier()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -255,23 +338,35 @@ def main():
             stages[name] = e
         roofline = None
         if stages:
-            dom = max((n for n in stages if n in sb), key=lambda n: stages[n]["ms_per_launch"])
+            dom = dom_stage if dom_stage in stages and dom_stage in sb else \
+                max((n for n in stages if n in sb), key=lambda n: stages[n]["ms_per_launch"])
             ach = stages[dom]["GBps"]
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "algorithmic_bytes_per_launch": sb[dom], "ms_per_launch": stages[dom]["ms_per_launch"],
-                        "note": "blend kernels are VALU-bound by construction (SURVEY 8d): render_bwd keeps the VALU "
-                                "busy 86 %% of all SIMD cycles (SQ_ACTIVE_INST_VALU, profiles/r01_sq_counters.csv) and "
-                                "moves 150 MB of HBM traffic for 875 MB of algorithmic bytes; "
-                                "step-level algorithmic bytes %.3f GB/view -> %.1f GB/s" % (
-                                    (902 * P + 172 * R_last + 84 * N) / 1e9,
-                                    (902 * P + 172 * R_last + 84 * N) / 1e9 * value / world)}
+            hbm = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+            roofline = dict(hbm)
+            roofline.update({"kernel": dom, "traffic": None, "algorithmic_bytes_per_launch": sb[dom],
+                             "ms_per_launch": stages[dom]["ms_per_launch"],
+                             "step_algorithmic_GB_per_view": (902 * P + 172 * R_last + 84 * N) / 1e9,
+                             "step_algorithmic_GBps": (902 * P + 172 * R_last + 84 * N) / 1e9 * value / world})
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tf) and args.config == "c3":  # counters were collected on the C3 workload
                 try:
-                    roofline["traffic"] = json.load(open(tf)).get(dom)
+                    t = json.load(open(tf))
+                    roofline["traffic"] = t.get(dom)
+                    roofline["traffic_from"] = "profiles/pmc_traffic.json (tag %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
+                                               "passes of this bench, not measured in this run" % t.get("tag", "r01")
                 except Exception:
                     pass
+            # the blend kernels are bound by VALU issue, not by HBM: report that roof for them
+            blend = {}
+            for kname in ("render_bwd", "render_fwd"):
+                if kname in stages:
+                    v = valu_roofline(kname, stages[kname]["ms_per_launch"])
+                    if v:
+                        blend[kname] = v
+            if dom in blend:
+                roofline.update(blend[dom])
+                roofline["hbm_view"] = hbm
+            roofline["blend_kernels_valu"] = blend or None
         out = {
             "metric": "train-step views/s (fwd+bwd) @1M Gaussians 1080p" if args.config == "c3"
                       else "train-step views/s (fwd+bwd) [%s]" % args.config,
@@ -281,12 +376,15 @@ def main():
             "config": {"workload": desc, "gaussians": P, "image": "%dx%d" % (W, H), "sh_degree": 3,
                        "scene": "trained-like (SURVEY 8d), seed 0", "cameras_per_step": world,
                        "num_rendered_last_view": R_last, "loss": "L1+SSIM" + ("+DWT2" if dwt else "") +
-                       ("+patchDWT" if patch else ""), "optimizer": "Adam eps 1e-15, fused HIP kernel over the flat buffer",
+                       ("+patchDWT" if patch else ""), "optimizer": "Adam eps 1e-15, " + ("inside the backward's per-Gaussian kernel (gs_backward_step)"
+                                                       if "preprocess_bwd_step" in stages else "fused HIP kernel over the flat buffer"),
                        "parallelism": "camera-sharded dp%d, one all-reduce of 61 f32/Gaussian (59 gradients + 2 statistic increments)" % world},
             "roofline": roofline,
+            "reference_lists": ref_lists,
             "stages": stages,
             "stages_note": "HIP events; %s measured inside the timed region, the other stages in a separate untimed "
-                           "pass of the same step (each event pair drains the pipeline for ~10 us)" % dom_stage,
+                           "pass of the same step before it (each event pair drains the pipeline for ~10 us); the timed "
+                           "step includes the optimizer" % dom_stage,
         }
         if world == 1 and not args.no_cpu_baseline and args.config not in NIR_CONFIGS:
             ci = tr.camera_index(k - 1)

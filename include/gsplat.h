@@ -106,6 +106,11 @@ typedef struct GsScratch {
   void* binning;
   size_t binning_bytes;
   int64_t binning_capacity; /* instances the binning buffer was sized for */
+  const uint32_t* tile_order_hint; /* optional (NULL: image order): launch order of the forward blend's tiles, as
+                                      gs_export_tile_order returned it for an earlier view of the SAME image size -
+                                      typically the previous visit of this camera, or just the previous view.  Pure
+                                      scheduling (longest tile first, see gs_export_tile_order): outputs do not depend on it.
+                                      Must be an unmodified export - every tile exactly once. */
 } GsScratch;
 
 /* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by
@@ -199,6 +204,40 @@ int gs_export_binning(const GsScratch* scratch, int64_t num_rendered, uint64_t* 
 int gs_export_img(const GsScratch* scratch, int32_t W, int32_t H, float* final_T,
                   uint32_t* n_contrib, uint32_t* ranges /*[T,2]*/, void* stream);
 
+/* The tail of a single-GPU train step fused into the backward (LGDWT-GS/train.py:262-288,
+ * scene/gaussian_model.py:40-60,183-193,471-473): gs_backward, then IN THE SAME per-Gaussian kernel the backward of the
+ * parameter activations (exp / F.normalize / sigmoid), the densification statistics of the view and the Adam update of
+ * the Gaussian's 59 parameters - the 236 B/Gaussian of gradients are never written to memory nor read back, and three
+ * launches (activation backward, statistics, Adam) disappear.  Valid when every gradient is final after this one view
+ * (one camera per optimizer step on one GPU - the reference's own loop); the data-parallel step keeps gs_backward +
+ * all-reduce + gs_adam_step.  Arithmetic per element is that of gs_activations_bwd, gs_densify_stats and gs_adam_step.
+ *
+ * The raw parameter rows live in the caller's buffers; g->means3D must BE st->xyz and g->shs must BE st->features (no
+ * activation in between), g->scales / rotations / opacities are the activated tensors handed to the forward;
+ * g->M == 16, no precomputed colours / covariances. */
+typedef struct GsStepState {
+  float* xyz;       /* [P,3]   raw parameters, updated in place */
+  float* features;  /* [P,16,3] */
+  float* opacity;   /* [P]   pre-sigmoid */
+  float* scaling;   /* [P,3] pre-exp */
+  float* rotation;  /* [P,4] un-normalised */
+  float* m[5];      /* Adam exp_avg of the five rows above, same shapes */
+  float* v[5];      /* Adam exp_avg_sq */
+  float lr[6];      /* xyz, features DC (k = 0), features rest (k = 1..15), opacity, scaling, rotation */
+  int32_t step[5];  /* the row's 1-based Adam step count (bias correction); 0 = row skipped: parameter and moments untouched */
+  float beta1, beta2, eps;
+  float* max_radii2D;        /* [P] densification statistics of train.py:266-268 (all three or none) */
+  float* xyz_gradient_accum; /* [P] */
+  float* denom;              /* [P] */
+  const float* rows_override; /* parity probe, normally NULL: [P,16] blend sums to use INSTEAD of running stage 1 (layout:
+                                gs_backward_from_rows) - lets a test hand the fused tail and the three-kernel tail the
+                                very same sums and compare them bit for bit */
+} GsStepState;
+int gs_backward_step(const GsView* view, const GsGaussians* g, const int32_t* radii,
+                     const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
+                     const float* dL_dinvdepth, const GsStepState* st, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* Stage 2 of gs_backward on its own (parity export): the per-Gaussian chain rule from given sums of the blend
  * backward.  rows [P,16] (device): mean2D.x, mean2D.y, conic.xx, conic.xy, conic.yy, opacity, r, g, b, depth slot,
  * 4th channel, 5 pad - what stage 1 leaves in the workspace (backward.cu:593-635 accumulates the same ten sums with
@@ -208,6 +247,14 @@ int gs_export_img(const GsScratch* scratch, int32_t W, int32_t H, float* final_T
 int gs_backward_from_rows(const GsView* view, const GsGaussians* g, const int32_t* radii,
                           const GsScratch* scratch, const float* rows, int32_t depth_mode,
                           const GsGrads* grads, void* stream);
+
+/* The order in which the backward blend of this view takes its tiles: 8 * ceil(T/8) entries, entry b = the tile of
+ * workgroup b (0xFFFFFFFF: none), per XCD band of the image by decreasing number of list entries the tile visits.  One
+ * wave owns a tile and runs at the pace of its dependent instruction chain, so handing out the longest tiles first
+ * shortens the kernel's tail (csrc/gs_render_fwd_wave.hip).  The forward blend's cost per tile is nearly the same
+ * quantity, unknown before it has run - but a good predictor is the previous view: pass the export back in as
+ * GsScratch.tile_order_hint.  out: device, 8 * ceil(T/8) uint32. */
+int gs_export_tile_order(const GsScratch* scratch, int32_t W, int32_t H, uint32_t* out, void* stream);
 
 /* ---- simple-knn ---- */
 /* out[i] = mean of the 3 smallest squared distances from point i to the other points.

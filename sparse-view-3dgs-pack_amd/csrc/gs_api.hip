@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 #include "gs_common.h"
 #include "gs_prof.h"
@@ -185,7 +186,10 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
   {
     GS_PROF(ST_RENDER_FWD, s);
     launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, iv.tile_work,
-                           out_color, out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
+                           sc->tile_order_hint, out_color, out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
+  }
+  {
+    GS_PROF(ST_TILE_ORDER, s);
     launch_tile_order(iv.tile_work, iv.tile_order, (int)T, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
@@ -201,7 +205,8 @@ int gs_backward(const GsView* v, const GsGaussians* g, const int32_t* radii, con
 
 static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
                          int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra,
-                         int fsgs, const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream);
+                         int fsgs, const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream,
+                         const GsStepState* step = nullptr);
 
 int gs_backward_x(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
                   int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra,
@@ -250,12 +255,42 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
   return a;
 }
 
+// host half of gs_backward_step: argument rules and the bias corrections (as gs_adam_step computes them)
+static int step_args(const GsGaussians* g, const GsStepState* st, StepArgs& sa) {
+  if (!st->xyz || !st->features || !st->opacity || !st->scaling || !st->rotation) return GS_E_NULL;
+  for (int k = 0; k < 5; k++)
+    if (!st->m[k] || !st->v[k]) return GS_E_NULL;
+  const bool any_stat = st->max_radii2D || st->xyz_gradient_accum || st->denom;
+  if (any_stat && !(st->max_radii2D && st->xyz_gradient_accum && st->denom)) return GS_E_NULL;
+  if (g->means3D != st->xyz || g->shs != st->features) return GS_E_SHAPE;  // no activation between them
+  if (g->M != 16 || g->colors_precomp || g->cov3D_precomp || !g->scales || !g->rotations || g->extra_channel)
+    return GS_E_UNSUPPORTED;
+  sa.st = *st;
+  static const int row_of_lr[6] = {0, 1, 1, 2, 3, 4};
+  for (int k = 0; k < 5; k++) {
+    if (st->step[k] < 0) return GS_E_SHAPE;
+    const int t = st->step[k] > 0 ? st->step[k] : 1;
+    sa.inv_sqrt_bc2[k] = (float)(1.0 / sqrt(1.0 - pow((double)st->beta2, (double)t)));
+  }
+  for (int c = 0; c < 6; c++) {
+    const int t = st->step[row_of_lr[c]] > 0 ? st->step[row_of_lr[c]] : 1;
+    sa.lr_bc1[c] = st->lr[c] * (float)(1.0 / (1.0 - pow((double)st->beta1, (double)t)));
+  }
+  return GS_OK;
+}
+
 static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc,
                          int64_t num_rendered, const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra,
-                         int fsgs, const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+                         int fsgs, const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream,
+                         const GsStepState* step) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !grads || !dL_dcolor) return GS_E_NULL;
+  StepArgs sa;
+  if (step && g->P > 0) {
+    rc = step_args(g, step, sa);
+    if (rc) return rc;
+  }
   const int P = g->P, W = v->image_width, H = v->image_height;
   if (P == 0) return GS_OK;
   if (!radii || !sc->geom || !sc->img || !workspace) return GS_E_NULL;
@@ -270,11 +305,14 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   ImgView iv = img_view(sc->img, N, T);
   SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
   float* rows = (float*)workspace;
-  {
+  const bool given_rows = step && step->rows_override;
+  if (given_rows) {
+    rows = const_cast<float*>(step->rows_override);
+  } else {
     GS_PROF(ST_BWD_MEMSET, s);
     GS_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)P * GR_STRIDE * sizeof(float), s));
   }
-  if (num_rendered > 0) {
+  if (num_rendered > 0 && !given_rows) {
     {
       GS_PROF(ST_RENDER_BWD, s);
       launch_render_bwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, iv.tile_work,
@@ -283,12 +321,24 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     GS_LAUNCH_CHECK(s, v->debug);
   }
   PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, grads);
-  {
+  if (step) {
+    GS_PROF(ST_BWD_STEP, s);
+    launch_preprocess_bwd_step(a, sa, s);
+  } else {
     GS_PROF(ST_PREPROCESS_BWD, s);
     launch_preprocess_bwd(a, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
+}
+
+int gs_backward_step(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, int64_t num_rendered,
+                     const float* dL_dcolor, const float* dL_dinvdepth, const GsStepState* st, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  if (!st) return GS_E_NULL;
+  const GsGrads none = {};
+  return backward_impl(v, g, radii, sc, num_rendered, dL_dcolor, dL_dinvdepth, nullptr, 0, &none, workspace, workspace_bytes,
+                       stream, st);
 }
 
 int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, const float* rows,
@@ -397,6 +447,17 @@ int gs_export_img(const GsScratch* sc, int32_t W, int32_t H, float* final_T, uin
   if (final_T) GS_HIP_CHECK(hipMemcpyAsync(final_T, iv.final_T, 4 * N, hipMemcpyDeviceToDevice, s));
   if (n_contrib) GS_HIP_CHECK(hipMemcpyAsync(n_contrib, iv.n_contrib, 4 * N, hipMemcpyDeviceToDevice, s));
   if (ranges) GS_HIP_CHECK(hipMemcpyAsync(ranges, iv.ranges, 8 * T, hipMemcpyDeviceToDevice, s));
+  return GS_OK;
+}
+
+int gs_export_tile_order(const GsScratch* sc, int32_t W, int32_t H, uint32_t* out, void* stream) {
+  if (!sc || !sc->img || !out) return GS_E_NULL;
+  if (W <= 0 || H <= 0) return GS_E_SHAPE;
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  if (sc->img_bytes < img_bytes(N, T)) return GS_E_SCRATCH;
+  ImgView iv = img_view(sc->img, N, T);
+  GS_HIP_CHECK(hipMemcpyAsync(out, iv.tile_order, 4 * (((T + 7) / 8) * 8), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return GS_OK;
 }
 

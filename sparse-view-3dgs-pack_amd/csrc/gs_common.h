@@ -119,10 +119,10 @@ struct ImgView {
   uint32_t* n_contrib;
   uint2* ranges;
   uint32_t* tile_work;   // [T] list entries the backward blend will visit in this tile = max last contributor (forward)
-  uint32_t* tile_order;  // [T] tiles by decreasing tile_work: launch order of the backward blend
+  uint32_t* tile_order;  // [8 ceil(T/8)] launch order of the backward blend: per XCD band, by decreasing tile_work
 };
 static inline __host__ __device__ size_t img_bytes(size_t N, size_t T) {
-  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T) + 2 * gs_align(4 * T);
+  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T) + gs_align(4 * T) + gs_align(4 * (T + 8));
 }
 static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T) {
   char* p = (char*)buf;
@@ -216,8 +216,9 @@ int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_h
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_work,
-                           float* out_color, float* out_invdepth, float* out_extra, int fsgs, int cull, hipStream_t s);
-// tile_order[] = the T tiles by decreasing tile_work[] (one small workgroup; order inside a bucket of equal work is free)
+                           const uint32_t* order_hint, float* out_color, float* out_invdepth, float* out_extra, int fsgs,
+                           int cull, hipStream_t s);
+// tile_order[] = per XCD band of the image, the tiles by decreasing tile_work[] (order inside a bucket of equal work is free)
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
@@ -246,3 +247,10 @@ struct PreprocessBwdArgs {
   GsGrads out;
 };
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+// the same stage with the train step's tail fused in (gs_backward_step); bias corrections precomputed on the host
+struct StepArgs {
+  GsStepState st;
+  float lr_bc1[6];        // lr / (1 - beta1^t) per learning-rate class
+  float inv_sqrt_bc2[5];  // 1 / sqrt(1 - beta2^t) per row
+};
+int launch_preprocess_bwd_step(const PreprocessBwdArgs& a, const StepArgs& sa, hipStream_t s);

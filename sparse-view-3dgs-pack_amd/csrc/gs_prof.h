@@ -26,6 +26,8 @@ enum GsStage {
   ST_DWT1,
   ST_ADAM,
   ST_MODEL,
+  ST_BWD_STEP,
+  ST_TILE_ORDER,
   ST_COUNT
 };
 

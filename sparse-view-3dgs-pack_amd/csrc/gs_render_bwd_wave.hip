@@ -64,8 +64,11 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
   __shared__ uint32_t s_id[WB];
 
   // longest tile first (tile_order_kernel in gs_render_fwd_wave.hip): the hardware hands workgroups to free wave slots
-  // in index order, so this is list scheduling by decreasing work - 64 % -> 97 % of the wave slots busy
-  const int tile = (int)tile_order[blockIdx.x];
+  // in index order, so this is list scheduling by decreasing work - 64 % -> 97 % of the wave slots busy in the model -
+  // and slot b holds a tile of image band b % 8, so that a band's splat records stay in one XCD's L2
+  const uint32_t tile_u = tile_order[blockIdx.x];
+  if (tile_u == 0xFFFFFFFFu) return;
+  const int tile = (int)tile_u;
   const uint32_t lmax = tile_work[tile];  // deepest last contributor of the tile's pixels
   if (lmax == 0) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -243,7 +246,7 @@ int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int 
                            const uint32_t* tile_work, const uint32_t* tile_order, const float* dL_dpix,
                            const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs, hipStream_t s) {
 #define GS_BWD_WAVE(ID, EX, FS)                                                                                           \
-  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX, FS>), dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, \
+  hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX, FS>), dim3(((grid_x * grid_y + 7) / 8) * 8), dim3(64), 0, s, ranges, point_list, W, H, \
                      grid_x, splat, bg, final_T, n_contrib, tile_work, tile_order, dL_dpix, dL_dinvdepth, dL_dextra, grad_rows)
   if (fsgs) GS_BWD_WAVE(true, true, true);
   else if (dL_dinvdepth && dL_dextra) GS_BWD_WAVE(true, true, false);

@@ -54,6 +54,7 @@ class GsScratch(C.Structure):
         ("binning", C.c_void_p),
         ("binning_bytes", C.c_size_t),
         ("binning_capacity", C.c_int64),
+        ("tile_order_hint", C.c_void_p),
     ]
 
 
@@ -82,6 +83,14 @@ class GsAdamSeg(C.Structure):
                 ("period", C.c_int32), ("split", C.c_int32), ("step", C.c_int32), ("_pad", C.c_int32)]
 
 
+class GsStepState(C.Structure):
+    _fields_ = [("xyz", C.c_void_p), ("features", C.c_void_p), ("opacity", C.c_void_p), ("scaling", C.c_void_p),
+                ("rotation", C.c_void_p), ("m", C.c_void_p * 5), ("v", C.c_void_p * 5), ("lr", C.c_float * 6),
+                ("step", C.c_int32 * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("max_radii2D", C.c_void_p), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
+                ("rows_override", C.c_void_p)]
+
+
 _P = C.c_void_p
 _I32 = C.c_int32
 _I64 = C.c_int64
@@ -104,12 +113,15 @@ PROTOTYPES = {
     "forward_render_fsgs": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P, _P]),
     "backward_fsgs": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P, _P,
                                 C.POINTER(GsGrads), _P, _SZ, _P]),
+    "backward_step": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P,
+                                C.POINTER(GsStepState), _P, _SZ, _P]),
     "backward_from_rows": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _P, _I32,
                                      C.POINTER(GsGrads), _P]),
     "mark_visible": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
     "export_geom": (C.c_int, [C.POINTER(GsScratch), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "export_binning": (C.c_int, [C.POINTER(GsScratch), _I64, _P, _P, _P]),
     "export_img": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _P, _P, _P, _P]),
+    "export_tile_order": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _P, _P]),
     "knn_tmp_bytes": (_SZ, [_I32]),
     "knn_mean_dist2": (C.c_int, [_P, _I32, _P, _P, _SZ, _P]),
     "knn_mean_dist2_idx": (C.c_int, [_P, _I32, _P, _P, _P, _SZ, _P]),
@@ -149,7 +161,7 @@ PROTOTYPES = {
 # entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
 # (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
 # reference's two 3-channel passes, so the checker does not need it)
-DEVICE_ONLY = ("profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
+DEVICE_ONLY = ("backward_step", "export_tile_order", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
                "forward_render_x", "backward_x")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}

@@ -51,10 +51,16 @@ class RasterBackend:
         self.tile_cull = os.environ.get("GS_TILE_CULL", "1") != "0"
         self._cap_memo = {}
         self._cap_by_buffer = {}
+        self._order_bufs = {}
+        self.order_hint_on = os.environ.get("GS_FWD_ORDER_HINT", "1") != "0"
         self._pinned_by_device = {}
         # one-shot output arena for the next backward: {"means3D": [P,3], "sh": [P,M,3]} fp32 tensors to write
         # dL_dmeans3D / dL_dsh INTO (e.g. views of a flat gradient buffer) instead of fresh allocations
         self.grad_arena = None
+        # one-shot request for the next backward: a gsplat_amd.capi.GsStepState (+ the tensors it points into, kept alive
+        # by the caller) - run gs_backward_step (backward + activation backward + view statistics + Adam in the same
+        # per-Gaussian kernel) instead of gs_backward; the backward then returns no gradients at all
+        self.fused_step = None
         # parity probes: keep the backward workspace (the per-Gaussian 16-float gradient rows of the blend backward)
         self.keep_workspace = False
         self.last_workspace = None
@@ -149,6 +155,18 @@ class RasterBackend:
         self.api.call("scratch_bytes", P, W, H, R, out, C.byref(ws))
         return out[0], out[1], out[2], ws.value
 
+    def _order_hint(self, device, W, H):
+        """Scheduling hint for the forward blend (GsScratch.tile_order_hint): the tile order of the previous view of the
+        same image size.  GS_FWD_ORDER_HINT=0 switches it off."""
+        if not self.order_hint_on or device.type != "cuda":
+            return None, None
+        key = (device.index, W, H)
+        n = ((((W + 15) // 16) * ((H + 15) // 16) + 7) // 8) * 8
+        buf = self._order_bufs.get(key)
+        if buf is None:
+            buf = self._order_bufs[key] = [torch.empty((n,), dtype=torch.int32, device=device), False]
+        return buf, (buf[0] if buf[1] else None)
+
     @staticmethod
     def _scratch(geom, img, binning, capacity):
         s = GsScratch()
@@ -191,16 +209,15 @@ class RasterBackend:
             e = torch.empty((0,), **u8)
             return (0, out_color, radii, e, e.clone(), e.clone(), out_invdepth) + tail
 
+        order_buf, order_hint = self._order_hint(device, W, H)
+
         def render(scratch):
-            if fsgs:
-                self.api.call("forward_render_fsgs", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
-                              out_invdepth.data_ptr(), out_extra.data_ptr(), stream)
-            elif extra is None:
-                self.api.call("forward_render", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
-                              out_invdepth.data_ptr(), stream)
-            else:
-                self.api.call("forward_render_x", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
-                              out_invdepth.data_ptr(), out_extra.data_ptr(), stream)
+            if order_hint is not None:
+                scratch.tile_order_hint = order_hint.data_ptr()
+            self._render(scratch, fsgs, extra, view, g, out_color, out_invdepth, out_extra, stream)
+            if order_buf is not None:  # this view's measured order becomes the next view's hint
+                self.api.call("export_tile_order", C.byref(scratch), W, H, order_buf[0].data_ptr(), stream)
+                order_buf[1] = True
 
         keep = []
         view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
@@ -262,6 +279,17 @@ class RasterBackend:
         render(s)
         return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
 
+    def _render(self, scratch, fsgs, extra, view, g, out_color, out_invdepth, out_extra, stream):
+        if fsgs:
+            self.api.call("forward_render_fsgs", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
+                          out_invdepth.data_ptr(), out_extra.data_ptr(), stream)
+        elif extra is None:
+            self.api.call("forward_render", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
+                          out_invdepth.data_ptr(), stream)
+        else:
+            self.api.call("forward_render_x", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
+                          out_invdepth.data_ptr(), out_extra.data_ptr(), stream)
+
     # ------------------------------------------------------------------ backward
     def rasterize_gaussians_backward(self, bg, means3D, radii, colors_precomp, opacities, scales, rotations,
                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy,
@@ -282,6 +310,23 @@ class RasterBackend:
         # every row is written by gs_backward (culled rows become 0): empty, not zeros
         alloc = torch.empty if P != 0 else torch.zeros
         arena, self.grad_arena = self.grad_arena, None
+        step, self.fused_step = self.fused_step, None
+        if step is not None and P != 0:
+            if fsgs or extra is not None:
+                raise RuntimeError("the fused train-step backward serves the plain RGB rasterizer only")
+            keep = []
+            view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
+                              degree, False, antialiasing, debug)
+            g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+            dL_dout_color = _prep(dL_dout_color, device)
+            dL_dout_invdepth = _prep(dL_dout_invdepth, device)
+            _, _, _, wsb = self.scratch_bytes(P, W, H, R)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
+            s = self._scratch(geomBuffer, imgBuffer, binningBuffer, self._capacity_for(binningBuffer, P, W, H, R))
+            self.api.call("backward_step", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
+                          dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(step), _ptr(ws), ws.numel(),
+                          self._stream(device))
+            return (None,) * 8
 
         def out(name, shape):
             t = None if arena is None else arena.get(name)

@@ -112,6 +112,26 @@ class FlatAdam:
                       self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
                       self.betas[0], self.betas[1], self.eps, self.t, stream)
 
+    def fused_request(self, skip=()):
+        """The GsStepState of ONE optimizer step (counters advanced as step() would) for gs_backward_step: raw parameter
+        rows, both moment buffers, per-row step counts (0 = skipped), learning rates, view statistics."""
+        from .capi import GsStepState
+        m = self.model
+        self.begin_step(skip)
+        st = GsStepState()
+        p, ea, eas = self.field_views(m.flat), self.field_views(self.exp_avg), self.field_views(self.exp_avg_sq)
+        names = ("xyz", "features", "opacity", "scaling", "rotation")
+        for k, name in enumerate(names):
+            setattr(st, name, p[name].data_ptr())
+            st.m[k], st.v[k] = ea[name].data_ptr(), eas[name].data_ptr()
+            st.step[k] = 0 if name in skip else (self.seg_steps[name] if self.seg_steps[name] > 0 else self.t)
+        for k, name in enumerate(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
+            st.lr[k] = self.lr[name]
+        st.beta1, st.beta2, st.eps = self.betas[0], self.betas[1], self.eps
+        st.max_radii2D, st.xyz_gradient_accum, st.denom = (m.max_radii2D.data_ptr(), m.xyz_gradient_accum.data_ptr(),
+                                                           m.denom.data_ptr())
+        return st
+
     def field_views(self, buf):
         P, off, out = self.model.P, 0, {}
         for name, n in self.model.fields:
@@ -666,29 +686,48 @@ class Trainer:
         if iteration % opt.sh_increase_interval == 0:
             m.oneupSHdegree()
         ci = self.draw_cameras(opt.seed)
-        loss = self._step_camera(ci, False, ())
-        densified, reset, skip_all = None, False, False
-        if iteration < opt.densify_until_iter:
-            if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
-                thr = opt.size_threshold if iteration > opt.opacity_reset_interval else None
-                gen = torch.Generator().manual_seed(opt.seed * 1000003 + iteration)
-                densified = m.densify_and_prune(opt.densify_grad_threshold, opt.min_opacity, opt.cameras_extent, thr,
-                                                self.last["radii"], generator=gen)
-                skip_all = True
-            if iteration % opt.opacity_reset_interval == 0 or (opt.white_background and iteration == opt.densify_from_iter):
-                m.reset_opacity()
-                reset = True
-        if iteration < opt.iterations and not skip_all:
-            m.optimizer.step(skip=("opacity",) if reset else ())
-            self._after_optimizer_step()
+        # What the schedule will do after the backward is known beforehand, so the optimizer step can run inside the
+        # step (fused into the backward on one GPU, overlapped with the all-reduce on several).  Its order against
+        # reset_opacity is free: the reset replaces the opacity row and its moments, the step skips exactly that row.
+        in_densify = iteration < opt.densify_until_iter
+        will_densify = in_densify and iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0
+        will_reset = in_densify and (iteration % opt.opacity_reset_interval == 0 or
+                                     (opt.white_background and iteration == opt.densify_from_iter))
+        do_step = iteration < opt.iterations and not will_densify
+        loss = self._step_camera(ci, do_step, ("opacity",) if will_reset else ())
+        densified, reset = None, False
+        if will_densify:
+            thr = opt.size_threshold if iteration > opt.opacity_reset_interval else None
+            gen = torch.Generator().manual_seed(opt.seed * 1000003 + iteration)
+            densified = m.densify_and_prune(opt.densify_grad_threshold, opt.min_opacity, opt.cameras_extent, thr,
+                                            self.last["radii"], generator=gen)
+        if will_reset:
+            m.reset_opacity()
+            reset = True
         return dict(loss=loss, densified=densified, reset=reset, P=m.P, camera=ci)
+
+    # single-GPU steps run the optimizer inside the rasterizer backward (gs_backward_step); GS_FUSED_STEP=0 keeps the
+    # separate activation-backward / statistics / Adam kernels (the path every multi-GPU step takes)
+    FUSED_STEP = __import__("os").environ.get("GS_FUSED_STEP", "1") != "0"
+
+    def _fused_step_ok(self, backend, optimizer_step):
+        m = self.model
+        return (self.FUSED_STEP and optimizer_step and self.world_size == 1 and backend is not None
+                and isinstance(m.optimizer, FlatAdam) and not m.with_nir and m.flat.is_cuda
+                and hasattr(backend.api, "_backward_step") and hasattr(backend, "fused_step"))
 
     def _step_camera(self, ci, optimizer_step, skip):
         m = self.model
         m.zero_grad()
         backend = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
         backend = getattr(backend, "backend", None)
-        if backend is not None:
+        fused_step = self._fused_step_ok(backend, optimizer_step)
+        if fused_step:
+            backend.fused_step = m.optimizer.fused_request(skip)
+            rows = getattr(self, "rows_override", None)  # parity tests: blend sums to use instead of stage 1
+            if rows is not None:
+                backend.fused_step.rows_override = rows.data_ptr()
+        elif backend is not None:
             m.arm_grad_arena(backend)
         fused = getattr(self.criterion, "fused", False)
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
@@ -706,9 +745,6 @@ class Trainer:
             self.exchange_and_step(optimizer_step, skip)
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
-
-    def _after_optimizer_step(self):
-        """Hook of train_iteration: parameters that live outside the flat buffer are stepped here."""
 
     DP_CHUNKS = 4
 
@@ -830,11 +866,8 @@ class TrainerNIR(Trainer):
                 dist.all_reduce(m.nir_gain.grad, op=dist.ReduceOp.SUM)
             self.exchange_and_step(optimizer_step, skip)
             if optimizer_step:
+                # the reference keeps the global gain in the main Adam (mult-dwtgs/scene/gaussian_model.py:266-280): it
+                # is stepped whenever optimizer.step() runs - and, like every group, not on a densification iteration
                 m.nir_gain_optimizer.step()
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
-
-    def _after_optimizer_step(self):
-        # the reference keeps the global gain in the main Adam (mult-dwtgs/scene/gaussian_model.py:266-280), so it is
-        # stepped whenever optimizer.step() runs - and, like every group, not on a densification iteration
-        self.model.nir_gain_optimizer.step()
