@@ -378,7 +378,10 @@ def main():
                        "num_rendered_last_view": R_last, "loss": "L1+SSIM" + ("+DWT2" if dwt else "") +
                        ("+patchDWT" if patch else ""), "optimizer": "Adam eps 1e-15, " + ("inside the backward's per-Gaussian kernel (gs_backward_step)"
                                                        if "preprocess_bwd_step" in stages else "fused HIP kernel over the flat buffer"),
-                       "parallelism": "camera-sharded dp%d, one all-reduce of 61 f32/Gaussian (59 gradients + 2 statistic increments)" % world},
+                       "parallelism": ("camera-sharded dp%d, reduce-scatter of 59 f32/Gaussian + Adam on 1/N of the rows + "
+                                       "all-gather of the parameters (GS_SHARDED_ADAM=1)" % world)
+                       if getattr(tr, "sharded_optimizer", False) and world > 1 else
+                       "camera-sharded dp%d, one all-reduce of 61 f32/Gaussian (59 gradients + 2 statistic increments)" % world},
             "roofline": roofline,
             "reference_lists": ref_lists,
             "stages": stages,

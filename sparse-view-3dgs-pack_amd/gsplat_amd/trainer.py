@@ -32,6 +32,7 @@ LRS = {"xyz": 0.00016, "f_dc": 0.0025, "f_rest": 0.0025 / 20.0, "opacity": 0.025
        # no schedule), the global gain at feature_lr
        "nir_albedo": 0.00016, "nir_gain": 0.0025}
 NIR_FIELD = ("nir_albedo", 1)
+SHARD_UNIT = 4 * 840  # float4 x lcm(1..8)
 
 
 def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
@@ -55,8 +56,7 @@ class FlatAdam:
     def __init__(self, api, model, betas=(0.9, 0.999), eps=1e-15):
         from .capi import GsAdamSeg
         self.api, self.model, self.betas, self.eps = api, model, betas, eps
-        self.exp_avg = torch.zeros_like(model.flat)
-        self.exp_avg_sq = torch.zeros_like(model.flat)
+        self.alloc_moments()
         self.t = 0
         # torch keeps Adam's step count per parameter; a group that is skipped (no gradient after its tensor
         # was replaced) falls behind the others
@@ -64,6 +64,15 @@ class FlatAdam:
         self.lr = dict(LRS)
         self.lr["xyz"] = LRS["xyz"] * model.spatial_lr_scale
         self._Seg = GsAdamSeg
+
+    def alloc_moments(self):
+        """Zeroed moment buffers for the model's current size, padded like the parameters (the sharded optimizer
+        all-gathers them in place before a re-layout or a checkpoint)."""
+        m = self.model
+        self.exp_avg_padded = torch.zeros_like(m.flat_padded)
+        self.exp_avg_sq_padded = torch.zeros_like(m.flat_padded)
+        self.exp_avg = self.exp_avg_padded[:m.flat.numel()]
+        self.exp_avg_sq = self.exp_avg_sq_padded[:m.flat.numel()]
 
     def segments(self, skip=()):
         P = self.model.P
@@ -94,7 +103,7 @@ class FlatAdam:
             if name not in skip:
                 self.seg_steps[name] += 1
 
-    def step_range(self, lo, hi, skip=()):
+    def step_range(self, lo, hi, skip=(), grads=None):
         """The update of elements [lo, hi) of the flat buffers (lo a multiple of 4): the data-parallel step applies
         Adam chunk by chunk as the chunks of the gradient all-reduce arrive.  The segment table is shifted by -lo so
         that the kernel's element index i stands for element lo + i (a negative `begin` keeps the phase of the
@@ -108,7 +117,9 @@ class FlatAdam:
             segs[k].begin -= lo
             segs[k].end -= lo
         stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
-        self.api.call("adam_step", m.flat.data_ptr() + 4 * lo, m.flat_grad.data_ptr() + 4 * lo,
+        # grads: a tensor holding the gradients of elements [lo, hi) (default: that slice of the flat gradient buffer)
+        gptr = m.flat_grad.data_ptr() + 4 * lo if grads is None else grads.data_ptr()
+        self.api.call("adam_step", m.flat.data_ptr() + 4 * lo, gptr,
                       self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
                       self.betas[0], self.betas[1], self.eps, self.t, stream)
 
@@ -235,12 +246,19 @@ class GaussianModelLite:
         """(Re)create the flat parameter / gradient buffers for P Gaussians and the views into them."""
         self.P = P
         W = self.width
-        self.flat = torch.zeros((P * W,), dtype=torch.float32, device=self.device)
+        # parameters and gradients are padded to a multiple of SHARD_UNIT floats so that the flat buffers split into
+        # equal, float4-aligned shards for any world size up to 8 (sharded optimizer: reduce-scatter / all-gather
+        # run in place on the padded buffers); `flat` / `flat_grad` are the un-padded views everything else uses
+        n = P * W
+        n_pad = (n + SHARD_UNIT - 1) // SHARD_UNIT * SHARD_UNIT
+        self.flat_padded = torch.zeros((n_pad,), dtype=torch.float32, device=self.device)
+        self.flat = self.flat_padded[:n]
         # gradient buffer + a [2, P] tail for this step's densification-statistic increments: the data-parallel
         # exchange is then ONE all-reduce (SUM) over gradients and increments together
-        self.exchange = torch.zeros((P * (W + 2),), dtype=torch.float32, device=self.device)
-        self.flat_grad = self.exchange[:P * W]
-        self.stat_delta = self.exchange[P * W:].view(2, P)
+        self.exchange = torch.zeros((n_pad + 2 * P,), dtype=torch.float32, device=self.device)
+        self.flat_grad = self.exchange[:n]
+        self.grad_padded = self.exchange[:n_pad]
+        self.stat_delta = self.exchange[n_pad:].view(2, P)
         self.params = {}
         off = 0
         shapes = self._shapes(P)
@@ -312,8 +330,9 @@ class GaussianModelLite:
         self._allocate(int(state["P"]))
         with torch.no_grad():
             self.flat.copy_(state["flat"])
-        opt.exp_avg = state["exp_avg"].to(self.device).clone()
-        opt.exp_avg_sq = state["exp_avg_sq"].to(self.device).clone()
+        opt.alloc_moments()
+        opt.exp_avg.copy_(state["exp_avg"])
+        opt.exp_avg_sq.copy_(state["exp_avg_sq"])
         opt.t, opt.seg_steps, opt.lr = int(state["t"]), dict(state["seg_steps"]), dict(state["lr"])
         self.active_sh_degree = int(state["active_sh_degree"])
         self.xyz_gradient_accum = state["xyz_gradient_accum"].to(self.device).clone()
@@ -350,8 +369,7 @@ class GaussianModelLite:
             cat_m[name] = torch.cat((old_m[name][src_idx], z), dim=0)
             cat_v[name] = torch.cat((old_v[name][src_idx], z), dim=0)
         self._allocate(P2)
-        opt.exp_avg = torch.zeros_like(self.flat)
-        opt.exp_avg_sq = torch.zeros_like(self.flat)
+        opt.alloc_moments()
         new_m, new_v = opt.field_views(opt.exp_avg), opt.field_views(opt.exp_avg_sq)
         with torch.no_grad():
             for name, n in self.fields:
@@ -644,7 +662,12 @@ class Trainer:
     `train_iteration(it, opt)` is one iteration of the reference's loop with its schedule."""
 
     def __init__(self, model, cameras, gt_images, criterion, Rasterizer, Settings, bg, rank=0, world_size=1,
-                 optimizer_step=True, masks=None):
+                 optimizer_step=True, masks=None, sharded_optimizer=None):
+        # sharded_optimizer (default: env GS_SHARDED_ADAM=1): reduce-scatter the gradients, Adam on this rank's 1/N of
+        # the rows, all-gather the parameters - instead of all-reduce + the full Adam pass on every replica
+        import os
+        self.sharded_optimizer = (os.environ.get("GS_SHARDED_ADAM", "0") == "1") if sharded_optimizer is None \
+            else bool(sharded_optimizer)
         self.model, self.cameras, self.gts, self.criterion = model, cameras, gt_images, criterion
         self.Rasterizer, self.Settings, self.bg = Rasterizer, Settings, bg
         self.rank, self.world_size = rank, world_size
@@ -697,6 +720,7 @@ class Trainer:
         loss = self._step_camera(ci, do_step, ("opacity",) if will_reset else ())
         densified, reset = None, False
         if will_densify:
+            self.gather_optimizer_state()
             thr = opt.size_threshold if iteration > opt.opacity_reset_interval else None
             gen = torch.Generator().manual_seed(opt.seed * 1000003 + iteration)
             densified = m.densify_and_prune(opt.densify_grad_threshold, opt.min_opacity, opt.cameras_extent, thr,
@@ -763,6 +787,8 @@ class Trainer:
             if optimizer_step:
                 opt.step(*([skip] if skip else []))
             return
+        if self.sharded_optimizer and chunked:
+            return self._exchange_and_step_sharded(optimizer_step, skip)
         n_grad = m.flat_grad.numel()
         nch = self.DP_CHUNKS if chunked else 1
         bounds = [(i * n_grad // nch) // 4 * 4 for i in range(nch)] + [m.exchange.numel()]
@@ -777,6 +803,45 @@ class Trainer:
                 opt.step_range(bounds[i], min(bounds[i + 1], n_grad), skip)
         if optimizer_step and not chunked:
             opt.step()
+        wmax.wait()
+        m.xyz_gradient_accum += m.stat_delta[0].unsqueeze(1)
+        m.denom += m.stat_delta[1].unsqueeze(1)
+
+    def gather_optimizer_state(self):
+        """Sharded optimizer only: every rank holds current Adam moments for ITS shard; before anything that needs them
+        all (densification re-layout, checkpoint) they are all-gathered in place.  No-op otherwise."""
+        m, opt = self.model, self.model.optimizer
+        if not (self.sharded_optimizer and self.world_size > 1 and isinstance(opt, FlatAdam)):
+            return
+        S = m.flat_padded.numel() // self.world_size
+        for buf in (opt.exp_avg_padded, opt.exp_avg_sq_padded):
+            dist.all_gather_into_tensor(buf, buf[self.rank * S:(self.rank + 1) * S])
+
+    def _exchange_and_step_sharded(self, optimizer_step, skip=()):
+        """The sharded form of exchange_and_step: rank r owns elements [r S, (r+1) S) of the padded flat
+        buffers.  reduce-scatter (SUM) leaves the summed gradients of its shard on each rank, Adam runs on that shard
+        only (1/N of the 28 B/element pass), all-gather returns the updated parameters to every replica; the view
+        statistics (8 B/Gaussian) and max_radii2D are all-reduced alongside.  Same bytes on the links as the all-reduce
+        (which is a reduce-scatter + all-gather inside RCCL), 1/N of the optimizer pass.  Both collectives run in place
+        on the padded buffers.  Replicas stay bit-identical: every parameter is computed once, by its owner.  With two
+        ranks the sums equal the all-reduce path's bit for bit (a + b is commutative); with more the reduction order
+        is the library's choice in both paths."""
+        m, opt = self.model, self.model.optimizer
+        world, rank = self.world_size, self.rank
+        n, n_pad = m.flat.numel(), m.flat_padded.numel()
+        S = n_pad // world
+        lo, hi = rank * S, min((rank + 1) * S, n)
+        gshard = m.grad_padded[rank * S:(rank + 1) * S]
+        wg = dist.reduce_scatter_tensor(gshard, m.grad_padded, op=dist.ReduceOp.SUM, async_op=True)
+        ws = dist.all_reduce(m.stat_delta, op=dist.ReduceOp.SUM, async_op=True)
+        wmax = dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)
+        wg.wait()
+        if optimizer_step:
+            opt.begin_step(skip)
+            if hi > lo:
+                opt.step_range(lo, hi, skip, grads=gshard)
+            dist.all_gather_into_tensor(m.flat_padded, m.flat_padded[rank * S:(rank + 1) * S])
+        ws.wait()
         wmax.wait()
         m.xyz_gradient_accum += m.stat_delta[0].unsqueeze(1)
         m.denom += m.stat_delta[1].unsqueeze(1)

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, sharded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
@@ -28,10 +28,12 @@ def _worker(rank, world, port, outdir):
     from test_trainer_cpu import make_trainer
     orc = oracle_lib.get()
     tr = make_trainer(orc, P=400, W=96, H=64, world_size=world, rank=rank)
+    tr.sharded_optimizer = sharded
     for k in range(2):
         tr.step(k)
     m = tr.model
-    torch.save(dict(flat=m.flat.clone(), grad=m.flat_grad.clone(), accum=m.xyz_gradient_accum.clone(),
+    torch.save(dict(flat=m.flat.clone(), grad=m.flat_grad.clone(), m1=m.optimizer.exp_avg.clone(),
+                    m2=m.optimizer.exp_avg_sq.clone(), accum=m.xyz_gradient_accum.clone(),
                     denom=m.denom.clone(), maxr=m.max_radii2D.clone(), cams=[tr.camera_index(k) for k in range(2)]),
                os.path.join(outdir, "rank%d.pt" % rank))
     dist.barrier()
@@ -77,7 +79,36 @@ def test_two_rank_gradient_allreduce_matches_single_process_sum(oracle):
     assert torch.allclose(acc, r0["accum"], rtol=1e-6, atol=1e-12)
 
 
-def _worker_schedule(rank, world, port, outdir):
+@pytest.mark.timeout(600)
+def test_sharded_optimizer_equals_the_all_reduce_path_bit_for_bit():
+    """reduce-scatter -> Adam on this rank's 1/N of the flat rows -> all-gather of the parameters (DESIGN.md 5,
+    Trainer._exchange_and_step_sharded) against all-reduce + the full Adam pass on every replica: after two steps on two
+    ranks the parameters and the statistics are the same bits on every rank of both runs; each rank's moments are
+    those of the all-reduce run on its own shard (and untouched elsewhere)."""
+    world = 2
+    runs = {}
+    for sharded in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker, args=(world, _free_port(), d, sharded), nprocs=world, join=True)
+            runs[sharded] = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(world)]
+    ref = runs[False][0]
+    n = ref["flat"].numel()
+    from gsplat_amd.trainer import SHARD_UNIT
+    S = ((n + SHARD_UNIT - 1) // SHARD_UNIT * SHARD_UNIT) // world
+    for r in range(world):
+        got = runs[True][r]
+        for k in ("flat", "accum", "denom", "maxr"):
+            assert torch.equal(got[k], ref[k]), (r, k)
+        lo, hi = r * S, min((r + 1) * S, n)
+        for k in ("m1", "m2"):
+            assert torch.equal(got[k][lo:hi], ref[k][lo:hi]), (r, k)
+            other = torch.cat((got[k][:lo], got[k][hi:]))
+            assert float(other.abs().max()) == 0.0  # this rank never touched the other shards' moments
+        assert torch.equal(got["grad"][lo:hi], ref["grad"][lo:hi])
+    assert 0 < S < n  # both ranks own a non-empty shard
+
+
+def _worker_schedule(rank, world, port, outdir, sharded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
@@ -88,6 +119,7 @@ def _worker_schedule(rank, world, port, outdir):
     from test_trainer_cpu import make_trainer
     orc = oracle_lib.get()
     tr = make_trainer(orc, P=300, W=96, H=64, world_size=world, rank=rank, dwt=False)
+    tr.sharded_optimizer = sharded
     opt = TrainOptions(iterations=20, densify_from_iter=2, densification_interval=3, opacity_reset_interval=5,
                        densify_until_iter=12, cameras_extent=4.4, densify_grad_threshold=1e-7, seed=1)
     cams, sizes = [], []
@@ -95,11 +127,31 @@ def _worker_schedule(rank, world, port, outdir):
         out = tr.train_iteration(it, opt)
         cams.append(out["camera"])
         sizes.append(out["P"])
+    tr.gather_optimizer_state()
     m = tr.model
     torch.save(dict(flat=m.flat.clone(), m1=m.optimizer.exp_avg.clone(), m2=m.optimizer.exp_avg_sq.clone(), cams=cams,
                     sizes=sizes), os.path.join(outdir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_optimizer_through_densification_equals_the_all_reduce_path():
+    """8 iterations of the schedule (densify / prune / opacity reset: the shard boundaries move with P, so the moments
+    are all-gathered before every re-layout) on two ranks, sharded against all-reduce: same sizes, parameters and
+    moments, bit for bit."""
+    out = {}
+    for sharded in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker_schedule, args=(2, _free_port(), d, sharded), nprocs=2, join=True)
+            out[sharded] = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(2)]
+    a = out[False][0]
+    assert a["sizes"][-1] != a["sizes"][0]
+    for r in range(2):
+        b = out[True][r]
+        assert b["sizes"] == a["sizes"]
+        for k in ("flat", "m1", "m2"):
+            assert torch.equal(a[k], b[k]), (r, k)
 
 
 @pytest.mark.timeout(600)
