@@ -229,6 +229,11 @@ typedef struct GsStepState {
   float* max_radii2D;        /* [P] densification statistics of train.py:266-268 (all three or none) */
   float* xyz_gradient_accum; /* [P] */
   float* denom;              /* [P] */
+  const float* coef_dev;      /* optional, device, 11 floats: lr[c] / (1 - beta1^t) for the six learning-rate classes, then
+                                1 / sqrt(1 - beta2^t) for the five rows.  NULL: computed from lr[] / step[] on the host and
+                                passed as kernel arguments.  A caller that REPLAYS a captured graph of the step must use
+                                this form (kernel arguments are frozen at capture) and refresh the buffer before each
+                                replay; step[] then only says which rows are skipped. */
   const float* rows_override; /* parity probe, normally NULL: [P,16] blend sums to use INSTEAD of running stage 1 (layout:
                                 gs_backward_from_rows) - lets a test hand the fused tail and the three-kernel tail the
                                 very same sums and compare them bit for bit */

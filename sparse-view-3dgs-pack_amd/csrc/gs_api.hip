@@ -323,6 +323,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, grads);
   if (step) {
     GS_PROF(ST_BWD_STEP, s);
+    sa.overflow = &gv.hdr->overflow;
     launch_preprocess_bwd_step(a, sa, s);
   } else {
     GS_PROF(ST_PREPROCESS_BWD, s);

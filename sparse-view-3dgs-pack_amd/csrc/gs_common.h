@@ -250,7 +250,8 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 // the same stage with the train step's tail fused in (gs_backward_step); bias corrections precomputed on the host
 struct StepArgs {
   GsStepState st;
-  float lr_bc1[6];        // lr / (1 - beta1^t) per learning-rate class
+  float lr_bc1[6];        // lr / (1 - beta1^t) per learning-rate class   (st.coef_dev, when given, replaces both arrays)
   float inv_sqrt_bc2[5];  // 1 / sqrt(1 - beta2^t) per row
+  const uint32_t* overflow;  // geom header flag: binning capacity exceeded, nothing was blended -> the step is a no-op
 };
 int launch_preprocess_bwd_step(const PreprocessBwdArgs& a, const StepArgs& sa, hipStream_t s);

@@ -129,6 +129,16 @@ GS_DEV void adam_row(float* p, float* m, float* v, int idx, const float* g, floa
 __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(PreprocessBwdArgs a, StepArgs sa) {
   __shared__ float s_sh[GS_BLOCK * SH_LDS_ROW];
   const GsStepState& st = sa.st;
+  // the forward ran out of binning capacity (possible only when the caller did not re-run it: a replayed graph): the
+  // image was not rendered, so nothing may be updated - the host sees the flag and repeats the step eagerly
+  if (*sa.overflow) return;
+  // step-dependent constants from device memory when the launch is replayed from a captured graph
+  if (st.coef_dev) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) sa.lr_bc1[k] = st.coef_dev[k];
+#pragma unroll
+    for (int k = 0; k < 5; k++) sa.inv_sqrt_bc2[k] = st.coef_dev[6 + k];
+  }
   const int idx_raw = blockIdx.x * GS_BLOCK + threadIdx.x;
   const bool in_range = idx_raw < a.P;
   const int idx = in_range ? idx_raw : a.P - 1;

@@ -88,7 +88,7 @@ class GsStepState(C.Structure):
                 ("rotation", C.c_void_p), ("m", C.c_void_p * 5), ("v", C.c_void_p * 5), ("lr", C.c_float * 6),
                 ("step", C.c_int32 * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_radii2D", C.c_void_p), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
-                ("rows_override", C.c_void_p)]
+                ("coef_dev", C.c_void_p), ("rows_override", C.c_void_p)]
 
 
 _P = C.c_void_p

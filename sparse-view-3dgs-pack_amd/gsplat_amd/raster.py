@@ -57,6 +57,11 @@ class RasterBackend:
         # one-shot output arena for the next backward: {"means3D": [P,3], "sh": [P,M,3]} fp32 tensors to write
         # dL_dmeans3D / dL_dsh INTO (e.g. views of a flat gradient buffer) instead of fresh allocations
         self.grad_arena = None
+        # capture-safe forward (hipGraph): a fixed binning capacity (instances) instead of the predicted one, no host
+        # wait, no host read.  The forward then returns the CAPACITY in place of num_rendered (the kernels read the real
+        # count from the device header; the backward only uses the value as an upper bound) and never re-runs: the
+        # caller checks `last_num_rendered()` against the capacity after the stream has drained.
+        self.static_capacity = None
         # one-shot request for the next backward: a gsplat_amd.capi.GsStepState (+ the tensors it points into, kept alive
         # by the caller) - run gs_backward_step (backward + activation backward + view statistics + Adam in the same
         # per-Gaussian kernel) instead of gs_backward; the backward then returns no gradients at all
@@ -140,6 +145,11 @@ class RasterBackend:
                 self._cap_memo.clear()
             self._cap_memo[key] = cap
         return cap
+
+    def last_num_rendered(self):
+        """num_rendered of the most recent forward on the current device / stream as the device reported it (pinned
+        host word written by an asynchronous copy: only valid once that forward has completed)."""
+        return None if self._pinned is None else int(self._pinned[0])
 
     def _capacity_for(self, binning, P, W, H, R):
         if binning.numel() == 0:
@@ -233,7 +243,9 @@ class RasterBackend:
 
         if device.type == "cuda":
             # one pinned counter per device AND stream: two forwards in flight on different streams must not share it
-            pkey = (device.index, torch.cuda.current_stream(device).cuda_stream)
+            # (capture-safe mode: one per device, created before the capture - pinned memory cannot be allocated inside)
+            pkey = (device.index, "static" if self.static_capacity is not None else
+                    torch.cuda.current_stream(device).cuda_stream)
             nr_host = self._pinned_by_device.get(pkey)
             if nr_host is None:
                 nr_host = self._pinned_by_device[pkey] = torch.empty((1,), dtype=torch.int32).pin_memory()
@@ -241,6 +253,13 @@ class RasterBackend:
             cur = torch.cuda.current_stream(device)
             self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(),
                           nr_host.data_ptr(), stream)
+            if self.static_capacity is not None:
+                cap = int(self.static_capacity)
+                _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
+                binning = torch.empty((bb,), **u8)
+                self._remember_capacity(binning, cap)
+                render(self._scratch(geom, img, binning, cap))
+                return (cap, out_color, radii, geom, binning, img, out_invdepth) + tail
             cap = self._capacity_hint if self.optimistic else 0
             if cap > 0:
                 # Optimistic path: the reference blocks the host on a D2H copy of num_rendered before it can

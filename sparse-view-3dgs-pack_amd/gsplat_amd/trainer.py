@@ -123,13 +123,34 @@ class FlatAdam:
                       self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
                       self.betas[0], self.betas[1], self.eps, self.t, stream)
 
-    def fused_request(self, skip=()):
+    ROWS = ("xyz", "features", "opacity", "scaling", "rotation")
+    LR_CLASSES = (("xyz", 0), ("f_dc", 1), ("f_rest", 1), ("opacity", 2), ("scaling", 3), ("rotation", 4))
+
+    def step_coefficients(self, skip=()):
+        """The 11 step-dependent constants of gs_backward_step for the CURRENT counters (call after begin_step):
+        lr / (1 - beta1^t) per learning-rate class, 1 / sqrt(1 - beta2^t) per row - in the float arithmetic of
+        gs_adam_step (double, rounded once; the product lr * 1/(1 - beta1^t) in float)."""
+        import numpy as np
+        t = [self.seg_steps[name] if self.seg_steps[name] > 0 else self.t for name in self.ROWS]
+        t = [max(x, 1) for x in t]
+        b1, b2 = (float(np.float32(b)) for b in self.betas)  # the C ABI takes the betas as float
+        out = np.zeros(11, dtype=np.float32)
+        for c, (name, row) in enumerate(self.LR_CLASSES):
+            out[c] = np.float32(self.lr[name]) * np.float32(1.0 / (1.0 - b1 ** t[row]))
+        for k in range(5):
+            out[6 + k] = np.float32(1.0 / math.sqrt(1.0 - b2 ** t[k]))
+        return out
+
+    def fused_request(self, skip=(), coef_dev=None):
         """The GsStepState of ONE optimizer step (counters advanced as step() would) for gs_backward_step: raw parameter
-        rows, both moment buffers, per-row step counts (0 = skipped), learning rates, view statistics."""
+        rows, both moment buffers, per-row step counts (0 = skipped), learning rates, view statistics.
+        coef_dev: device tensor of 11 floats to read the step-dependent constants from (graph replay)."""
         from .capi import GsStepState
         m = self.model
         self.begin_step(skip)
         st = GsStepState()
+        if coef_dev is not None:
+            st.coef_dev = coef_dev.data_ptr()
         p, ea, eas = self.field_views(m.flat), self.field_views(self.exp_avg), self.field_views(self.exp_avg_sq)
         names = ("xyz", "features", "opacity", "scaling", "rotation")
         for k, name in enumerate(names):
@@ -747,7 +768,7 @@ class Trainer:
         backend = getattr(backend, "backend", None)
         fused_step = self._fused_step_ok(backend, optimizer_step)
         if fused_step:
-            backend.fused_step = m.optimizer.fused_request(skip)
+            backend.fused_step = m.optimizer.fused_request(skip, coef_dev=getattr(self, "_coef_dev", None))
             rows = getattr(self, "rows_override", None)  # parity tests: blend sums to use instead of stage 1
             if rows is not None:
                 backend.fused_step.rows_override = rows.data_ptr()
@@ -763,10 +784,16 @@ class Trainer:
             loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
         loss.backward()
         radii = pkg["radii"]
-        with torch.no_grad():
-            m.collect_grads()
-            m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
-            self.exchange_and_step(optimizer_step, skip)
+        if fused_step:
+            # gs_backward_step has already applied the activation backward, the view statistics and Adam
+            if backend.fused_step is not None:
+                backend.fused_step = None
+                raise RuntimeError("fused train step armed but the rasterizer backward did not run")
+        else:
+            with torch.no_grad():
+                m.collect_grads()
+                m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
+                self.exchange_and_step(optimizer_step, skip)
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
 
@@ -936,3 +963,154 @@ class TrainerNIR(Trainer):
                 m.nir_gain_optimizer.step()
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# hipGraph replay of the steady-state single-GPU step
+# ----------------------------------------------------------------------------------------------------------------
+class GraphedStep:
+    """Captures ONE train step of a Trainer (forward, fused criterion, gs_backward_step) into a hipGraph and replays it:
+    ~45 kernel launches, their Python glue and the forward's host wait become one graph launch.  What changes from step
+    to step travels through device buffers the captured kernels read: the camera (matrices, centre), its ground truth
+    and patch mask are copied into static tensors, Adam's step-dependent constants into `coef` (GsStepState.coef_dev).
+    Everything frozen at capture is checked before a replay (image size, field of view, active SH degree, number of
+    Gaussians, skipped rows); when it no longer holds - or when a view needs more binning capacity than was captured
+    (the step kernel then does nothing, see gs_backward_step) - the step runs eagerly and the graph is re-captured.
+    Results are those of the eager fused step: same kernels, same arguments."""
+
+    def __init__(self, trainer, capacity_margin=1.5, warmup=3):
+        self.tr = trainer
+        self.capacity_margin = capacity_margin
+        self.warmup = warmup
+        self.graph = None
+        self.key = None
+        self.replays = self.eager_steps = self.captures = 0
+
+    # -- what the capture froze
+    def _key(self, cam):
+        m = self.tr.model
+        return (m.P, m.active_sh_degree, int(cam.image_height), int(cam.image_width), float(cam.FoVx), float(cam.FoVy))
+
+    def _backend(self):
+        tr = self.tr
+        be = getattr(getattr(getattr(tr.Rasterizer, "_fn", None), "_impl", None), "backend", None)
+        return be
+
+    def _load(self, ci):
+        tr = self.tr
+        cam = tr.cameras[ci]
+        self.s_view.copy_(cam.world_view_transform, non_blocking=True)
+        self.s_proj.copy_(cam.full_proj_transform, non_blocking=True)
+        self.s_center.copy_(cam.camera_center, non_blocking=True)
+        self.s_gt.copy_(tr.gts[ci], non_blocking=True)
+        if self.s_mask is not None:
+            mk = tr.masks[ci]
+            self.s_mask.copy_(mk, non_blocking=True)
+            self.s_mask._gs_n_sel.copy_(mk._gs_n_sel, non_blocking=True)
+
+    def _capture(self, ci):
+        import numpy as np
+        tr, be = self.tr, self._backend()
+        m = tr.model
+        cam = tr.cameras[ci]
+        dev = m.flat.device
+        # static inputs
+        self.s_view = cam.world_view_transform.clone()
+        self.s_proj = cam.full_proj_transform.clone()
+        self.s_center = cam.camera_center.clone()
+        self.s_gt = tr.gts[ci].clone()
+        self.s_mask = None
+        if tr.masks is not None and tr.masks[ci] is not None:
+            self.s_mask = tr.masks[ci].clone()
+            self.s_mask._gs_n_sel = tr.masks[ci]._gs_n_sel.clone()
+        self.s_cam = cam._replace(world_view_transform=self.s_view, full_proj_transform=self.s_proj,
+                                  camera_center=self.s_center)
+        self.coef = torch.zeros((11,), dtype=torch.float32, device=dev)
+        self.coef_host = torch.zeros((11,), dtype=torch.float32).pin_memory()
+        # binning capacity: the largest view seen so far with head-room
+        self.capacity = int(max(be._capacity_hint, 4096) * self.capacity_margin)
+        be._pinned_by_device.setdefault((dev.index, "static"), torch.empty((1,), dtype=torch.int32).pin_memory())
+        saved = (tr.cameras, tr.gts, tr.masks)
+
+        def one_step():
+            be.static_capacity = self.capacity
+            tr.cameras, tr.gts, tr.masks = [self.s_cam], [self.s_gt], (None if self.s_mask is None else [self.s_mask])
+            tr._coef_dev = self.coef
+            try:
+                return tr._step_camera(0, True, ())
+            finally:
+                be.static_capacity = None
+                tr.cameras, tr.gts, tr.masks = saved
+                tr._coef_dev = None
+
+        self._coef_event = None
+        crit = tr.criterion
+        if getattr(crit, "dwt_running_mean", None) is None and hasattr(crit, "dwt_running_mean"):
+            crit.dwt_running_mean = torch.ones((1,), dtype=torch.float32, device=dev)
+        self.s_rm_backup = None if getattr(crit, "dwt_running_mean", None) is None else crit.dwt_running_mean.clone()
+        # warm-up on a side stream (allocator and library state settle), then capture; every one of these runs is a
+        # real train step of camera `ci`: counters and parameters advance as in eager mode
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self._load(ci)
+                self._coef_for_next()  # (_step_camera's fused_request advances the counters itself)
+                one_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        self._load(ci)
+        self._coef_for_next()
+        with torch.cuda.graph(self.graph):
+            self.s_loss = one_step()
+        self.key = self._key(cam)
+        self.captures += 1
+        # the capture itself launched nothing: replay once so that this call IS a step
+        self.graph.replay()
+        return self.s_loss
+
+    def _coef_for_next(self):
+        """Constants of the step the NEXT launch performs: the launch (eager inside one_step, or a replay) is step t + 1."""
+        opt = self.tr.model.optimizer
+        saved_t, saved_seg = opt.t, dict(opt.seg_steps)
+        opt.begin_step(())
+        coefs = torch.from_numpy(opt.step_coefficients(()))
+        opt.t, opt.seg_steps = saved_t, saved_seg
+        if self._coef_event is not None:
+            self._coef_event.synchronize()  # the previous upload has read the pinned staging buffer
+        self.coef_host.copy_(coefs)
+        self.coef.copy_(self.coef_host, non_blocking=True)
+        self._coef_event = torch.cuda.Event()
+        self._coef_event.record(torch.cuda.current_stream(self.coef.device))
+
+    def step(self, k):
+        tr = self.tr
+        ci = tr.camera_index(k)
+        cam = tr.cameras[ci]
+        be = self._backend()
+        if self.graph is None or self.key != self._key(cam):
+            return self._capture(ci)
+        self._load(ci)
+        self._coef_for_next()
+        crit = tr.criterion
+        if self.s_rm_backup is not None:
+            self.s_rm_backup.copy_(crit.dwt_running_mean)
+        self.graph.replay()
+        tr.model.optimizer.begin_step(())
+        self.replays += 1
+        # one host wait per step (the eager path has one too, inside the forward): did the view fit the capacity?
+        torch.cuda.current_stream(tr.model.flat.device).synchronize()
+        if be.last_num_rendered() > self.capacity:
+            # the captured step was a no-op on the device (gs_backward_step skips on overflow): undo the counter,
+            # run the step eagerly (which also raises the capacity hint) and capture again next time
+            opt = tr.model.optimizer
+            opt.t -= 1
+            for name in opt.seg_steps:
+                opt.seg_steps[name] -= 1
+            if self.s_rm_backup is not None:  # the criterion's running mean saw a loss of an un-rendered image
+                crit.dwt_running_mean.copy_(self.s_rm_backup)
+            self.graph, self.key = None, None
+            self.eager_steps += 1
+            return tr._step_camera(ci, True, ())
+        return self.s_loss

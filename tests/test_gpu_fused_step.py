@@ -81,3 +81,49 @@ def test_fused_step_argument_errors(hip):
     hip.fused_step = st
     with pytest.raises(GsError):
         tr._step_camera(0, False, ())  # optimizer_step False -> the trainer does not re-arm; the stale request is used
+
+
+# ---- hipGraph replay of the step ----------------------------------------------------------------------------------
+def test_graphed_step_equals_the_eager_fused_step(hip):
+    """GraphedStep replays a captured fused step; with the blend sums pinned to one fixed tensor (rows_override: the
+    only run-dependent part of a step, float-atomic order, is then out of the picture) three warm-up steps, the capture
+    step and four replays over four cameras leave the very same bits as eight eager steps."""
+    from gsplat_amd.trainer import GraphedStep
+    a, b = make(hip, True), make(hip, True)
+    P = a.model.P
+    g = torch.Generator().manual_seed(11)
+    rows = torch.zeros((P, 16))
+    rows[:, :9] = torch.randn((P, 9), generator=g) * 1e-3
+    rows = rows.cuda()
+    a.rows_override = b.rows_override = rows
+    gs = GraphedStep(b)
+    la, lb = [], []
+    for k in range(8):
+        la.append(float(a.step(k)))
+        lb.append(float(gs.step(k)))
+    torch.cuda.synchronize()
+    assert gs.captures == 1 and gs.replays >= 4 and gs.eager_steps == 0
+    sa, sb = state(a), state(b)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), (k, float((sa[k] - sb[k]).abs().max()))
+    assert a.model.optimizer.t == b.model.optimizer.t == 8
+    assert la == lb  # the forward and the criterion are deterministic
+
+
+def test_graphed_step_trains_and_survives_a_capacity_overflow(hip):
+    from gsplat_amd.trainer import GraphedStep
+    a, b = make(hip, True), make(hip, True)
+    gs = GraphedStep(b)
+    la = [float(a.step(k)) for k in range(12)]
+    lb = [float(gs.step(k)) for k in range(12)]
+    assert gs.replays > 0 and lb[-1] < lb[0]
+    assert max(abs(x - y) for x, y in zip(la, lb)) <= 2e-4 * max(la)
+    # a capacity far below what the views need: every replay overflows, is recognised as a no-op and repeated eagerly
+    c = make(hip, True)
+    gc = GraphedStep(c, capacity_margin=0.2)
+    lc = [float(gc.step(k)) for k in range(12)]
+    assert gc.eager_steps > 0
+    assert c.model.optimizer.t == 12
+    assert max(abs(x - y) for x, y in zip(la, lc)) <= 2e-4 * max(la)
+    d = (a.model.flat - c.model.flat).double()
+    assert float(d.pow(2).mean().sqrt()) <= 1e-4 * float(a.model.flat.double().pow(2).mean().sqrt())
