@@ -283,13 +283,13 @@ def main():
             api.call("profile_reset")
             api.call("profile_only", names.index(dom_stage))
             api.call("profile_enable", 1)
-    if graphed is not None:
-        # capture (three warm-up steps on a side stream + the captured one) and one replay per camera of a full cycle
-        # so that nothing is captured or re-captured inside the timed region
-        for _ in range(2):
-            run_step(k)
-            k += 1
-        barrier()
+    # steady state = every camera has been visited before (sparse-view training revisits its few cameras all the time):
+    # one more untimed cycle over the camera set, which also fills the forward's per-camera tile-order hints; in graph
+    # mode the first of these steps captures the graph (three warm-up steps on a side stream + the captured one)
+    for _ in range(len(cams) // world + 2):
+        run_step(k)
+        k += 1
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step(k)

@@ -111,23 +111,58 @@ GS_DEV void adam_update(float& p, float g, float& m, float& v, float lr_bc1, flo
   const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
   p = p - lr_bc1 * (m / denom);
 }
-// rows of `n` consecutive floats per Gaussian (any 4-byte alignment: after a densification a row's segment of the flat
-// buffer need not start on 16 bytes)
-template <int n>
-GS_DEV void adam_row(float* p, float* m, float* v, int idx, const float* g, float lr_bc1, float inv_sqrt_bc2, float b1,
-                     float b2, float eps) {
+// Adam over the workgroup's contiguous piece of one parameter row array: `cnt` Gaussians x N floats starting at element
+// `first * N` of p / m / v, gradients from the LDS image s_g[cnt * N] (same element order).  One float4 per thread and
+// iteration when the piece starts on 16 bytes (always when P is a multiple of 4; after a densification a row's segment
+// of the flat buffer may start anywhere), else element-wise.  LR_SPLIT > 0: elements with (index % 48) < LR_SPLIT take
+// lr_a, the others lr_b (the SH block: 3 DC floats at feature_lr, 45 at feature_lr / 20).
+template <int N, int LR_SPLIT, typename G>
+__device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int first,
+                                           int cnt, const G& grad, float lr_a, float lr_b, float isb, float b1, float b2,
+                                           float eps) {
+  float* pf = p + (size_t)first * N;
+  float* mf = m + (size_t)first * N;
+  float* vf = v + (size_t)first * N;
+  const int nfl = cnt * N;
+  const bool vec = (((((uintptr_t)pf) | ((uintptr_t)mf) | ((uintptr_t)vf)) & 15) == 0) && (nfl % 4 == 0);
+  if (vec) {
+    for (int j = 4 * threadIdx.x; j < nfl; j += 4 * GS_BLOCK) {
+      float4 p4 = *reinterpret_cast<const float4*>(pf + j), m4 = *reinterpret_cast<const float4*>(mf + j),
+             v4 = *reinterpret_cast<const float4*>(vf + j);
+      float* pe = reinterpret_cast<float*>(&p4);
+      float* me = reinterpret_cast<float*>(&m4);
+      float* ve = reinterpret_cast<float*>(&v4);
 #pragma unroll
-  for (int k = 0; k < n; k++) {
-    float pe = p[n * (size_t)idx + k], me = m[n * (size_t)idx + k], ve = v[n * (size_t)idx + k];
-    adam_update(pe, g[k], me, ve, lr_bc1, inv_sqrt_bc2, b1, b2, eps);
-    p[n * (size_t)idx + k] = pe;
-    m[n * (size_t)idx + k] = me;
-    v[n * (size_t)idx + k] = ve;
+      for (int e = 0; e < 4; e++) {
+        const float lr = (LR_SPLIT > 0 && ((j + e) % 48) >= LR_SPLIT) ? lr_b : lr_a;
+        adam_update(pe[e], grad(j + e), me[e], ve[e], lr, isb, b1, b2, eps);
+      }
+      *reinterpret_cast<float4*>(pf + j) = p4;
+      *reinterpret_cast<float4*>(mf + j) = m4;
+      *reinterpret_cast<float4*>(vf + j) = v4;
+    }
+  } else {
+    for (int j = threadIdx.x; j < nfl; j += GS_BLOCK) {
+      float pe = pf[j], me = mf[j], ve = vf[j];
+      const float lr = (LR_SPLIT > 0 && (j % 48) >= LR_SPLIT) ? lr_b : lr_a;
+      adam_update(pe, grad(j), me, ve, lr, isb, b1, b2, eps);
+      pf[j] = pe;
+      mf[j] = me;
+      vf[j] = ve;
+    }
   }
 }
 
+// LDS image of the 11 non-SH gradients of the workgroup's Gaussians, row arrays back to back in their own element order
+#define SG_XYZ 0
+#define SG_OPAC (3 * GS_BLOCK)
+#define SG_SCALE (4 * GS_BLOCK)
+#define SG_ROT (7 * GS_BLOCK)
+#define SG_TOTAL (11 * GS_BLOCK)
+
 __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(PreprocessBwdArgs a, StepArgs sa) {
   __shared__ float s_sh[GS_BLOCK * SH_LDS_ROW];
+  __shared__ float s_g[SG_TOTAL];
   const GsStepState& st = sa.st;
   // the forward ran out of binning capacity (possible only when the caller did not re-run it: a replayed graph): the
   // image was not rendered, so nothing may be updated - the host sees the flag and repeats the step eagerly
@@ -139,7 +174,8 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
 #pragma unroll
     for (int k = 0; k < 5; k++) sa.inv_sqrt_bc2[k] = st.coef_dev[6 + k];
   }
-  const int idx_raw = blockIdx.x * GS_BLOCK + threadIdx.x;
+  const int tid = threadIdx.x;
+  const int idx_raw = blockIdx.x * GS_BLOCK + tid;
   const bool in_range = idx_raw < a.P;
   const int idx = in_range ? idx_raw : a.P - 1;
   const int radius = a.radii[idx];
@@ -147,98 +183,78 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   const float b1 = st.beta1, b2 = st.beta2, eps = st.eps;
 
   GeomBack gb = {};
-  ShSink dsh{s_sh + threadIdx.x * SH_LDS_ROW, true};
+  ShSink dsh{s_sh + tid * SH_LDS_ROW, true};
 #pragma unroll
   for (int k = 0; k < SH_LDS_ROW; k++) dsh.p[k] = 0.f;
   if (visible) geometry_backward(a, idx, gb);
 
-  if (in_range) {
-    // ---- view statistics (train.py:266-268, gaussian_model.py:471-473)
-    if (visible && st.max_radii2D) {
-      st.max_radii2D[idx] = fmaxf(st.max_radii2D[idx], (float)radius);
-      st.xyz_gradient_accum[idx] += sqrtf(gb.dmean2D_x * gb.dmean2D_x + gb.dmean2D_y * gb.dmean2D_y);
-      st.denom[idx] += 1.0f;
-    }
-    // ---- opacity = sigmoid(raw): grad * s * (1 - s)
-    if (st.step[2] > 0) {
-      const float sg = 1.0f / (1.0f + expf(-st.opacity[idx]));
-      const float g = gb.dop * (1.0f - sg) * sg;
-      adam_row<1>(st.opacity, st.m[2], st.v[2], idx, &g, sa.lr_bc1[3], sa.inv_sqrt_bc2[2], b1, b2, eps);
-    }
-    // ---- scaling = exp(raw): grad * result
-    if (st.step[3] > 0) {
-      float g[3];
-      g[0] = gb.dscale.x * expf(st.scaling[3 * (size_t)idx]);
-      g[1] = gb.dscale.y * expf(st.scaling[3 * (size_t)idx + 1]);
-      g[2] = gb.dscale.z * expf(st.scaling[3 * (size_t)idx + 2]);
-      adam_row<3>(st.scaling, st.m[3], st.v[3], idx, g, sa.lr_bc1[4], sa.inv_sqrt_bc2[3], b1, b2, eps);
-    }
-    // ---- rotation = q / max(|q|, 1e-12): dq = (g - v (v . g)) / |q|
-    if (st.step[4] > 0) {
-      const float* qr = st.rotation + 4 * (size_t)idx;
-      const float4 q = make_float4(qr[0], qr[1], qr[2], qr[3]);
-      const float norm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-      float g[4];
-      if (norm > 1e-12f) {
-        const float inv = 1.0f / norm;
-        const float vx = q.x * inv, vy = q.y * inv, vz = q.z * inv, vw = q.w * inv;
-        const float dot = vx * gb.dq[0] + vy * gb.dq[1] + vz * gb.dq[2] + vw * gb.dq[3];
-        g[0] = (gb.dq[0] - vx * dot) * inv;
-        g[1] = (gb.dq[1] - vy * dot) * inv;
-        g[2] = (gb.dq[2] - vz * dot) * inv;
-        g[3] = (gb.dq[3] - vw * dot) * inv;
-      } else {
-        g[0] = gb.dq[0] / 1e-12f; g[1] = gb.dq[1] / 1e-12f; g[2] = gb.dq[2] / 1e-12f; g[3] = gb.dq[3] / 1e-12f;
-      }
-      adam_row<4>(st.rotation, st.m[4], st.v[4], idx, g, sa.lr_bc1[5], sa.inv_sqrt_bc2[4], b1, b2, eps);
-    }
+  // ---- view statistics (train.py:266-268, gaussian_model.py:471-473)
+  if (in_range && visible && st.max_radii2D) {
+    st.max_radii2D[idx] = fmaxf(st.max_radii2D[idx], (float)radius);
+    st.xyz_gradient_accum[idx] += sqrtf(gb.dmean2D_x * gb.dmean2D_x + gb.dmean2D_y * gb.dmean2D_y);
+    st.denom[idx] += 1.0f;
   }
-
+  // ---- activation backward of this Gaussian's rows into the LDS gradient image
+  {
+    // opacity = sigmoid(raw): grad * s * (1 - s)
+    const float sg = 1.0f / (1.0f + expf(-st.opacity[idx]));
+    s_g[SG_OPAC + tid] = gb.dop * (1.0f - sg) * sg;
+    // scaling = exp(raw): grad * result
+    s_g[SG_SCALE + 3 * tid] = gb.dscale.x * expf(st.scaling[3 * (size_t)idx]);
+    s_g[SG_SCALE + 3 * tid + 1] = gb.dscale.y * expf(st.scaling[3 * (size_t)idx + 1]);
+    s_g[SG_SCALE + 3 * tid + 2] = gb.dscale.z * expf(st.scaling[3 * (size_t)idx + 2]);
+    // rotation = q / max(|q|, 1e-12): dq = (g - v (v . g)) / |q|
+    const float* qr = st.rotation + 4 * (size_t)idx;
+    const float4 q = make_float4(qr[0], qr[1], qr[2], qr[3]);
+    const float norm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    float g[4];
+    if (norm > 1e-12f) {
+      const float inv = 1.0f / norm;
+      const float vx = q.x * inv, vy = q.y * inv, vz = q.z * inv, vw = q.w * inv;
+      const float dot = vx * gb.dq[0] + vy * gb.dq[1] + vz * gb.dq[2] + vw * gb.dq[3];
+      g[0] = (gb.dq[0] - vx * dot) * inv;
+      g[1] = (gb.dq[1] - vy * dot) * inv;
+      g[2] = (gb.dq[2] - vz * dot) * inv;
+      g[3] = (gb.dq[3] - vw * dot) * inv;
+    } else {
+      g[0] = gb.dq[0] / 1e-12f; g[1] = gb.dq[1] / 1e-12f; g[2] = gb.dq[2] / 1e-12f; g[3] = gb.dq[3] / 1e-12f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_g[SG_ROT + 4 * tid + k] = g[k];
+  }
   // ---- SH half: basis values and colour gradient to the LDS row; the view-direction part completes dL_dmean
   if (visible) gb.dmean = gb.dmean + sh_backward_row(a, idx, gb.dcolor, dsh);
-  if (in_range && st.step[0] > 0) {
-    const float g[3] = {gb.dmean.x, gb.dmean.y, gb.dmean.z};
-    adam_row<3>(st.xyz, st.m[0], st.v[0], idx, g, sa.lr_bc1[0], sa.inv_sqrt_bc2[0], b1, b2, eps);
-  }
-  __syncthreads();  // every thread of the workgroup has read its SH coefficients and positions: rows may now change
-  if (st.step[1] > 0) {
-    const int first = blockIdx.x * GS_BLOCK;
-    const int nfl = min(GS_BLOCK, a.P - first) * 48;
-    float* pf = st.features + (size_t)first * 48;
-    float* mf = st.m[1] + (size_t)first * 48;
-    float* vf = st.v[1] + (size_t)first * 48;
-    const float lr_dc = sa.lr_bc1[1], lr_rest = sa.lr_bc1[2], isb = sa.inv_sqrt_bc2[1];
-    const bool vec = ((((uintptr_t)pf) | ((uintptr_t)mf) | ((uintptr_t)vf)) & 15) == 0;
-    for (int j = 4 * threadIdx.x; j < nfl; j += 4 * GS_BLOCK) {
-      const int r = j / 48, c = j - r * 48;
-      const float* src = s_sh + r * SH_LDS_ROW;
-      float pe[4], me[4], ve[4];
-      if (vec) {
-        const float4 p4 = *reinterpret_cast<const float4*>(pf + j), m4 = *reinterpret_cast<const float4*>(mf + j),
-                     v4 = *reinterpret_cast<const float4*>(vf + j);
-        pe[0] = p4.x; pe[1] = p4.y; pe[2] = p4.z; pe[3] = p4.w;
-        me[0] = m4.x; me[1] = m4.y; me[2] = m4.z; me[3] = m4.w;
-        ve[0] = v4.x; ve[1] = v4.y; ve[2] = v4.z; ve[3] = v4.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) { pe[e] = pf[j + e]; me[e] = mf[j + e]; ve[e] = vf[j + e]; }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int k = (c + e) / 3, ch = (c + e) - 3 * k;
-        const float g = src[k] * src[16 + ch];  // dL_dsh[r][k][ch] = basis_k * dL_dRGB[ch]
-        adam_update(pe[e], g, me[e], ve[e], (c + e) < 3 ? lr_dc : lr_rest, isb, b1, b2, eps);
-      }
-      if (vec) {
-        *reinterpret_cast<float4*>(pf + j) = make_float4(pe[0], pe[1], pe[2], pe[3]);
-        *reinterpret_cast<float4*>(mf + j) = make_float4(me[0], me[1], me[2], me[3]);
-        *reinterpret_cast<float4*>(vf + j) = make_float4(ve[0], ve[1], ve[2], ve[3]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) { pf[j + e] = pe[e]; mf[j + e] = me[e]; vf[j + e] = ve[e]; }
-      }
+  s_g[SG_XYZ + 3 * tid] = gb.dmean.x;
+  s_g[SG_XYZ + 3 * tid + 1] = gb.dmean.y;
+  s_g[SG_XYZ + 3 * tid + 2] = gb.dmean.z;
+  __syncthreads();  // every thread of the workgroup has read its parameters: the rows may now change
+
+  // ---- Adam over the workgroup's contiguous pieces of the five row arrays: coalesced float4 streams of p, m, v
+  const int first = blockIdx.x * GS_BLOCK;
+  const int cnt = min(GS_BLOCK, a.P - first);
+  struct Lds {
+    const float* p;
+    __device__ __forceinline__ float operator()(int j) const { return p[j]; }
+  };
+  struct ShGrad {  // dL_dsh[r][k][ch] = basis_k * dL_dRGB[ch] from the 19-word rows
+    const float* s;
+    __device__ __forceinline__ float operator()(int j) const {
+      const int r = j / 48, c = j - r * 48, k = c / 3, ch = c - 3 * k;
+      const float* src = s + r * SH_LDS_ROW;
+      return src[k] * src[16 + ch];
     }
-  }
+  };
+  if (st.step[0] > 0)
+    adam_block<3, 0>(st.xyz, st.m[0], st.v[0], first, cnt, Lds{s_g + SG_XYZ}, sa.lr_bc1[0], 0.f, sa.inv_sqrt_bc2[0], b1, b2, eps);
+  if (st.step[2] > 0)
+    adam_block<1, 0>(st.opacity, st.m[2], st.v[2], first, cnt, Lds{s_g + SG_OPAC}, sa.lr_bc1[3], 0.f, sa.inv_sqrt_bc2[2], b1, b2, eps);
+  if (st.step[3] > 0)
+    adam_block<3, 0>(st.scaling, st.m[3], st.v[3], first, cnt, Lds{s_g + SG_SCALE}, sa.lr_bc1[4], 0.f, sa.inv_sqrt_bc2[3], b1, b2, eps);
+  if (st.step[4] > 0)
+    adam_block<4, 0>(st.rotation, st.m[4], st.v[4], first, cnt, Lds{s_g + SG_ROT}, sa.lr_bc1[5], 0.f, sa.inv_sqrt_bc2[4], b1, b2, eps);
+  if (st.step[1] > 0)
+    adam_block<48, 3>(st.features, st.m[1], st.v[1], first, cnt, ShGrad{s_sh}, sa.lr_bc1[1], sa.lr_bc1[2], sa.inv_sqrt_bc2[1], b1,
+                      b2, eps);
 }
 
 int launch_preprocess_bwd_step(const PreprocessBwdArgs& a, const StepArgs& sa, hipStream_t s) {

@@ -165,15 +165,20 @@ class RasterBackend:
         self.api.call("scratch_bytes", P, W, H, R, out, C.byref(ws))
         return out[0], out[1], out[2], ws.value
 
-    def _order_hint(self, device, W, H):
-        """Scheduling hint for the forward blend (GsScratch.tile_order_hint): the tile order of the previous view of the
-        same image size.  GS_FWD_ORDER_HINT=0 switches it off."""
+    def _order_hint(self, device, W, H, viewmatrix):
+        """Scheduling hint for the forward blend (GsScratch.tile_order_hint): the tile order measured on the previous
+        visit of the SAME camera (a hint from another camera is worthless: 0.203 ms either way at C3; from the same
+        camera 0.204 -> 0.164 ms, tests/tools/fwd_order_probe.py).  Cameras are told apart by the address of their view
+        matrix - training loops keep one tensor per camera.  GS_FWD_ORDER_HINT=0 switches it off.
+        -> ([buffer, valid], hint tensor or None)"""
         if not self.order_hint_on or device.type != "cuda":
             return None, None
-        key = (device.index, W, H)
-        n = ((((W + 15) // 16) * ((H + 15) // 16) + 7) // 8) * 8
+        key = (device.index, W, H, viewmatrix.data_ptr())
         buf = self._order_bufs.get(key)
         if buf is None:
+            if len(self._order_bufs) >= 256:  # forget the oldest camera
+                self._order_bufs.pop(next(iter(self._order_bufs)))
+            n = ((((W + 15) // 16) * ((H + 15) // 16) + 7) // 8) * 8
             buf = self._order_bufs[key] = [torch.empty((n,), dtype=torch.int32, device=device), False]
         return buf, (buf[0] if buf[1] else None)
 
@@ -219,7 +224,7 @@ class RasterBackend:
             e = torch.empty((0,), **u8)
             return (0, out_color, radii, e, e.clone(), e.clone(), out_invdepth) + tail
 
-        order_buf, order_hint = self._order_hint(device, W, H)
+        order_buf, order_hint = self._order_hint(device, W, H, viewmatrix)
 
         def render(scratch):
             if order_hint is not None:

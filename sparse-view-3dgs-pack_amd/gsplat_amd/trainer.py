@@ -984,6 +984,7 @@ class GraphedStep:
         self.warmup = warmup
         self.graph = None
         self.key = None
+        self.cam_orders = {}
         self.replays = self.eager_steps = self.captures = 0
 
     # -- what the capture froze
@@ -1007,6 +1008,23 @@ class GraphedStep:
             mk = tr.masks[ci]
             self.s_mask.copy_(mk, non_blocking=True)
             self.s_mask._gs_n_sel.copy_(mk._gs_n_sel, non_blocking=True)
+        # the forward's per-camera tile-order hint (RasterBackend._order_hint keys it by the view matrix's address, which
+        # is the static tensor's here): bring in what this camera's last visit measured
+        ob = self._order_buf()
+        if ob is not None and ci in self.cam_orders:
+            ob[0].copy_(self.cam_orders[ci], non_blocking=True)
+
+    def _order_buf(self):
+        be = self._backend()
+        cam = self.s_cam
+        return be._order_bufs.get((self.s_view.device.index, int(cam.image_width), int(cam.image_height), self.s_view.data_ptr()))
+
+    def _save_order(self, ci):
+        ob = self._order_buf()
+        if ob is not None and ob[1]:
+            if ci not in self.cam_orders:
+                self.cam_orders[ci] = torch.empty_like(ob[0])
+            self.cam_orders[ci].copy_(ob[0], non_blocking=True)
 
     def _capture(self, ci):
         import numpy as np
@@ -1068,6 +1086,7 @@ class GraphedStep:
         self.captures += 1
         # the capture itself launched nothing: replay once so that this call IS a step
         self.graph.replay()
+        self._save_order(ci)
         return self.s_loss
 
     def _coef_for_next(self):
@@ -1097,6 +1116,7 @@ class GraphedStep:
         if self.s_rm_backup is not None:
             self.s_rm_backup.copy_(crit.dwt_running_mean)
         self.graph.replay()
+        self._save_order(ci)
         tr.model.optimizer.begin_step(())
         self.replays += 1
         # one host wait per step (the eager path has one too, inside the forward): did the view fit the capacity?
