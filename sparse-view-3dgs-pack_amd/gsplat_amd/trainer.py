@@ -231,6 +231,8 @@ class GaussianModelLite:
         self.fields = FIELDS + ((NIR_FIELD,) if self.with_nir else ())
         self.width = sum(n for _, n in self.fields)
         self.nir_gain = None
+        self.exposure = None
+        self.exposure_optimizer = None
         self._allocate(P)
         with torch.no_grad():
             self.params["xyz"].copy_(scene["means3D"])
@@ -257,6 +259,17 @@ class GaussianModelLite:
         self.xyz_gradient_accum = torch.zeros((P, 1), device=device)
         self.denom = torch.zeros((P, 1), device=device)
         self.max_radii2D = torch.zeros((P,), device=device)
+
+    def enable_exposure(self, n_cameras):
+        """Per-camera exposure (LGDWT-GS/scene/gaussian_model.py:173-176,201: a [n_cams, 3, 4] parameter starting at
+        [I | 0] with its own Adam; rate from get_expon_lr_func(0.01, 0.001, delay_steps 0, delay_mult 0) over the
+        run, arguments/__init__.py:87-90, set by update_learning_rate).  Used by render(..., use_trained_exp=True)."""
+        eye = torch.eye(3, 4, device=self.device)[None].repeat(int(n_cameras), 1, 1)
+        self.exposure = torch.nn.Parameter(eye.requires_grad_(True))
+        self.exposure_optimizer = torch.optim.Adam([self.exposure])
+
+    def get_exposure(self, camera_index):
+        return self.exposure[camera_index]
 
     @staticmethod
     def _shapes(P):
@@ -483,6 +496,10 @@ class GaussianModelLite:
             self.optimizer.lr["xyz"] = lr
         else:
             self.optimizer.set_xyz_lr(lr)
+        if self.exposure_optimizer is not None:  # gaussian_model.py:215-217
+            elr = expon_lr(iteration, 0.01, 0.001, lr_delay_steps=0, lr_delay_mult=0.0, max_steps=max_steps)
+            for group in self.exposure_optimizer.param_groups:
+                group["lr"] = elr
         return lr
 
     # activations, gaussian_model.py:102-135
@@ -605,7 +622,7 @@ class _TorchAdamWithFeatureSplit:
 
 
 def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifier=1.0, antialiasing=False,
-           debug=False, filter_as_indices=True, clamp=True, fused=False):
+           debug=False, filter_as_indices=True, clamp=True, fused=False, use_trained_exp=False, camera_index=None):
     """= render() of LGDWT-GS/gaussian_renderer/__init__.py:18-128 (SH evaluated by the rasterizer, scale +
     rotation given, no exposure): returns {render, viewspace_points, visibility_filter, radii, depth}."""
     act = pc.fused_activations() if fused else None
@@ -630,6 +647,10 @@ def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifie
     rendered_image, radii, depth_image = rasterizer(
         means3D=pc.get_xyz, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None,
         opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=None)
+    if use_trained_exp:  # gaussian_renderer/__init__.py:112-115 (training only): 3x3 colour matrix + offset per camera
+        exposure = pc.get_exposure(camera_index)
+        rendered_image = torch.matmul(rendered_image.permute(1, 2, 0), exposure[:3, :3]).permute(2, 0, 1) + \
+            exposure[:3, 3, None, None]
     if clamp:  # gaussian_renderer/__init__.py:119; the fused criterion applies (and differentiates) it itself
         rendered_image = rendered_image.clamp(0, 1)
     return {"render": rendered_image, "viewspace_points": screenspace_points,
@@ -776,7 +797,7 @@ class Trainer:
             m.arm_grad_arena(backend)
         fused = getattr(self.criterion, "fused", False)
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
-                     clamp=not fused, fused=True)
+                     clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci)
         mask = None if self.masks is None else self.masks[ci]
         if fused:
             loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
@@ -794,6 +815,15 @@ class Trainer:
                 m.collect_grads()
                 m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
                 self.exchange_and_step(optimizer_step, skip)
+        if m.exposure_optimizer is not None:
+            # train.py:280-281: the exposure optimizer steps with the main one; a camera's row is only touched by the
+            # rank that rendered it, the others hold a zero gradient for it (N > 1: summed like every other gradient)
+            if m.exposure.grad is not None:
+                if self.world_size > 1:
+                    dist.all_reduce(m.exposure.grad, op=dist.ReduceOp.SUM)
+                if optimizer_step:
+                    m.exposure_optimizer.step()
+            m.exposure_optimizer.zero_grad(set_to_none=True)
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
         return loss.detach()
 
@@ -1108,6 +1138,9 @@ class GraphedStep:
         ci = tr.camera_index(k)
         cam = tr.cameras[ci]
         be = self._backend()
+        if tr.model.exposure is not None or not tr._fused_step_ok(be, True):
+            self.eager_steps += 1  # what the capture cannot hold (a torch optimizer for the exposure, N > 1, ...)
+            return tr._step_camera(ci, True, ())
         if self.graph is None or self.key != self._key(cam):
             return self._capture(ci)
         self._load(ci)

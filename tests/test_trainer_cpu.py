@@ -42,3 +42,30 @@ def test_render_contract_matches_reference_renderer(oracle):
     assert float(pkg["render"].min()) >= 0 and float(pkg["render"].max()) <= 1
     pkg["render"].sum().backward()
     assert pkg["viewspace_points"].grad is not None and pkg["viewspace_points"].grad.shape == (600, 3)
+
+
+def test_exposure_is_applied_and_optimised(oracle):
+    """render(..., use_trained_exp=True) = LGDWT-GS/gaussian_renderer/__init__.py:112-115: image -> image . E[:3,:3] + E[:3,3]
+    per camera, before the clamp; the [n_cams,3,4] parameter starts at the identity (so the first render is unchanged),
+    has its own Adam at the scheduled rate and only the rendered camera's row moves (train.py:280-281)."""
+    from gsplat_amd.trainer import render
+    tr = make_trainer(oracle, P=300, W=96, H=64)
+    m = tr.model
+    base = render(tr.cameras[1], m, tr.Rasterizer, tr.Settings, tr.bg)["render"].detach()
+    m.enable_exposure(len(tr.cameras))
+    same = render(tr.cameras[1], m, tr.Rasterizer, tr.Settings, tr.bg, use_trained_exp=True, camera_index=1)["render"]
+    assert torch.equal(same.detach(), base)
+    with torch.no_grad():
+        m.exposure[1, :3, :3] = torch.tensor([[0.5, 0.1, 0.0], [0.0, 0.8, 0.0], [0.2, 0.0, 1.1]])
+        m.exposure[1, :3, 3] = torch.tensor([0.01, 0.02, 0.03])
+    raw = render(tr.cameras[1], m, tr.Rasterizer, tr.Settings, tr.bg, clamp=False)["render"].detach()
+    got = render(tr.cameras[1], m, tr.Rasterizer, tr.Settings, tr.bg, use_trained_exp=True, camera_index=1,
+                 clamp=False)["render"].detach()
+    want = torch.einsum("chw,cd->dhw", raw, m.exposure[1, :3, :3].detach()) + m.exposure[1, :3, 3].detach()[:, None, None]
+    assert torch.allclose(got, want, atol=1e-6)
+    m.update_learning_rate(1)
+    assert abs(m.exposure_optimizer.param_groups[0]["lr"] - 0.01) < 1e-4
+    before = m.exposure.detach().clone()
+    tr.step(1)  # camera 1
+    moved = (m.exposure.detach() - before).abs().amax(dim=(1, 2))
+    assert float(moved[1]) > 0 and float(moved[0]) == 0 and float(moved[2]) == 0
