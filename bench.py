@@ -44,9 +44,13 @@ CONFIGS = {
     "c1": (10_000, 400, 400, False, False, "BASELINE configs[0]: 10k Gaussians, 400x400, DWT off"),
     "tiny": (2_000, 256, 160, True, True, "plumbing check"),
     # multispectral step (train_nir.py: L1 + SSIM on RGB and on the NIR image, no DWT terms): ONE fused 4-channel pass
-    "c5": (1_000_000, 1920, 1080, False, False, "BASELINE configs[4]: RGB+NIR 4-channel render, 1M Gaussians, 1080p"),
+    # as BASELINE.json words it: the 4-channel pass with the LGDWT criterion (global + patch DWT) on the RGB image
+    "c5": (1_000_000, 1920, 1080, True, True, "BASELINE configs[4]: RGB+NIR 4-channel render, 1M Gaussians, 1080p, "
+                                              "global+patch DWT on the RGB image"),
+    # the reference's train_nir.py as written: L1 + SSIM on RGB and NIR, no DWT terms
+    "c5_plain": (1_000_000, 1920, 1080, False, False, "RGB+NIR 4-channel render, 1M Gaussians, 1080p, train_nir.py's loss"),
 }
-NIR_CONFIGS = ("c5",)
+NIR_CONFIGS = ("c5", "c5_plain")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -94,8 +98,13 @@ def build_workload(cfg, device, rank, world, seed=0):
         g = torch.Generator().manual_seed(seed + 2)
         nirs = [None if x is None else (torch.round(torch.rand((1, H, W), generator=g) * 255.0) / 255.0).to(device) for x in gts]
         model = GaussianModelLite(scene, device, api=hip_api_(), with_nir=True)
-        tr = TrainerNIR(model, cams, gts, nirs, NirCriterion(LossOps(hip_api_())), dgr.GaussianRasterizationSettings, bg,
-                        rank=rank, world_size=world)
+        rgb_crit, masks = None, None
+        if dwt or patch:
+            rgb_crit = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch, fused=False)
+            if patch:
+                masks = [None if x is None else rgb_crit.elf_mask(x) for x in gts]
+        tr = TrainerNIR(model, cams, gts, nirs, NirCriterion(LossOps(hip_api_()), rgb_criterion=rgb_crit),
+                        dgr.GaussianRasterizationSettings, bg, rank=rank, world_size=world, masks=masks)
         return tr, scene, cams, gts
     model = GaussianModelLite(scene, device, api=hip_api_())
     crit = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch)
@@ -248,8 +257,12 @@ def main():
     # single GPU: the steady-state step is replayed from a hipGraph (gsplat_amd.trainer.GraphedStep: same kernels and
     # arguments as the eager step, one graph launch instead of ~45 kernel launches with their Python glue);
     # GS_BENCH_GRAPH=0 times the eager step.  The event timers need eager launches: stage passes run eagerly.
-    use_graph = world == 1 and args.config not in NIR_CONFIGS and os.environ.get("GS_BENCH_GRAPH", "1") != "0"
-    graphed = None
+    # GS_BENCH_GRAPH = auto (default): both forms are timed over a few untimed steps and the faster one runs the timed
+    # region (a replay saves the launches and their Python glue but waits for the device once per step, which costs
+    # more than it saves once a step is longer than ~1 ms: C1 0.75 -> 0.50 ms, C3 1.57 -> 1.63 ms); 0 / 1 force a form.
+    graph_mode = os.environ.get("GS_BENCH_GRAPH", "auto")
+    use_graph = world == 1 and args.config not in NIR_CONFIGS and graph_mode != "0"
+    graphed, graph_choice = None, None
     if use_graph:
         from gsplat_amd.trainer import GraphedStep
         graphed = GraphedStep(tr)
@@ -279,10 +292,6 @@ def main():
         if not dom_stage:
             timed_kernels = [n for n in prof if n in stage_bytes(1, 1, 1)]
             dom_stage = max(timed_kernels, key=lambda n: prof[n][0] / prof[n][1]) if timed_kernels else "render_bwd"
-        if graphed is None:
-            api.call("profile_reset")
-            api.call("profile_only", names.index(dom_stage))
-            api.call("profile_enable", 1)
     # steady state = every camera has been visited before (sparse-view training revisits its few cameras all the time):
     # one more untimed cycle over the camera set, which also fills the forward's per-camera tile-order hints; in graph
     # mode the first of these steps captures the graph (three warm-up steps on a side stream + the captured one)
@@ -290,6 +299,25 @@ def main():
         run_step(k)
         k += 1
     barrier()
+    if graphed is not None and graph_mode == "auto":
+        trial = {}
+        for form in ("graph", "eager"):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                (graphed.step if form == "graph" else tr.step)(k)
+                k += 1
+            barrier()
+            trial[form] = (time.perf_counter() - t1) / 8 * 1e3
+        graph_choice = {"graph_ms_per_step": trial["graph"], "eager_ms_per_step": trial["eager"],
+                        "chosen": "graph" if trial["graph"] < trial["eager"] else "eager"}
+        log("launch form: graph %.3f ms, eager %.3f ms per step -> %s" % (trial["graph"], trial["eager"], graph_choice["chosen"]))
+        if graph_choice["chosen"] == "eager":
+            graphed = None
+    if graphed is None and not args.no_stage_timers:  # an eager timed region carries the event pair of the dominant kernel
+        api.call("profile_reset")
+        api.call("profile_only", names.index(dom_stage))
+        api.call("profile_enable", 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step(k)
@@ -414,6 +442,7 @@ def main():
                             "pass of the same step before it (each event pair drains the pipeline for ~10 us); the timed "
                             "step includes the optimizer" % dom_stage),
             "launch": "hipGraph replay of the captured step" if graphed is not None else "eager",
+            "launch_trial": graph_choice,
         }
         if world == 1 and not args.no_cpu_baseline and args.config not in NIR_CONFIGS:
             ci = tr.camera_index(k - 1)

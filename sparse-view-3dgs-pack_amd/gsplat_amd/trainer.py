@@ -948,14 +948,21 @@ class NirCriterion:
     (mult-dwtgs/utils/loss_utils.py:93-144; the reference evaluates the single-channel SSIM on three identical
     copies, whose mean is the single-channel value)."""
 
-    def __init__(self, ops, lambda_dssim=0.2, nir_weight=1.0, nir_l1_weight=1.0, nir_ssim_weight=0.2):
+    def __init__(self, ops, lambda_dssim=0.2, nir_weight=1.0, nir_l1_weight=1.0, nir_ssim_weight=0.2, rgb_criterion=None):
+        """rgb_criterion: an LGDWTCriterion (fused=False) to use for the RGB term instead of train_nir.py's plain
+        L1 + SSIM - the multispectral step WITH the global / patch DWT terms of LGDWT-GS/train.py:128-202 (BASELINE
+        configs[4] names a patch-DWT loss; the reference's train_nir.py itself has none)."""
         self.ops, self.lambda_dssim, self.nir_weight = ops, lambda_dssim, nir_weight
         self.nir_l1_weight, self.nir_ssim_weight = nir_l1_weight, nir_ssim_weight
+        self.rgb_criterion = rgb_criterion
 
-    def __call__(self, image, gt_image, nir_pred, nir_gt):
+    def __call__(self, image, gt_image, nir_pred, nir_gt, mask=None):
         o = self.ops
-        l1 = o.l1_loss(image, gt_image)
-        rgb = (1.0 - self.lambda_dssim) * l1 + self.lambda_dssim * (1.0 - o.ssim(image, gt_image))
+        if self.rgb_criterion is not None:
+            rgb, _ = self.rgb_criterion(image, gt_image, mask=mask)
+        else:
+            l1 = o.l1_loss(image, gt_image)
+            rgb = (1.0 - self.lambda_dssim) * l1 + self.lambda_dssim * (1.0 - o.ssim(image, gt_image))
         nir = self.nir_l1_weight * o.l1_loss(nir_pred, nir_gt) + self.nir_ssim_weight * (1.0 - o.ssim(nir_pred, nir_gt))
         return rgb + self.nir_weight * nir, dict(rgb=rgb.detach(), nir=nir.detach())
 
@@ -975,7 +982,9 @@ class TrainerNIR(Trainer):
         if m.nir_gain.grad is not None:
             m.nir_gain.grad = None
         pkg = render_rgb_nir(self.cameras[ci], m, self.Settings, self.bg, two_pass_rasterizer=self.two_pass)
-        loss, parts = self.criterion(pkg["render"], self.gts[ci], pkg["nir"], self.nirs[ci])
+        mask = None if self.masks is None else self.masks[ci]
+        loss, parts = self.criterion(pkg["render"], self.gts[ci], pkg["nir"], self.nirs[ci], **(
+            {} if mask is None else {"mask": mask}))
         loss.backward()
         radii = pkg["radii"]
         with torch.no_grad():
@@ -1098,6 +1107,9 @@ class GraphedStep:
         self.s_rm_backup = None if getattr(crit, "dwt_running_mean", None) is None else crit.dwt_running_mean.clone()
         # warm-up on a side stream (allocator and library state settle), then capture; every one of these runs is a
         # real train step of camera `ci`: counters and parameters advance as in eager mode
+        opt = m.optimizer
+        counters = (opt.t, dict(opt.seg_steps))
+        rm0 = None if self.s_rm_backup is None else crit.dwt_running_mean.clone()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -1107,15 +1119,28 @@ class GraphedStep:
                 one_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        self._load(ci)
-        self._coef_for_next()
-        with torch.cuda.graph(self.graph):
-            self.s_loss = one_step()
+        fits = be.last_num_rendered() <= self.capacity
+        if fits:
+            self.graph = torch.cuda.CUDAGraph()
+            self._load(ci)
+            self._coef_for_next()
+            with torch.cuda.graph(self.graph):
+                self.s_loss = one_step()
+            # the capture itself launched nothing: replay once so that this call ends with a step
+            self.graph.replay()
+            torch.cuda.synchronize(dev)
+            fits = be.last_num_rendered() <= self.capacity
+        if not fits:
+            # this view needs more instances than the capacity: none of the steps above changed anything on the device
+            # (gs_backward_step skips on overflow).  Put the counters back and take ONE eager step instead.
+            opt.t, opt.seg_steps = counters[0], dict(counters[1])
+            if rm0 is not None:
+                crit.dwt_running_mean.copy_(rm0)
+            self.graph, self.key = None, None
+            self.eager_steps += 1
+            return tr._step_camera(ci, True, ())
         self.key = self._key(cam)
         self.captures += 1
-        # the capture itself launched nothing: replay once so that this call IS a step
-        self.graph.replay()
         self._save_order(ci)
         return self.s_loss
 
