@@ -310,7 +310,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     rows = const_cast<float*>(step->rows_override);
   } else {
     GS_PROF(ST_BWD_MEMSET, s);
-    GS_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)P * GR_STRIDE * sizeof(float), s));
+    launch_zero_rows(rows, (size_t)P * GR_STRIDE, s);
   }
   if (num_rendered > 0 && !given_rows) {
     {

@@ -126,20 +126,37 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
   const int nfl = cnt * N;
   const bool vec = (((((uintptr_t)pf) | ((uintptr_t)mf) | ((uintptr_t)vf)) & 15) == 0) && (nfl % 4 == 0);
   if (vec) {
-    for (int j = 4 * threadIdx.x; j < nfl; j += 4 * GS_BLOCK) {
-      float4 p4 = *reinterpret_cast<const float4*>(pf + j), m4 = *reinterpret_cast<const float4*>(mf + j),
-             v4 = *reinterpret_cast<const float4*>(vf + j);
-      float* pe = reinterpret_cast<float*>(&p4);
-      float* me = reinterpret_cast<float*>(&m4);
-      float* ve = reinterpret_cast<float*>(&v4);
+    // U float4 triples in flight per thread: the loads of a group are all issued before the first is consumed (a plain
+    // loop waits out the HBM latency once per float4: 12 round trips per thread for the SH block)
+    constexpr int U = 3;
+    for (int j0 = 4 * threadIdx.x; j0 < nfl; j0 += 4 * GS_BLOCK * U) {
+      float4 p4[U], m4[U], v4[U];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const float lr = (LR_SPLIT > 0 && ((j + e) % 48) >= LR_SPLIT) ? lr_b : lr_a;
-        adam_update(pe[e], grad(j + e), me[e], ve[e], lr, isb, b1, b2, eps);
+      for (int u = 0; u < U; u++) {
+        const int j = j0 + u * 4 * GS_BLOCK;
+        if (j < nfl) {
+          p4[u] = *reinterpret_cast<const float4*>(pf + j);
+          m4[u] = *reinterpret_cast<const float4*>(mf + j);
+          v4[u] = *reinterpret_cast<const float4*>(vf + j);
+        }
       }
-      *reinterpret_cast<float4*>(pf + j) = p4;
-      *reinterpret_cast<float4*>(mf + j) = m4;
-      *reinterpret_cast<float4*>(vf + j) = v4;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int j = j0 + u * 4 * GS_BLOCK;
+        if (j < nfl) {
+          float* pe = reinterpret_cast<float*>(&p4[u]);
+          float* me = reinterpret_cast<float*>(&m4[u]);
+          float* ve = reinterpret_cast<float*>(&v4[u]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float lr = (LR_SPLIT > 0 && ((j + e) % 48) >= LR_SPLIT) ? lr_b : lr_a;
+            adam_update(pe[e], grad(j + e), me[e], ve[e], lr, isb, b1, b2, eps);
+          }
+          *reinterpret_cast<float4*>(pf + j) = p4[u];
+          *reinterpret_cast<float4*>(mf + j) = m4[u];
+          *reinterpret_cast<float4*>(vf + j) = v4[u];
+        }
+      }
     }
   } else {
     for (int j = threadIdx.x; j < nfl; j += GS_BLOCK) {

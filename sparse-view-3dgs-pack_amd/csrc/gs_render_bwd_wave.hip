@@ -241,6 +241,18 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
   }
 }
 
+// zero fill of the gradient rows
+__global__ void __launch_bounds__(GS_BLOCK) zero_rows_kernel(float4* __restrict__ p, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * GS_BLOCK + threadIdx.x;
+  if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+int launch_zero_rows(float* rows, size_t n_floats, hipStream_t s) {
+  const size_t n4 = n_floats / 4;  // GR_STRIDE = 16 floats per row
+  if (n4) hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n4 + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, s,
+                             reinterpret_cast<float4*>(rows), n4);
+  return 0;
+}
+
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                            const uint32_t* tile_work, const uint32_t* tile_order, const float* dL_dpix,

@@ -346,6 +346,8 @@ class RasterBackend:
             dL_dout_invdepth = _prep(dL_dout_invdepth, device)
             _, _, _, wsb = self.scratch_bytes(P, W, H, R)
             ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
+            if self.keep_workspace:
+                self.last_workspace = ws
             s = self._scratch(geomBuffer, imgBuffer, binningBuffer, self._capacity_for(binningBuffer, P, W, H, R))
             self.api.call("backward_step", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
                           dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(step), _ptr(ws), ws.numel(),

@@ -1163,8 +1163,10 @@ class GraphedStep:
         ci = tr.camera_index(k)
         cam = tr.cameras[ci]
         be = self._backend()
-        if tr.model.exposure is not None or not tr._fused_step_ok(be, True):
-            self.eager_steps += 1  # what the capture cannot hold (a torch optimizer for the exposure, N > 1, ...)
+        if tr.model.exposure is not None or not tr._fused_step_ok(be, True) or be._capacity_hint <= 0:
+            # what the capture cannot hold (a torch optimizer for the exposure, N > 1, ...), or no view has been
+            # rendered yet to size the binning capacity from
+            self.eager_steps += 1
             return tr._step_camera(ci, True, ())
         if self.graph is None or self.key != self._key(cam):
             return self._capture(ci)

@@ -30,6 +30,31 @@ for name, a in (("list length", n), ("entries visited by bwd (max last contribut
     print("%-48s mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %d  sum/4096 slots %.0f" %
           (name, a.mean(), np.percentile(a, 50), np.percentile(a, 90), np.percentile(a, 99), a.max(), a.sum() / 4096))
 
+# Launch order of the one-wave-per-tile blend kernels: a wave runs at the pace of its dependent chain, so a tile costs
+# ~ its visited entries and a kernel ends with its last wave.  List-scheduling model: S wave slots, tiles handed out in
+# the given order to the first free slot; efficiency = mean slot load / makespan.
+import heapq  # noqa: E402
+
+
+def makespan(order, work, slots):
+    h = [0.0] * slots
+    heapq.heapify(h)
+    for t in order:
+        heapq.heappush(h, heapq.heappop(h) + float(work[t]))
+    return max(h)
+
+
+T = len(lmax)
+per = (T + 7) // 8
+image_order = [t for t in ((b & 7) * per + (b >> 3) for b in range(per * 8)) if t < T]
+lpt = np.argsort(-lmax, kind="stable")
+print("corr(list length, visited) = %.3f" % np.corrcoef(n, lmax)[0, 1])
+for S, what in ((4096, "backward, 4 waves/SIMD"), (7168, "forward, 7 waves/SIMD"), (8192, "8 waves/SIMD")):
+    avg = lmax.sum() / S
+    a, b_ = makespan(image_order, lmax, S), makespan(lpt, lmax, S)
+    print("S = %d (%s): mean slot load %.0f | image order: makespan %.0f (%.0f %% busy) | longest first: %.0f (%.0f %% busy)" % (
+        S, what, avg, a, 100 * avg / a, b_, 100 * avg / b_))
+
 # What a two-chunk emission would process: chunk A = the nearest f*P Gaussians of the depth order,
 # chunk B = the rest, only for tiles some pixel of which is not saturated when A's part of the list ends.
 pl = st["point_list"].long()
