@@ -19,7 +19,8 @@ OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs
         "scan_sums_kernel", "scan_down_kernel", "rs_rowscan_kernel", "sorted_block_sums_kernel", "duplicate_kernel", "tile_ranges_kernel",
         "bin_prepare_kernel", "render_fwd_wave_kernel", "render_bwd_wave_kernel", "render_fwd_kernel", "render_bwd_kernel", "adam_kernel", "scan_small_kernel", "preprocess_bwd_kernel", "l1_fwd_kernel",
         "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
-        "patch_dwt_kernel", "lgdwt_combine_kernel", "act_fwd_kernel", "act_bwd_kernel", "densify_stats_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel")
+        "patch_dwt_kernel", "lgdwt_combine_kernel", "act_fwd_kernel", "act_bwd_kernel", "densify_stats_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel", "preprocess_bwd_step_kernel",
+        "tile_order_kernel", "zero_rows_kernel")
 
 
 def short(name):
@@ -81,8 +82,10 @@ with open(os.path.join(here, "%s_pmc_traffic.csv" % tag), "w") as f:
         w.writerow([k, len(v["FETCH_SIZE"]), "%.1f" % fm, "%.1f" % wm, "%.0f" % rd, "%.0f" % wr, "%.0f" % (rd + wr)])
         traffic[k] = rd + wr
 stage_of = {"render_bwd": "render_bwd_wave_kernel", "render_fwd": "render_fwd_wave_kernel", "preprocess_fwd": "preprocess_fwd_kernel",
-            "preprocess_bwd": "preprocess_bwd_kernel", "duplicate": "duplicate_kernel", "tile_ranges": "tile_ranges_kernel"}
+            "preprocess_bwd": "preprocess_bwd_kernel", "preprocess_bwd_step": "preprocess_bwd_step_kernel",
+            "duplicate": "duplicate_kernel", "tile_ranges": "tile_ranges_kernel"}
 out = {st: traffic[k] for st, k in stage_of.items() if k in traffic}
+out["tag"] = tag
 if "rs_scatter_kernel" in traffic:  # the sort stage = all passes of hist + scatter (launch counts per step: 6 each)
     out["sort"] = 6 * (traffic.get("rs_scatter_kernel", 0) + traffic.get("rs_hist_kernel", 0))
 json.dump(out, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
@@ -97,9 +100,13 @@ for f in glob.glob(os.path.join(src, "sq*", "*", "*_counter_collection.csv")):
 if sq:
     with open(os.path.join(here, "%s_sq_counters.csv" % tag), "w") as f:
         w = csv.writer(f)
+        # VALU_issue_pct_of_peak: wave-instructions x 2 cycles (the wave64 issue rate a SIMD sustains with >= 2 ready waves)
+        # over all SIMD cycles of the launch; VALU_active_x4: SQ_ACTIVE_INST_VALU (quad-cycles) x 4, which prices every
+        # instruction at the 4-cycle single-wave issue cost and so reads high (round 1 quoted it as "busy")
         w.writerow(["kernel", "waves", "VALU_insts_per_wave", "LDS_insts_per_wave", "SALU_insts_per_wave", "VMEM_rd_per_wave",
-                    "VMEM_wr_per_wave", "VALU_busy_pct_of_SIMD_cycles", "wait_any_pct_of_wave_cycles",
+                    "VMEM_wr_per_wave", "VALU_issue_pct_of_peak", "VALU_active_x4_pct_of_SIMD_cycles", "wait_any_pct_of_wave_cycles",
                     "wait_inst_pct_of_wave_cycles", "waves_per_SIMD", "LDS_bank_conflict_pct_of_LDS_cycles"])
+        sq_insts = {"tag": tag}
         for k, v in sorted(sq.items()):
             m = {c: sum(x) / len(x) for c, x in v.items()}
             if k not in OURS or "GRBM_GUI_ACTIVE" not in m or m.get("SQ_WAVES", 0) == 0:
@@ -109,7 +116,13 @@ if sq:
             w.writerow([k, int(m["SQ_WAVES"]), round(m.get("SQ_INSTS_VALU", 0) / m["SQ_WAVES"], 1),
                         round(m.get("SQ_INSTS_LDS", 0) / m["SQ_WAVES"], 1), round(m.get("SQ_INSTS_SALU", 0) / m["SQ_WAVES"], 1),
                         round(m.get("SQ_INSTS_VMEM_RD", 0) / m["SQ_WAVES"], 1), round(m.get("SQ_INSTS_VMEM_WR", 0) / m["SQ_WAVES"], 1),
+                        round(100 * m.get("SQ_INSTS_VALU", 0) * 2 / simd_cycles, 1),
                         round(100 * m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles, 1),   # quad-cycles -> cycles
                         round(100 * m.get("SQ_WAIT_ANY", 0) / wc, 1), round(100 * m.get("SQ_WAIT_INST_ANY", 0) / wc, 1),
                         round(wc * 4 / simd_cycles, 2),
                         round(100 * m.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, m.get("SQ_LDS_IDX_ACTIVE", 0)), 1)])
+            for st, kn in (("render_bwd", "render_bwd_wave_kernel"), ("render_fwd", "render_fwd_wave_kernel")):
+                if k == kn:
+                    sq_insts[st] = m.get("SQ_INSTS_VALU", 0)   # wave-instructions per launch (mean over the launches)
+    json.dump(sq_insts, open(os.path.join(here, "sq_insts.json"), "w"), indent=1)
+    print(open(os.path.join(here, "%s_sq_counters.csv" % tag)).read())

@@ -196,6 +196,9 @@ class _FusedActivations(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_s, g_r, g_o):
+        if g_s is None and g_r is None and g_o is None:
+            # nothing flowed back (the fused train step has already consumed the gradients inside gs_backward_step)
+            return None, None, None, None
         scaling, rotation, opacity = ctx.saved_tensors
         model = ctx.model
         P = scaling.shape[0]
