@@ -279,19 +279,23 @@ def main():
     # them around ONE kernel only - the dominant one, found by an untimed pass with every stage instrumented first.
     names = [api.raw("profile_stage_name")(i).decode() for i in range(api.raw("profile_stage_count")())]
     prof, prof_timed, dom_stage = {}, {}, os.environ.get("GS_BENCH_DOMINANT", "")
-    if not args.no_stage_timers:
+
+    def profile_all_stages(nsteps):
+        nonlocal k
         api.call("profile_reset")
         api.call("profile_only", -1)
         api.call("profile_enable", 1)
-        for _ in range(min(args.steps, 10)):
+        for _ in range(nsteps):
             tr.step(k)
             k += 1
         barrier()
         api.call("profile_enable", 0)
-        prof = read_profile(api)
-        if not dom_stage:
-            timed_kernels = [n for n in prof if n in stage_bytes(1, 1, 1)]
-            dom_stage = max(timed_kernels, key=lambda n: prof[n][0] / prof[n][1]) if timed_kernels else "render_bwd"
+        return read_profile(api)
+
+    if not args.no_stage_timers and not dom_stage:
+        pre = profile_all_stages(min(args.steps, 4))
+        timed_kernels = [n for n in pre if n in stage_bytes(1, 1, 1)]
+        dom_stage = max(timed_kernels, key=lambda n: pre[n][0] / pre[n][1]) if timed_kernels else "render_bwd"
     # steady state = every camera has been visited before (sparse-view training revisits its few cameras all the time):
     # one more untimed cycle over the camera set, which also fills the forward's per-camera tile-order hints; in graph
     # mode the first of these steps captures the graph (three warm-up steps on a side stream + the captured one)
@@ -324,10 +328,13 @@ def main():
         k += 1
     barrier()
     dt = time.perf_counter() - t0
-    if not args.no_stage_timers and graphed is None:
-        api.call("profile_enable", 0)
-        prof_timed = read_profile(api)
-        api.call("profile_only", -1)
+    if not args.no_stage_timers:
+        if graphed is None:
+            api.call("profile_enable", 0)
+            prof_timed = read_profile(api)
+            api.call("profile_only", -1)
+        # every stage, in an untimed eager pass of the same steady-state step right after the timed region
+        prof = profile_all_stages(min(args.steps, 10))
         if dom_stage in prof_timed:
             prof[dom_stage] = prof_timed[dom_stage]  # the timed region's own measurement of the dominant kernel
     # the same step on the reference's bounding-square instance lists (GsView.tile_cull = 0: point_list / ranges /
@@ -433,13 +440,13 @@ def main():
             "roofline": roofline,
             "reference_lists": ref_lists,
             "stages": stages,
-            "stages_note": ("HIP events around every kernel group in an untimed EAGER pass of the same step before the timed "
+            "stages_note": ("HIP events around every kernel group in an untimed EAGER pass of the same step right after the timed "
                             "region (each event pair drains the pipeline for ~10 us); the timed region replays the step "
                             "from a hipGraph (%d replays, %d eager fall-backs, %d captures), so no event sits inside it; "
                             "the timed step includes the optimizer" % (graphed.replays, graphed.eager_steps, graphed.captures))
                            if graphed is not None else
                            ("HIP events; %s measured inside the timed region, the other stages in a separate untimed "
-                            "pass of the same step before it (each event pair drains the pipeline for ~10 us); the timed "
+                            "pass of the same step right after it (each event pair drains the pipeline for ~10 us); the timed "
                             "step includes the optimizer" % dom_stage),
             "launch": "hipGraph replay of the captured step" if graphed is not None else "eager",
             "launch_trial": graph_choice,

@@ -154,9 +154,11 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
       const float4 a = s_a[j];
       const float4 co = s_c[j];
       // alpha test for the four pixels of this lane
+      // (the four lane masks are kept as 64-bit scalars: with per-lane bools OR-ed together the compiler materialises
+      // them as 0/1 bytes in VGPRs - four v_cndmask, shifts and a bit-op per entry - and re-derives the masks afterwards)
       float G[4], alpha[4];
       bool valid[4];
-      bool any_valid = false;
+      unsigned long long vmask[4];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
@@ -164,10 +166,11 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
         const float p2 = blend_power2(co, dx, dy);
         G[s] = blend_exp2(p2);
         alpha[s] = fminf(0.99f, co.w * G[s]);
-        valid[s] = (contributor < lastc[s]) && (p2 <= 0.0f) && (alpha[s] >= 1.0f / 255.0f);
-        any_valid |= valid[s];
+        const bool c0 = contributor < lastc[s], c1 = p2 <= 0.0f, c2 = alpha[s] >= 1.0f / 255.0f;
+        valid[s] = c0 && c1 && c2;
+        vmask[s] = __ballot(c0) & __ballot(c1) & __ballot(c2);  // ballot of a compare IS the compare's scalar result
       }
-      if (!__any(any_valid)) continue;
+      if ((vmask[0] | vmask[1] | vmask[2] | vmask[3]) == 0ull) continue;
 
       // Raw sums; the constant factors of backward.cu:617-635 are applied once per (tile, Gaussian) after the
       // reduction:  mean2D.x = (0.5 W / log2e) * sum h (2 qa dx + qb dy),  conic.xx = -0.5 * sum h dx^2, ...
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
       const float q2a = co.x + co.x, q2c = co.z + co.z;
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        if (!__any(valid[s])) continue;  // wave-uniform: quadrant not touched by this Gaussian
+        if (vmask[s] == 0ull) continue;  // wave-uniform: quadrant not touched by this Gaussian
         if (valid[s]) {
           const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
           const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));

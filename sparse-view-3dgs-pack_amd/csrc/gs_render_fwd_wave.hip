@@ -117,17 +117,18 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       const float4 co = s_c[j];
       float alpha[4];
       bool hit[4];
-      bool any_hit = false;
+      unsigned long long hmask = 0ull;  // lane masks stay scalar (see the backward kernel)
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
         const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));
         const float p2 = blend_power2(co, dx, dy);
         alpha[s] = fminf(0.99f, co.w * blend_exp2(p2));
-        hit[s] = !done[s] && (p2 <= 0.0f) && (alpha[s] >= 1.0f / 255.0f);
-        any_hit |= hit[s];
+        const bool c1 = p2 <= 0.0f, c2 = alpha[s] >= 1.0f / 255.0f;
+        hit[s] = !done[s] && c1 && c2;
+        hmask |= __ballot(c1) & __ballot(c2) & ~__ballot(done[s]);
       }
-      if (!__any(any_hit)) continue;
+      if (hmask == 0ull) continue;
       // (a branch-free, select-masked update of all four pixels - 14 VALU ops each, no exec-mask bookkeeping - was
       // measured 5 % slower: 0.215 vs 0.204 ms; the exec-masked form skips untouched quadrants)
 #pragma unroll
