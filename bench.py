@@ -297,27 +297,42 @@ def main():
         timed_kernels = [n for n in pre if n in stage_bytes(1, 1, 1)]
         dom_stage = max(timed_kernels, key=lambda n: pre[n][0] / pre[n][1]) if timed_kernels else "render_bwd"
     # steady state = every camera has been visited before (sparse-view training revisits its few cameras all the time):
-    # one more untimed cycle over the camera set, which also fills the forward's per-camera tile-order hints; in graph
-    # mode the first of these steps captures the graph (three warm-up steps on a side stream + the captured one)
-    for _ in range(len(cams) // world + 2):
-        run_step(k)
+    # one more untimed cycle over the camera set, which also fills the forward's per-camera tile-order hints
+    cycle = len(cams) // world + 2
+    trial = {}
+    for _ in range(cycle):
+        tr.step(k)
         k += 1
     barrier()
-    if graphed is not None and graph_mode == "auto":
-        trial = {}
-        for form in ("graph", "eager"):
-            barrier()
+    if graphed is not None:
+        if graph_mode == "auto":
             t1 = time.perf_counter()
             for _ in range(8):
-                (graphed.step if form == "graph" else tr.step)(k)
+                tr.step(k)
                 k += 1
             barrier()
-            trial[form] = (time.perf_counter() - t1) / 8 * 1e3
-        graph_choice = {"graph_ms_per_step": trial["graph"], "eager_ms_per_step": trial["eager"],
-                        "chosen": "graph" if trial["graph"] < trial["eager"] else "eager"}
-        log("launch form: graph %.3f ms, eager %.3f ms per step -> %s" % (trial["graph"], trial["eager"], graph_choice["chosen"]))
-        if graph_choice["chosen"] == "eager":
-            graphed = None
+            trial["eager"] = (time.perf_counter() - t1) / 8 * 1e3
+        # the first of these steps captures the graph (three warm-up steps on a side stream + the captured one)
+        for _ in range(cycle):
+            graphed.step(k)
+            k += 1
+        barrier()
+        if graph_mode == "auto":
+            t1 = time.perf_counter()
+            for _ in range(8):
+                graphed.step(k)
+                k += 1
+            barrier()
+            trial["graph"] = (time.perf_counter() - t1) / 8 * 1e3
+            graph_choice = {"graph_ms_per_step": trial["graph"], "eager_ms_per_step": trial["eager"],
+                            "chosen": "graph" if trial["graph"] < trial["eager"] else "eager"}
+            log("launch form: graph %.3f ms, eager %.3f ms per step -> %s" % (trial["graph"], trial["eager"], graph_choice["chosen"]))
+            if graph_choice["chosen"] == "eager":
+                graphed = None
+                for _ in range(3):  # back on the eager allocator state before timing
+                    tr.step(k)
+                    k += 1
+                barrier()
     if graphed is None and not args.no_stage_timers:  # an eager timed region carries the event pair of the dominant kernel
         api.call("profile_reset")
         api.call("profile_only", names.index(dom_stage))

@@ -1020,8 +1020,11 @@ class GraphedStep:
     (the step kernel then does nothing, see gs_backward_step) - the step runs eagerly and the graph is re-captured.
     Results are those of the eager fused step: same kernels, same arguments."""
 
-    def __init__(self, trainer, capacity_margin=1.5, warmup=3):
+    def __init__(self, trainer, capacity_margin=1.5, warmup=3, capacity=None):
+        """capacity: binning capacity (instances) to capture with; default = capacity_margin x the largest view the
+        backend has seen recently."""
         self.tr = trainer
+        self.fixed_capacity = capacity
         self.capacity_margin = capacity_margin
         self.warmup = warmup
         self.graph = None
@@ -1088,7 +1091,8 @@ class GraphedStep:
         self.coef = torch.zeros((11,), dtype=torch.float32, device=dev)
         self.coef_host = torch.zeros((11,), dtype=torch.float32).pin_memory()
         # binning capacity: the largest view seen so far with head-room
-        self.capacity = int(max(be._capacity_hint, 4096) * self.capacity_margin)
+        self.capacity = int(self.fixed_capacity) if self.fixed_capacity is not None else \
+            int(max(be._capacity_hint, 4096) * self.capacity_margin)
         be._pinned_by_device.setdefault((dev.index, "static"), torch.empty((1,), dtype=torch.int32).pin_memory())
         saved = (tr.cameras, tr.gts, tr.masks)
 

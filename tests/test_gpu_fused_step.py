@@ -138,7 +138,7 @@ def test_graphed_step_trains_and_survives_a_capacity_overflow(hip):
     # a capacity far below what the views need: every attempt overflows, is recognised as a no-op on the device
     # (nothing updated, counters put back) and the step is taken eagerly: the run is the plain eager run
     c, e = make(hip, True), make(hip, True)
-    gc = GraphedStep(c, capacity_margin=0.2)
+    gc = GraphedStep(c, capacity=50_000)  # the views of this scene need ~250 000 instances
     lc = [float(gc.step(k)) for k in range(6)]
     le = [float(e.step(k)) for k in range(6)]
     assert gc.eager_steps == 6 and gc.replays == 0
