@@ -267,8 +267,18 @@ def main():
         from gsplat_amd.trainer import GraphedStep
         graphed = GraphedStep(tr)
 
+    # depth-limited instance lists (csrc/gs_tilecull.h; exact, verified by the forward, verdict collected one step later -
+    # gsplat_amd.trainer.Trainer.depth_limit): GS_BENCH_DEPTH_LIMIT=0 switches them off
+    depth_limit = world == 1 and args.config not in NIR_CONFIGS and os.environ.get("GS_BENCH_DEPTH_LIMIT", "1") != "0"
+    if depth_limit:
+        tr.depth_limit = "deferred"
+
     def run_step(kk):
         return graphed.step(kk) if graphed is not None else tr.step(kk)
+
+    def settle():
+        if hasattr(tr, "sync"):
+            tr.sync()
 
     k = 0
     for _ in range(args.warmup):
@@ -337,12 +347,17 @@ def main():
         api.call("profile_reset")
         api.call("profile_only", names.index(dom_stage))
         api.call("profile_enable", 1)
+    from gsplat_amd import hip_backend as _hb0
+    dl0 = dict(_hb0().depth_limit_stats)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step(k)
         k += 1
+    settle()  # (the last step's deferred verdict: inside the timed region)
     barrier()
     dt = time.perf_counter() - t0
+    dl1 = dict(_hb0().depth_limit_stats)
+    R_timed = int(_hb0()._pinned[0]) if _hb0()._pinned is not None else 0
     if not args.no_stage_timers:
         if graphed is None:
             api.call("profile_enable", 0)
@@ -392,7 +407,7 @@ def main():
         Rs = []
         import diff_gaussian_rasterization as dgr  # noqa: F401
         from gsplat_amd import hip_backend
-        R_last = int(hip_backend()._pinned[0]) if hip_backend()._pinned is not None else 0
+        R_last = R_timed
         N = W * H
         views = args.steps * world
         value = views / dt
@@ -464,6 +479,12 @@ def main():
                             "pass of the same step right after it (each event pair drains the pipeline for ~10 us); the timed "
                             "step includes the optimizer" % dom_stage),
             "launch": "hipGraph replay of the captured step" if graphed is not None else "eager",
+            "depth_limit": ({"mode": "deferred verdict", "limited_views_in_timed_region": dl1["used"] - dl0["used"],
+                             "fallbacks_in_timed_region": dl1["failed"] - dl0["failed"],
+                             "what": "on a camera's later visits, (tile, Gaussian) pairs behind the depth at which the tile's "
+                                     "blend stopped last time are not emitted; the forward verifies the cut lists, a failed "
+                                     "view is stepped again with full lists (csrc/gs_tilecull.h, tests/test_gpu_depth_limit.py); "
+                                     "GS_BENCH_DEPTH_LIMIT=0 = full lists"} if depth_limit else None),
             "launch_trial": graph_choice,
         }
         if world == 1 and not args.no_cpu_baseline and args.config not in NIR_CONFIGS:

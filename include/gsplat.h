@@ -111,6 +111,13 @@ typedef struct GsScratch {
                                       typically the previous visit of this camera, or just the previous view.  Pure
                                       scheduling (longest tile first, see gs_export_tile_order): outputs do not depend on it.
                                       Must be an unmodified export - every tile exactly once. */
+  const float* tile_depth_limit;   /* optional (NULL: none), only read when GsView.tile_cull is set; gs_tile_depth_limit_floats(W, H) floats: per tile, the view
+                                      depth beyond which (plus a 5 % + 0.02 margin) no (tile, Gaussian) pair is emitted -
+                                      gs_export_tile_stop_depth of an earlier forward of the SAME camera.  The forward checks
+                                      that the cut lists were long enough (gs_forward_status.trunc_failed == 0); when they
+                                      were, every output and gradient equals that of the uncut lists.  When the flag is set
+                                      the outputs are NOT valid: repeat gs_forward_geometry + gs_forward_render without
+                                      limits.  The same pointer and contents must be passed to both forward calls. */
 } GsScratch;
 
 /* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by
@@ -260,6 +267,21 @@ int gs_backward_from_rows(const GsView* view, const GsGaussians* g, const int32_
  * quantity, unknown before it has run - but a good predictor is the previous view: pass the export back in as
  * GsScratch.tile_order_hint.  out: device, 8 * ceil(T/8) uint32. */
 int gs_export_tile_order(const GsScratch* scratch, int32_t W, int32_t H, uint32_t* out, void* stream);
+
+/* Depth-limited emission.  Most (tile, Gaussian) pairs of a trained scene lie behind the depth at which the tile's
+ * pixels saturate (forward.cu:326-328 stops there); they are keyed, sorted and stored but never blended.
+ * gs_export_tile_stop_depth returns, per tile, the view depth of the list entry at which the last forward on this
+ * scratch stopped (+inf: some pixel of the tile never saturated - the whole list matters).  Handed back as
+ * GsScratch.tile_depth_limit on the next forward of the same camera, pairs deeper than that (with margin) are not emitted.
+ * out: device, gs_tile_depth_limit_floats(W, H) floats: per tile the largest stop depth of its 3 x 3 neighbourhood, then
+ * the largest of those per aligned run of four tiles of a row (why: csrc/gs_tilecull.h).  "No limit" = all +inf. */
+size_t gs_tile_depth_limit_floats(int32_t W, int32_t H);
+int gs_export_tile_stop_depth(const GsScratch* scratch, int32_t W, int32_t H, float* out, void* stream);
+/* Asynchronous read-back of the last forward's counters into host memory (pinned for a true async copy):
+ * out[0] = instances emitted (num_rendered), out[1] = overflow (binning capacity exceeded: nothing was blended),
+ * out[2] = trunc_failed (a depth-limited tile ran out of list entries: outputs invalid, see GsScratch.tile_depth_limit),
+ * out[3] = 0.  Valid after `stream` has been synchronised. */
+int gs_forward_status(const GsScratch* scratch, uint32_t* out /*[4] host*/, void* stream);
 
 /* ---- simple-knn ---- */
 /* out[i] = mean of the 3 smallest squared distances from point i to the other points.

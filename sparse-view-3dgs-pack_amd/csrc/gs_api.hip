@@ -6,6 +6,7 @@
 #include <math.h>
 
 #include "gs_common.h"
+#include "gs_tilecull.h"
 #include "gs_prof.h"
 
 static int check_args(const GsView* v, const GsGaussians* g) {
@@ -90,6 +91,7 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   a.antialiasing = v->antialiasing;
   a.extra_channel = g->extra_channel;
   a.tile_cull = v->tile_cull;
+  a.tile_depth_limit = v->tile_cull ? sc->tile_depth_limit : nullptr;
   {
     GS_PROF(ST_PREPROCESS_FWD, s);
     launch_preprocess_fwd(a, gv, s);
@@ -168,7 +170,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
     const int start = passes & 1;
     {
       GS_PROF(ST_DUPLICATE, s);
-      rc = launch_emit_instances(gv, P, gx, v->tile_cull, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
+      rc = launch_emit_instances(gv, P, gx, gy, v->tile_cull, sc->tile_depth_limit, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
       if (rc) return rc;
     }
     {
@@ -186,7 +188,8 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
   {
     GS_PROF(ST_RENDER_FWD, s);
     launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, iv.tile_work,
-                           sc->tile_order_hint, out_color, out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
+                           sc->tile_order_hint, sc->tile_depth_limit, iv.tile_stop_depth, &gv.hdr->trunc_failed, out_color,
+                           out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
   }
   {
     GS_PROF(ST_TILE_ORDER, s);
@@ -323,7 +326,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, grads);
   if (step) {
     GS_PROF(ST_BWD_STEP, s);
-    sa.overflow = &gv.hdr->overflow;
+    sa.hdr = gv.hdr;
     launch_preprocess_bwd_step(a, sa, s);
   } else {
     GS_PROF(ST_PREPROCESS_BWD, s);
@@ -459,6 +462,28 @@ int gs_export_tile_order(const GsScratch* sc, int32_t W, int32_t H, uint32_t* ou
   if (sc->img_bytes < img_bytes(N, T)) return GS_E_SCRATCH;
   ImgView iv = img_view(sc->img, N, T);
   GS_HIP_CHECK(hipMemcpyAsync(out, iv.tile_order, 4 * (((T + 7) / 8) * 8), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return GS_OK;
+}
+
+int gs_export_tile_stop_depth(const GsScratch* sc, int32_t W, int32_t H, float* out, void* stream) {
+  if (!sc || !sc->img || !out) return GS_E_NULL;
+  if (W <= 0 || H <= 0) return GS_E_SHAPE;
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  if (sc->img_bytes < img_bytes(N, T)) return GS_E_SCRATCH;
+  ImgView iv = img_view(sc->img, N, T);
+  return launch_export_stop_depth(iv.tile_stop_depth, out, gx, gy, (hipStream_t)stream);
+}
+
+size_t gs_tile_depth_limit_floats(int32_t W, int32_t H) {
+  if (W <= 0 || H <= 0) return 0;
+  return depth_limit_floats((uint32_t)((W + TILE_X - 1) / TILE_X), (uint32_t)((H + TILE_Y - 1) / TILE_Y));
+}
+
+int gs_forward_status(const GsScratch* sc, uint32_t* out, void* stream) {
+  if (!sc || !sc->geom || !out) return GS_E_NULL;
+  if (sc->geom_bytes < sizeof(GeomHeader)) return GS_E_SCRATCH;
+  GS_HIP_CHECK(hipMemcpyAsync(out, sc->geom, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return GS_OK;
 }
 

@@ -33,6 +33,8 @@ __global__ void __launch_bounds__(GS_BLOCK) bin_prepare_kernel(GeomHeader* hdr, 
     const bool ovf = R > capacity;
     hdr->overflow = ovf ? 1u : 0u;
     hdr->sort_n = ovf ? 0u : R;
+    hdr->trunc_failed = 0u;
+    hdr->zero = 0u;
   }
 }
 
@@ -311,7 +313,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t
   return woff + inc - v;
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, uint32_t grid_x, int tile_cull,
+__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, uint32_t grid_x, uint32_t grid_y, int tile_cull,
+                                                             const float* __restrict__ depth_limit,
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ block_base,
                                                              uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals) {
@@ -321,6 +324,8 @@ __global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, 
   __shared__ uint32_t s_rmin[GS_BLOCK];
   __shared__ uint32_t s_rmax[GS_BLOCK];
   __shared__ TileCull s_cull[GS_BLOCK];
+  __shared__ float s_depth[GS_BLOCK];
+  __shared__ int s_dq[GS_BLOCK];
   __shared__ uint32_t s_span_off[DUP_RC + 1];  // exclusive prefix of span lengths within the row chunk
   __shared__ uint32_t s_span_key[DUP_RC];      // first tile id of the span
   __shared__ uint32_t s_span_own[DUP_RC];      // owner (index into s_id)
@@ -341,6 +346,8 @@ __global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, 
       if (tile_cull) {
         const float4 ra = rec[0], rc = rec[1];
         s_cull[tid] = tilecull_setup(1, ra.x, ra.y, rc.x, rc.y, rc.z, rc.w);
+        s_depth[tid] = ra.z;
+        s_dq[tid] = depth_limit ? (int)((tail.w >> 8) & 3u) : 0;  // the preprocess kernel's verdict (gs_tilecull.h)
       } else {
         s_cull[tid].mode = 0;
       }
@@ -374,6 +381,8 @@ __global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, 
         const uint32_t ty = (rmin >> 16) + (rs - s_rowoff[lo]);
         uint32_t tx0;
         n = tilecull_row_span(s_cull[lo], ty, rmin & 0xFFFFu, rmax & 0xFFFFu, tx0);
+        if (s_dq[lo] == 2) n = tilecull_trim_span(depth_limit, grid_x, ty, s_depth[lo], tx0, n);
+        if (s_dq[lo] == 3) n = tilecull_trim_span_segments(depth_limit + (size_t)grid_x * grid_y, grid_x, ty, s_depth[lo], tx0, n);
         s_span_key[r] = ty * grid_x + tx0;
         s_span_own[r] = (uint32_t)lo;
       }
@@ -483,14 +492,14 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
   return 0;
 }
 
-int launch_emit_instances(const GeomView& g, int P, int grid_x, int tile_cull, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
-                          hipStream_t s, int debug) {
+int launch_emit_instances(const GeomView& g, int P, int grid_x, int grid_y, int tile_cull, const float* tile_depth_limit,
+                          const uint32_t* order, uint32_t* tkeys, uint32_t* tvals, hipStream_t s, int debug) {
   const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
   hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, order, g.tiles_touched, P, g.sorted_sums);
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, g.sorted_sums, nb);
   GS_LAUNCH_CHECK(s, debug);
-  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, P, (uint32_t)grid_x, tile_cull, order, g.sorted_sums, tkeys,
-                     tvals);
+  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, P, (uint32_t)grid_x, (uint32_t)grid_y,
+                     tile_cull, tile_cull ? tile_depth_limit : nullptr, order, g.sorted_sums, tkeys, tvals);
   GS_LAUNCH_CHECK(s, debug);
   return 0;
 }

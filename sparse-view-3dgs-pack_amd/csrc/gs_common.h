@@ -26,9 +26,11 @@
 struct GeomHeader {
   uint32_t num_rendered;  // R = sum tiles_touched
   uint32_t overflow;      // set by the duplicate kernel when R > binning capacity
+  uint32_t trunc_failed;  // depth-limited emission (gs_tilecull.h): a bounded tile ran out of list entries before saturating
+  uint32_t zero;          // (the first 16 bytes are what gs_forward_status copies out)
   uint32_t P;
   uint32_t sort_n;        // instances the binning stage really processes: overflow ? 0 : num_rendered
-  uint32_t pad[60];
+  uint32_t pad[58];
 };
 static_assert(sizeof(GeomHeader) == 256, "header is one 256-B block");
 
@@ -120,9 +122,10 @@ struct ImgView {
   uint2* ranges;
   uint32_t* tile_work;   // [T] list entries the backward blend will visit in this tile = max last contributor (forward)
   uint32_t* tile_order;  // [8 ceil(T/8)] launch order of the backward blend: per XCD band, by decreasing tile_work
+  float* tile_stop_depth;  // [T] view depth of the list entry at which the tile's last pixel saturated (+inf: never)
 };
 static inline __host__ __device__ size_t img_bytes(size_t N, size_t T) {
-  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T) + gs_align(4 * T) + gs_align(4 * (T + 8));
+  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T) + gs_align(4 * T) + gs_align(4 * (T + 8)) + gs_align(4 * T);
 }
 static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T) {
   char* p = (char*)buf;
@@ -131,7 +134,8 @@ static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T
   v.n_contrib = (uint32_t*)p; p += gs_align(4 * N);
   v.ranges = (uint2*)p; p += gs_align(8 * T);
   v.tile_work = (uint32_t*)p; p += gs_align(4 * T);
-  v.tile_order = (uint32_t*)p;
+  v.tile_order = (uint32_t*)p; p += gs_align(4 * (T + 8));
+  v.tile_stop_depth = (float*)p;
   return v;
 }
 
@@ -199,6 +203,7 @@ struct PreprocessArgs {
   int antialiasing;
   const float* extra_channel;  // [P] or NULL
   int tile_cull;  // GsView.tile_cull: 1 = emit only tiles the alpha >= 1/255 ellipse can reach (gs_tilecull.h)
+  const float* tile_depth_limit;  // [T] or NULL: depth-limited emission (gs_tilecull.h); only with tile_cull
 };
 int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_t s);
 int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s);
@@ -208,17 +213,18 @@ int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T
 // first_keys != NULL: the first pass reads its keys from there (left untouched) and takes value = index
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
                       const uint32_t* first_keys, hipStream_t s, int debug);
-int launch_emit_instances(const GeomView& g, int P, int grid_x, int tile_cull, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals,
-                          hipStream_t s, int debug);
+int launch_emit_instances(const GeomView& g, int P, int grid_x, int grid_y, int tile_cull, const float* tile_depth_limit,
+                          const uint32_t* order, uint32_t* tkeys, uint32_t* tvals, hipStream_t s, int debug);
 int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
                        hipStream_t s);
 
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_work,
-                           const uint32_t* order_hint, float* out_color, float* out_invdepth, float* out_extra, int fsgs,
-                           int cull, hipStream_t s);
+                           const uint32_t* order_hint, const float* depth_limit, float* stop_depth, uint32_t* trunc_failed,
+                           float* out_color, float* out_invdepth, float* out_extra, int fsgs, int cull, hipStream_t s);
 // tile_order[] = per XCD band of the image, the tiles by decreasing tile_work[] (order inside a bucket of equal work is free)
+int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, int grid_y, hipStream_t s);
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, hipStream_t s);
 int launch_zero_rows(float* rows, size_t n_floats, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
@@ -253,6 +259,6 @@ struct StepArgs {
   GsStepState st;
   float lr_bc1[6];        // lr / (1 - beta1^t) per learning-rate class   (st.coef_dev, when given, replaces both arrays)
   float inv_sqrt_bc2[5];  // 1 / sqrt(1 - beta2^t) per row
-  const uint32_t* overflow;  // geom header flag: binning capacity exceeded, nothing was blended -> the step is a no-op
+  const GeomHeader* hdr;  // overflow (binning capacity exceeded, nothing blended) or trunc_failed set -> the step is a no-op
 };
 int launch_preprocess_bwd_step(const PreprocessBwdArgs& a, const StepArgs& sa, hipStream_t s);

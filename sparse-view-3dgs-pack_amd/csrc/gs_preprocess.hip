@@ -48,9 +48,33 @@ struct ShMem {  // generic M: scalar loads
   __device__ __forceinline__ V3 operator()(int k) const { return {p[3 * k], p[3 * k + 1], p[3 * k + 2]}; }
 };
 
-__global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs a, GeomView g) {
+// Depth limits (gs_tilecull.h): the look-ups of a Gaussian have nothing to do with its neighbours' in the wave - fully
+// divergent loads, served one lane at a time by the vector memory path.  The tables are small, so each workgroup first
+// copies them into LDS (coalesced, out of L2) and the look-ups become ds_reads: always the segment table (1 B per tile),
+// the per-tile table (4 B per tile, 32 KB at 1080p) only if GS_LIMIT_TILES_IN_LDS.  Dynamic LDS: nothing is allocated
+// when there are no limits.
+#ifndef GS_LIMIT_TILES_IN_LDS
+#define GS_LIMIT_TILES_IN_LDS 0
+#endif
+#define GS_LIMIT_LDS_MAX_FLOATS (GS_LIMIT_TILES_IN_LDS ? 10240 : 4096)
+extern __shared__ float s_limit[];
+static inline size_t preprocess_limit_lds_floats(const PreprocessArgs& a) {
+  if (!a.tile_depth_limit) return 0;
+  const size_t T = (size_t)a.grid_x * a.grid_y, all = depth_limit_floats((uint32_t)a.grid_x, (uint32_t)a.grid_y);
+  const size_t want = GS_LIMIT_TILES_IN_LDS ? all : all - T;
+  return want <= GS_LIMIT_LDS_MAX_FLOATS ? want : 0;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs a, GeomView g, int lds_floats) {
   const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
   uint32_t tiles = 0;
+  const int T = a.grid_x * a.grid_y;
+  if (lds_floats) {  // the tail of the limit buffer (segments), or all of it
+    const float* src = a.tile_depth_limit + (GS_LIMIT_TILES_IN_LDS ? 0 : T);
+    for (int i = threadIdx.x; i < lds_floats; i += GS_BLOCK) s_limit[i] = src[i];
+    __syncthreads();
+  }
+  const GsLdsFloatPtr lds_seg = (GsLdsFloatPtr)s_limit + (GS_LIMIT_TILES_IN_LDS ? T : 0);
   if (idx < a.P) {
     Splat sp;
     sp.x = sp.y = sp.depth = sp.invdepth = 0.f;
@@ -164,9 +188,48 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
         if (tc.mode == 0) {
           tiles = (maxy - miny) * (maxx - minx);
         } else if (tc.mode == 2) {
+          // the tiles the ellipse really reaches (far fewer than the bounding square's), their bounding box and - with
+          // depth limits - how many of them survive the segment rule (gs_tilecull.h)
+          uint32_t bx0 = 0xFFFFFFFFu, bx1 = 0, by0 = 0xFFFFFFFFu, by1 = 0, tiles_seg = 0;
           for (uint32_t ty = miny; ty < maxy; ty++) {
             uint32_t tx0;
-            tiles += tilecull_row_span(tc, ty, minx, maxx, tx0);
+            const uint32_t n = tilecull_row_span(tc, ty, minx, maxx, tx0);
+            tiles += n;
+            if (n && a.tile_depth_limit) {
+              bx0 = min(bx0, tx0); bx1 = max(bx1, tx0 + n);
+              by0 = min(by0, ty); by1 = ty + 1;
+              if (lds_floats) {
+                uint32_t t0 = tx0;
+                tiles_seg += tilecull_trim_span_segments(lds_seg, (uint32_t)a.grid_x, ty, sp.depth, t0, n);
+              }
+            }
+          }
+          if (a.tile_depth_limit && tiles) {
+            // The verdict travels to the duplicate kernel in the record (bits 8-9 of `clamped`): 0 nothing cut, 1 all,
+            // 2 cut by the exact rule (Gaussians inside a 4 x 4 tile box: their <= 16 bounds fetched at once, rows then
+            // need no loads), 3 cut by the segment rule (larger Gaussians; only with the LDS table).
+            const uint32_t full = tiles;
+            uint32_t how = 0;
+            if (bx1 - bx0 <= 4u && by1 - by0 <= 4u) {
+              uint32_t beyond;
+              if (GS_LIMIT_TILES_IN_LDS && lds_floats)
+                beyond = depth_limit_box_mask((GsLdsFloatPtr)s_limit, (uint32_t)a.grid_x, bx0, by0, bx1, by1, sp.depth);
+              else
+                beyond = depth_limit_box_mask(a.tile_depth_limit, (uint32_t)a.grid_x, bx0, by0, bx1, by1, sp.depth);
+              if (beyond) {
+                tiles = 0;
+                for (uint32_t ty = by0; ty < by1; ty++) {
+                  uint32_t tx0;
+                  const uint32_t n = tilecull_row_span(tc, ty, minx, maxx, tx0);
+                  tiles += tilecull_trim_span_mask(beyond, bx0, by0, ty, tx0, n);
+                }
+                how = 2;
+              }
+            } else if (lds_floats) {
+              tiles = tiles_seg;
+              how = 3;
+            }
+            sp.clamped |= (tiles == 0 ? 1u : (tiles == full ? 0u : how)) << 8;
           }
         }
       } else {
@@ -247,7 +310,8 @@ __global__ void __launch_bounds__(GS_BLOCK) mark_visible_kernel(int P, const flo
 
 int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_t s) {
   const int nb = (a.P + GS_BLOCK - 1) / GS_BLOCK;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, a, g);
+  const size_t lds = preprocess_limit_lds_floats(a);
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(GS_BLOCK), 4 * lds, s, a, g, (int)lds);
   return 0;
 }
 int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s) {

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   const GsStepState& st = sa.st;
   // the forward ran out of binning capacity (possible only when the caller did not re-run it: a replayed graph): the
   // image was not rendered, so nothing may be updated - the host sees the flag and repeats the step eagerly
-  if (*sa.overflow) return;
+  if (sa.hdr->overflow | sa.hdr->trunc_failed) return;
   // step-dependent constants from device memory when the launch is replayed from a captured graph
   if (st.coef_dev) {
 #pragma unroll

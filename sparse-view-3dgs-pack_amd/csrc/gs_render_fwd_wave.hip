@@ -8,6 +8,7 @@
 // Replaces renderCUDA<3> forward (forward.cu:274-397); per-pixel arithmetic and stopping rules unchanged.
 #include "gs_blend.h"
 #include "gs_common.h"
+#include "gs_tilecull.h"
 
 #define WB 64
 
@@ -26,10 +27,13 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
                                                              uint32_t* __restrict__ n_contrib,
                                                              uint32_t* __restrict__ tile_work,
                                                              const uint32_t* __restrict__ order_hint,
+                                                             const float* __restrict__ depth_limit,
+                                                             float* __restrict__ stop_depth,
+                                                             uint32_t* __restrict__ trunc_failed,
                                                              float* __restrict__ out_color,
                                                              float* __restrict__ out_invdepth,
                                                              float* __restrict__ out_extra) {
-  __shared__ float4 s_a[WB];  // x, y, invdepth, cull extent y
+  __shared__ float4 s_a[WB];  // x, y, invdepth, cull extent y (CULL) / view depth (!CULL)
   __shared__ float4 s_c[WB];  // conic, opacity
   __shared__ float4 s_k[WB];  // rgb, cull extent x
   __shared__ float s_e[HAS_EXTRA ? WB : 1];  // 4th channel (N1: NIR albedo blended with the same weights)
@@ -67,6 +71,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     last_contributor[s] = 0;
   }
 
+  float stop_z = __builtin_inff();  // view depth of the entry at which the tile's last pixel saturated
   float4 ra, rc, rk;
   ra = rc = rk = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < n) {
@@ -77,7 +82,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     // the whole tile is done (forward.cu:326-328)
     if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
     __syncthreads();  // single wave: previous batch fully consumed
-    s_a[lane] = make_float4(ra.x, ra.y, FSGS ? ra.z : ra.w, 0.f);
+    s_a[lane] = make_float4(ra.x, ra.y, FSGS ? ra.z : ra.w, ra.z);
     s_c[lane] = blend_stage_conic(rc);  // (qa, qb, qc, opacity), see gs_blend.h
     if (!CULL) {
       s_k[lane] = rk;
@@ -150,7 +155,20 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
           }
         }
       }
-      if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
+      if (!__any(!(done[0] && done[1] && done[2] && done[3]))) {
+        if (!CULL) stop_z = a.w;
+        break;
+      }
+    }
+  }
+  if (lane == 0) {
+    // depth-limited emission (gs_tilecull.h): the list of this tile was cut at depth_limit[tile] (+ margin).  All entries
+    // up to that bound are present and in the reference's order, so the blend is the reference's iff it stopped inside
+    // them; otherwise the caller repeats the forward with full lists.
+    stop_depth[tile] = stop_z;
+    if (depth_limit) {
+      const float lim = depth_limit[tile];
+      if (lim < __builtin_inff() && depth_beyond_limit(stop_z, lim)) *trunc_failed = 1u;  // stop_z = +inf: never saturated
     }
   }
   {
@@ -181,11 +199,12 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_work,
-                           const uint32_t* order_hint, float* out_color, float* out_invdepth, float* out_extra, int fsgs,
-                           int cull, hipStream_t s) {
+                           const uint32_t* order_hint, const float* depth_limit, float* stop_depth, uint32_t* trunc_failed,
+                           float* out_color, float* out_invdepth, float* out_extra, int fsgs, int cull, hipStream_t s) {
 #define GS_FWD_WAVE(EX, FS, CU)                                                                                          \
   hipLaunchKernelGGL((render_fwd_wave_kernel<EX, FS, CU>), dim3(((grid_x * grid_y + 7) / 8) * 8), dim3(64), 0, s, ranges, point_list, W, H, \
-                     grid_x, splat, bg, final_T, n_contrib, tile_work, order_hint, out_color, out_invdepth, out_extra)
+                     grid_x, splat, bg, final_T, n_contrib, tile_work, order_hint, cull ? nullptr : depth_limit, stop_depth, trunc_failed, out_color,   \
+                     out_invdepth, out_extra)
   if (fsgs) {
     if (cull) GS_FWD_WAVE(false, true, true); else GS_FWD_WAVE(false, true, false);
   } else if (out_extra) {
@@ -259,6 +278,35 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* 
     const uint32_t pos = atomicAdd(&s_cnt[TO_BUCKETS - 1 - (tile_work[t] >> shift)], 1u);
     tile_order[band + 8 * pos] = (uint32_t)t;
   }
+}
+
+// gs_export_tile_stop_depth: per tile the largest stop depth of its 3 x 3 neighbourhood (reasons: gs_tilecull.h)
+__global__ void __launch_bounds__(256) stop_depth_bounds_kernel(const float* __restrict__ stop, float* __restrict__ out,
+                                                                int grid_x, int grid_y) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= grid_x * grid_y) return;
+  const int tx = t % grid_x, ty = t / grid_x;
+  float hi = -__builtin_inff();
+  for (int y = max(ty - 1, 0); y <= min(ty + 1, grid_y - 1); y++)
+    for (int x = max(tx - 1, 0); x <= min(tx + 1, grid_x - 1); x++) hi = fmaxf(hi, stop[y * grid_x + x]);
+  out[t] = hi;
+}
+
+__global__ void __launch_bounds__(256) stop_depth_segments_kernel(float* __restrict__ out, int grid_x, int grid_y) {
+  const int segs_x = (int)depth_limit_segs_x((uint32_t)grid_x);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= segs_x * grid_y) return;
+  const int sx = i % segs_x, ty = i / segs_x;
+  float hi = -__builtin_inff();
+  for (int x = 4 * sx; x < min(4 * sx + 4, grid_x); x++) hi = fmaxf(hi, out[ty * grid_x + x]);
+  out[grid_x * grid_y + i] = hi;
+}
+
+int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, int grid_y, hipStream_t s) {
+  const int T = grid_x * grid_y, S = (int)depth_limit_segs_x((uint32_t)grid_x) * grid_y;
+  hipLaunchKernelGGL(stop_depth_bounds_kernel, dim3((T + 255) / 256), dim3(256), 0, s, stop_depth, out, grid_x, grid_y);
+  hipLaunchKernelGGL(stop_depth_segments_kernel, dim3((S + 255) / 256), dim3(256), 0, s, out, grid_x, grid_y);
+  return 0;
 }
 
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, hipStream_t s) {

@@ -81,3 +81,115 @@ __device__ inline uint32_t tilecull_row_span(const TileCull& c, uint32_t ty, uin
   tx0 = (uint32_t)a;
   return (uint32_t)(b - a);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Depth-limited emission (GsScratch.tile_depth_limit).  The blend of a tile stops at the list entry where its last
+// pixel saturates (T < 1e-4); everything behind that depth is sorted, stored and never visited - ~80 % of the
+// instances at the bench workload.  A caller that renders the same camera again (sparse-view training does, every few
+// iterations) hands back, per tile, a depth bound derived from where the previous blend of the tile and of its eight
+// neighbours stopped (gs_export_tile_stop_depth; +inf where some pixel of them never saturated).  A (tile, Gaussian)
+// pair whose depth exceeds that bound by more than the margin below is not emitted: a row span is cut down to
+// [first tile not beyond its bound, last tile not beyond its bound], so spans stay contiguous (tiles in the middle of a
+// span are kept even if they fail the test: a harmless superset).
+// EXACTNESS is checked by the forward blend itself, not assumed: if a tile with a finite bound has not saturated all of
+// its pixels by the end of its list, or saturates them at an entry deeper than the bound, the launch sets
+// GeomHeader.trunc_failed and the caller repeats the forward without bounds.  When no tile does: every pair within the
+// bound is present, lists are depth-sorted, so each tile's list up to its stopping entry is the reference's and images,
+// n_contrib, final_T and all gradients are those of the uncut lists.
+// Why the 3 x 3 neighbourhood: the tiles whose last pixel flips between "saturates" and "never does" from one visit to
+// the next sit next to tiles that never saturate (silhouettes); with the dilated bound they get none.  Bench workload
+// (tests/tools/depth_limit_probe.py, 51 re-visits): 2 views fail with the tile's own stop depth - whatever the margin -
+// none with the dilated one, for 18 % instead of 16 % of the instances kept.
+// The preprocess kernel (count) and the duplicate kernel (emit) compute the same cut from the same comparisons.
+// ---------------------------------------------------------------------------------------------------------------------
+#define GS_DEPTH_LIMIT_REL 1.05f
+#define GS_DEPTH_LIMIT_ABS 0.02f
+// the one definition of "beyond the limit" (count, emit and the blend's check must agree to the bit: no contraction)
+__device__ inline bool depth_beyond_limit(float depth, float limit) {
+#pragma clang fp contract(off)
+  const float scaled = limit * GS_DEPTH_LIMIT_REL;
+  const float bound = scaled + GS_DEPTH_LIMIT_ABS;
+  return depth > bound;  // limit = +inf: never
+}
+// Limit buffer (gs_export_tile_stop_depth): T per-tile bounds, then grid_y * ceil(grid_x / 4) SEGMENT bounds - the largest
+// bound of each aligned run of four tiles of a row.
+__host__ __device__ inline uint32_t depth_limit_segs_x(uint32_t grid_x) { return (grid_x + 3u) / 4u; }
+__host__ __device__ inline size_t depth_limit_floats(uint32_t grid_x, uint32_t grid_y) {
+  return (size_t)grid_x * grid_y + (size_t)depth_limit_segs_x(grid_x) * grid_y;
+}
+typedef const __attribute__((address_space(3))) float* GsLdsFloatPtr;  // an LDS pointer the compiler can see is one
+
+// Exact rule: span [tx0, tx0 + n) of tile row ty -> [first tile not beyond its bound, last tile not beyond]; four
+// independent loads at a time (selects, not branches, so that they are in flight together).  n is at most 4 wherever this
+// is called (Gaussians inside a 4 x 4 tile box).
+template <typename Ptr>
+__device__ __forceinline__ uint32_t tilecull_trim_span(Ptr limit, uint32_t grid_x, uint32_t ty, float depth, uint32_t& tx0,
+                                                       uint32_t n) {
+  if (!limit || n == 0) return n;
+  const Ptr row = limit + (ty * grid_x + tx0);
+  uint32_t first = n, last = 0;
+  for (uint32_t b = 0; b < n; b += 4) {
+    const uint32_t i1 = min(b + 1, n - 1), i2 = min(b + 2, n - 1), i3 = min(b + 3, n - 1);
+    const float v0 = row[b], v1 = row[i1], v2 = row[i2], v3 = row[i3];
+    const bool k0 = !depth_beyond_limit(depth, v0), k1 = !depth_beyond_limit(depth, v1);
+    const bool k2 = !depth_beyond_limit(depth, v2), k3 = !depth_beyond_limit(depth, v3);
+    first = min(first, k0 ? b : (k1 ? i1 : (k2 ? i2 : (k3 ? i3 : n))));
+    last = max(last, k3 ? i3 + 1 : (k2 ? i2 + 1 : (k1 ? i1 + 1 : (k0 ? b + 1 : 0u))));
+  }
+  if (last <= first) return 0;
+  tx0 += first;
+  return last - first;
+}
+// Segment rule, for Gaussians that reach beyond a 4 x 4 tile box (a quarter of them at the bench workload, holding two
+// thirds of the instances): the span is cut to [first segment not beyond its bound, last such segment] - a superset of
+// the exact cut (a tile that is not beyond lies in a segment that is not), at a quarter of the look-ups.  Walking the
+// tiles of those spans one by one made every wave wait for its largest Gaussian: +0.08 ms at C3, as much as the shorter
+// sort saves - whether the bounds came from L2 or from LDS.
+template <typename Ptr>
+__device__ __forceinline__ uint32_t tilecull_trim_span_segments(Ptr seg_limit, uint32_t grid_x, uint32_t ty, float depth,
+                                                                uint32_t& tx0, uint32_t n) {
+  if (n == 0) return 0;
+  const uint32_t s0 = tx0 >> 2, ns = ((tx0 + n - 1) >> 2) - s0 + 1;
+  const Ptr row = seg_limit + (ty * depth_limit_segs_x(grid_x) + s0);
+  uint32_t first = ns, last = 0;
+  for (uint32_t b = 0; b < ns; b += 4) {
+    const uint32_t i1 = min(b + 1, ns - 1), i2 = min(b + 2, ns - 1), i3 = min(b + 3, ns - 1);
+    const float v0 = row[b], v1 = row[i1], v2 = row[i2], v3 = row[i3];
+    const bool k0 = !depth_beyond_limit(depth, v0), k1 = !depth_beyond_limit(depth, v1);
+    const bool k2 = !depth_beyond_limit(depth, v2), k3 = !depth_beyond_limit(depth, v3);
+    first = min(first, k0 ? b : (k1 ? i1 : (k2 ? i2 : (k3 ? i3 : ns))));
+    last = max(last, k3 ? i3 + 1 : (k2 ? i2 + 1 : (k1 ? i1 + 1 : (k0 ? b + 1 : 0u))));
+  }
+  if (last <= first) return 0;
+  const uint32_t lo = max(tx0, (s0 + first) << 2), hi = min(tx0 + n, (s0 + last) << 2);
+  tx0 = lo;
+  return hi - lo;
+}
+// The same cut for a Gaussian whose spans fit a 4 x 4 tile box [bx0, bx1) x [by0, by1): all (at most 16) bounds are
+// fetched at once into a bit mask (bit 4 r + c set = tile (by0 + r, bx0 + c) is beyond), the rows then need no loads.
+template <typename Ptr>
+__device__ __forceinline__ uint32_t depth_limit_box_mask(Ptr limit, uint32_t grid_x, uint32_t bx0, uint32_t by0, uint32_t bx1,
+                                                         uint32_t by1, float depth) {
+  // all loads first, then selects (no branches in between): sixteen loads in flight, one L2 round trip
+  float b[16];
+#pragma unroll
+  for (uint32_t r = 0; r < 4; r++) {
+    const Ptr row = limit + min(by0 + r, by1 - 1) * grid_x;  // clamped: bits past the box are never read
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) b[4 * r + c] = row[min(bx0 + c, bx1 - 1)];
+  }
+  uint32_t beyond = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 16; i++) beyond |= depth_beyond_limit(depth, b[i]) ? (1u << i) : 0u;
+  return beyond;
+}
+__device__ inline uint32_t tilecull_trim_span_mask(uint32_t beyond, uint32_t bx0, uint32_t by0, uint32_t ty, uint32_t& tx0,
+                                                   uint32_t n) {
+  if (n == 0) return 0;
+  const uint32_t c0 = tx0 - bx0;
+  const uint32_t keep = (~beyond >> (4 * (ty - by0))) & (((1u << n) - 1u) << c0) & 0xFu;
+  if (!keep) return 0;
+  const uint32_t first = (uint32_t)__builtin_ctz(keep), last = 31u - (uint32_t)__builtin_clz(keep);
+  tx0 = bx0 + first;
+  return last - first + 1;
+}

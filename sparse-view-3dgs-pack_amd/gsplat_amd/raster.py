@@ -51,8 +51,21 @@ class RasterBackend:
         self.tile_cull = os.environ.get("GS_TILE_CULL", "1") != "0"
         self._cap_memo = {}
         self._cap_by_buffer = {}
-        self._order_bufs = {}
+        self._cam_cache = {}
         self.order_hint_on = os.environ.get("GS_FWD_ORDER_HINT", "1") != "0"
+        # depth-limited emission (GsScratch.tile_depth_limit): on the second and later visits of a camera, (tile, Gaussian)
+        # pairs behind the depth at which that tile's blend stopped last time are not emitted.  Checked, not assumed: the
+        # forward flags lists that were cut too short and the view is rendered again without limits - which the host
+        # can only know once the blend has finished.  Waiting for that inside the forward costs more than the shorter sort
+        # saves (C3: 1.43 -> 1.60 ms/step), so it is OFF unless asked for (GS_DEPTH_LIMIT=1), and the train step asks for
+        # the deferred form instead: `depth_limit_request = "defer"` (one-shot, next forward) leaves the verdict in
+        # `self.deferred` for the caller to collect later - gsplat_amd.trainer does, its step kernel being a no-op on the
+        # device when the flag is set.  Only with tile_cull.
+        self.depth_limit_on = os.environ.get("GS_DEPTH_LIMIT", "0") == "1"
+        self.depth_limit_request = None
+        self.deferred = None
+        self._status_ring = {}
+        self.depth_limit_stats = dict(used=0, failed=0)
         self._pinned_by_device = {}
         # one-shot output arena for the next backward: {"means3D": [P,3], "sh": [P,M,3]} fp32 tensors to write
         # dL_dmeans3D / dL_dsh INTO (e.g. views of a flat gradient buffer) instead of fresh allocations
@@ -151,6 +164,28 @@ class RasterBackend:
         host word written by an asynchronous copy: only valid once that forward has completed)."""
         return None if self._pinned is None else int(self._pinned[0])
 
+    def take_deferred(self):
+        """The pending verdict of the last forward run with depth_limit_request = "defer", or None.  -> callable that
+        waits for that forward and returns True when its limits held (outputs valid) - on False it has already
+        invalidated the camera's limits, and the caller must discard everything computed from that forward."""
+        d, self.deferred = self.deferred, None
+        if d is None:
+            return None
+
+        def verdict():
+            d["event"].synchronize()
+            ok = int(d["status"][1]) == 0 and int(d["status"][2]) == 0
+            if not ok:
+                self.depth_limit_stats["failed"] += 1
+                d["cache"]["limit_ok"] = False
+            return ok
+        return verdict
+
+    def last_status(self):
+        """(num_rendered, overflow, trunc_failed) of the most recent forward that copied its status out
+        (gs_forward_status: the capture-safe mode and depth-limited forwards do); valid once it has completed."""
+        return None if self._pinned is None else tuple(int(x) for x in self._pinned[:3])
+
     def _capacity_for(self, binning, P, W, H, R):
         if binning.numel() == 0:
             return R
@@ -165,22 +200,28 @@ class RasterBackend:
         self.api.call("scratch_bytes", P, W, H, R, out, C.byref(ws))
         return out[0], out[1], out[2], ws.value
 
-    def _order_hint(self, device, W, H, viewmatrix):
-        """Scheduling hint for the forward blend (GsScratch.tile_order_hint): the tile order measured on the previous
-        visit of the SAME camera (a hint from another camera is worthless: 0.203 ms either way at C3; from the same
-        camera 0.204 -> 0.164 ms, tests/tools/fwd_order_probe.py).  Cameras are told apart by the address of their view
-        matrix - training loops keep one tensor per camera.  GS_FWD_ORDER_HINT=0 switches it off.
-        -> ([buffer, valid], hint tensor or None)"""
-        if not self.order_hint_on or device.type != "cuda":
-            return None, None
+    def _camera_cache(self, device, W, H, viewmatrix):
+        """What the previous visit of the SAME camera measured, per tile:
+        order - the launch order for the forward blend (GsScratch.tile_order_hint; a hint from another camera is
+                worthless: 0.203 ms either way at C3; from the same camera 0.204 -> 0.164 ms, tests/tools/fwd_order_probe.py);
+        limit - the depth at which each tile's blend stopped (GsScratch.tile_depth_limit).
+        Cameras are told apart by the address of their view matrix - training loops keep one tensor per camera; a stale
+        or foreign entry costs time, never correctness (the order is pure scheduling, the limits are verified by the
+        forward).  -> dict(order, order_ok, limit, limit_ok) or None"""
+        if device.type != "cuda" or not (self.order_hint_on or self.depth_limit_on):
+            return None
         key = (device.index, W, H, viewmatrix.data_ptr())
-        buf = self._order_bufs.get(key)
-        if buf is None:
-            if len(self._order_bufs) >= 256:  # forget the oldest camera
-                self._order_bufs.pop(next(iter(self._order_bufs)))
-            n = ((((W + 15) // 16) * ((H + 15) // 16) + 7) // 8) * 8
-            buf = self._order_bufs[key] = [torch.empty((n,), dtype=torch.int32, device=device), False]
-        return buf, (buf[0] if buf[1] else None)
+        c = self._cam_cache.get(key)
+        if c is None:
+            if len(self._cam_cache) >= 256:  # forget the oldest camera
+                self._cam_cache.pop(next(iter(self._cam_cache)))
+            T = ((W + 15) // 16) * ((H + 15) // 16)
+            c = self._cam_cache[key] = dict(order=torch.empty((((T + 7) // 8) * 8,), dtype=torch.int32, device=device),
+                                            order_ok=False,
+                                            limit=torch.full((int(self.api.raw("tile_depth_limit_floats")(W, H)),), float("inf"),
+                                                             dtype=torch.float32, device=device),
+                                            limit_ok=False)
+        return c
 
     @staticmethod
     def _scratch(geom, img, binning, capacity):
@@ -224,15 +265,34 @@ class RasterBackend:
             e = torch.empty((0,), **u8)
             return (0, out_color, radii, e, e.clone(), e.clone(), out_invdepth) + tail
 
-        order_buf, order_hint = self._order_hint(device, W, H, viewmatrix)
+        cache = self._camera_cache(device, W, H, viewmatrix)
+        static = self.static_capacity is not None
+        use_order = cache is not None and self.order_hint_on
+        request, self.depth_limit_request = self.depth_limit_request, None
+        self.deferred = None
+        use_limit = cache is not None and (self.depth_limit_on or request is not None) and self.tile_cull
+        defer = request == "defer"
+        # capture-safe mode always passes the limit buffer (+inf = no limit): the pointer is frozen into the graph
+        limit = cache["limit"] if use_limit and (static or cache["limit_ok"]) else None
+
+        def scratch_of(binning, capacity, limit):
+            s = self._scratch(geom, img, binning, capacity)
+            if limit is not None:
+                s.tile_depth_limit = limit.data_ptr()
+            return s
 
         def render(scratch):
-            if order_hint is not None:
-                scratch.tile_order_hint = order_hint.data_ptr()
+            if use_order and cache["order_ok"]:
+                scratch.tile_order_hint = cache["order"].data_ptr()
             self._render(scratch, fsgs, extra, view, g, out_color, out_invdepth, out_extra, stream)
-            if order_buf is not None:  # this view's measured order becomes the next view's hint
-                self.api.call("export_tile_order", C.byref(scratch), W, H, order_buf[0].data_ptr(), stream)
-                order_buf[1] = True
+
+        def remember(scratch):  # what this view measured becomes the hint of this camera's next visit
+            if use_order:
+                self.api.call("export_tile_order", C.byref(scratch), W, H, cache["order"].data_ptr(), stream)
+                cache["order_ok"] = True
+            if use_limit:
+                self.api.call("export_tile_stop_depth", C.byref(scratch), W, H, cache["limit"].data_ptr(), stream)
+                cache["limit_ok"] = True
 
         keep = []
         view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
@@ -244,28 +304,51 @@ class RasterBackend:
         geom = torch.empty((gb,), **u8)
         img = torch.empty((ib,), **u8)
         empty = torch.empty((0,), **u8)
-        s = self._scratch(geom, img, empty, 0)
 
-        if device.type == "cuda":
-            # one pinned counter per device AND stream: two forwards in flight on different streams must not share it
-            # (capture-safe mode: one per device, created before the capture - pinned memory cannot be allocated inside)
-            pkey = (device.index, "static" if self.static_capacity is not None else
-                    torch.cuda.current_stream(device).cuda_stream)
-            nr_host = self._pinned_by_device.get(pkey)
-            if nr_host is None:
-                nr_host = self._pinned_by_device[pkey] = torch.empty((1,), dtype=torch.int32).pin_memory()
-            self._pinned = nr_host  # (last used: read by bench.py for the instance count of the last view)
-            cur = torch.cuda.current_stream(device)
-            self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(),
-                          nr_host.data_ptr(), stream)
-            if self.static_capacity is not None:
-                cap = int(self.static_capacity)
-                _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
-                binning = torch.empty((bb,), **u8)
-                self._remember_capacity(binning, cap)
-                render(self._scratch(geom, img, binning, cap))
-                return (cap, out_color, radii, geom, binning, img, out_invdepth) + tail
+        def new_binning(cap):
+            _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
+            binning = torch.empty((bb,), **u8)
+            self._remember_capacity(binning, cap)
+            return binning
+
+        if device.type != "cuda":
+            nr = (C.c_int32 * 1)()
+            self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(scratch_of(empty, 0, None)),
+                          radii.data_ptr(), C.cast(nr, C.c_void_p), stream)
+            num_rendered = int(nr[0])
+            binning = new_binning(num_rendered)
+            render(scratch_of(binning, num_rendered, None))
+            return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
+
+        # one pinned status block per device AND stream: two forwards in flight on different streams must not share it
+        # (capture-safe mode: one per device, created before the capture - pinned memory cannot be allocated inside).
+        # Words: num_rendered, overflow, trunc_failed, 0 (gs_forward_status; gs_forward_geometry writes word 0 alone)
+        cur = torch.cuda.current_stream(device)
+        pkey = (device.index, "static" if static else cur.cuda_stream)
+        status = self._pinned_by_device.get(pkey)
+        if status is None:
+            status = self._pinned_by_device[pkey] = torch.zeros((4,), dtype=torch.int32).pin_memory()
+        self._pinned = status  # (last used: read by bench.py for the instance count of the last view)
+
+        def geometry(limit):
+            self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(scratch_of(empty, 0, limit)),
+                          radii.data_ptr(), status.data_ptr(), stream)
+
+        if static:
+            # capture-safe: fixed capacity, no host wait, no re-run; the caller reads last_status() after the stream drained
+            cap = int(self.static_capacity)
+            geometry(limit)
+            binning = new_binning(cap)
+            s = scratch_of(binning, cap, limit)
+            render(s)
+            self.api.call("forward_status", C.byref(s), status.data_ptr(), stream)
+            remember(s)
+            return (cap, out_color, radii, geom, binning, img, out_invdepth) + tail
+
+        for limit in ((limit, None) if limit is not None else (None,)):
+            geometry(limit)
             cap = self._capacity_hint if self.optimistic else 0
+            binning = None
             if cap > 0:
                 # Optimistic path: the reference blocks the host on a D2H copy of num_rendered before it can
                 # size the binning buffer (rasterizer_impl.cu:284-288) and the GPU idles meanwhile.  Here the
@@ -275,33 +358,47 @@ class RasterBackend:
                 # the prediction was too small.
                 ev = torch.cuda.Event()
                 ev.record(cur)
-                _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
-                binning = torch.empty((bb,), **u8)
-                self._remember_capacity(binning, cap)
-                s2 = self._scratch(geom, img, binning, cap)
-                render(s2)
+                binning = new_binning(cap)
+                s = scratch_of(binning, cap, limit)
+                render(s)
                 ev.synchronize()
-                num_rendered = int(nr_host[0])
-                self._update_hint(num_rendered)
-                if num_rendered <= cap:
-                    return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
-                del binning
             else:
                 cur.synchronize()  # the reference's blocking D2H (rasterizer_impl.cu:284)
-                num_rendered = int(nr_host[0])
+            num_rendered = int(status[0])
+            if limit is None:
                 self._update_hint(num_rendered)
-        else:
-            nr = (C.c_int32 * 1)()
-            self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(),
-                          C.cast(nr, C.c_void_p), stream)
-            num_rendered = int(nr[0])
-
-        _, _, bb, _ = self.scratch_bytes(P, W, H, num_rendered)
-        binning = torch.empty((bb,), **u8)
-        self._remember_capacity(binning, num_rendered)
-        s = self._scratch(geom, img, binning, num_rendered)
-        render(s)
-        return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
+            if binning is None or num_rendered > cap:
+                binning = new_binning(num_rendered)
+                s = scratch_of(binning, num_rendered, limit)
+                render(s)
+            if limit is not None:
+                # depth-limited lists: the blend has checked that every bounded tile saturated inside the part of its
+                # list that is certainly complete; the host has to know before it hands the image out (this wait ends
+                # when the blend does, the un-limited path's when the geometry phase does)
+                self.depth_limit_stats["used"] += 1
+                if defer:
+                    # the caller collects the verdict later (take_deferred): its own status block, from a small ring -
+                    # a block is re-used only after eight further deferred forwards
+                    ring = self._status_ring.setdefault(device.index, [[], 0])
+                    if len(ring[0]) < 8:
+                        ring[0].append(torch.zeros((4,), dtype=torch.int32).pin_memory())
+                    block = ring[0][ring[1] % len(ring[0])]
+                    ring[1] += 1
+                    self.api.call("forward_status", C.byref(s), block.data_ptr(), stream)
+                    done = torch.cuda.Event()
+                    done.record(cur)
+                    self.deferred = dict(status=block, event=done, cache=cache)
+                    remember(s)
+                    return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
+                self.api.call("forward_status", C.byref(s), status.data_ptr(), stream)
+                cur.synchronize()
+                if int(status[2]) != 0:  # some tile needed entries that were cut: forget the limits, do the view again
+                    self.depth_limit_stats["failed"] += 1
+                    cache["limit_ok"] = False
+                    del binning
+                    continue
+            remember(s)
+            return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
 
     def _render(self, scratch, fsgs, extra, view, g, out_color, out_invdepth, out_extra, stream):
         if fsgs:

@@ -763,6 +763,8 @@ class Trainer:
                                      (opt.white_background and iteration == opt.densify_from_iter))
         do_step = iteration < opt.iterations and not will_densify
         loss = self._step_camera(ci, do_step, ("opacity",) if will_reset else ())
+        if will_densify or will_reset or iteration >= opt.iterations:
+            self.sync()  # (depth-limited steps: the model is about to be read / re-laid out)
         densified, reset = None, False
         if will_densify:
             self.gather_optimizer_state()
@@ -785,12 +787,36 @@ class Trainer:
                 and isinstance(m.optimizer, FlatAdam) and not m.with_nir and m.flat.is_cuda
                 and hasattr(backend.api, "_backward_step") and hasattr(backend, "fused_step"))
 
+    # Depth-limited instance lists (RasterBackend.depth_limit_request) for the fused single-GPU step: None = off,
+    # "deferred" = on, with the forward's verdict ("were the cut lists long enough?") collected one step later, when it
+    # costs no wait.  A step whose limits failed changed nothing on the device (gs_backward_step checks the same flag),
+    # so it is simply taken again without limits; until then its loss tensor holds the value of the invalid image - it
+    # is overwritten in place.  Anything that reads the model between steps goes through sync() first.
+    depth_limit = None
+
+    def sync(self):
+        """Settle the verdict of the last depth-limited step (redoing the step if its limits failed)."""
+        p, self._pending = getattr(self, "_pending", None), None
+        if p is None or p["verdict"]():
+            return
+        opt = self.model.optimizer
+        opt.t, opt.seg_steps = p["counters"][0], dict(p["counters"][1])
+        if p["running_mean"] is not None:
+            self.criterion.dwt_running_mean.copy_(p["running_mean"])
+        p["loss"].copy_(self._step_camera(p["ci"], True, p["skip"]))  # (the camera's limits are invalid now: full lists)
+        self.sync()
+
     def _step_camera(self, ci, optimizer_step, skip):
+        self.sync()
         m = self.model
         m.zero_grad()
         backend = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
         backend = getattr(backend, "backend", None)
         fused_step = self._fused_step_ok(backend, optimizer_step)
+        deferred = fused_step and self.depth_limit == "deferred" and getattr(self, "_coef_dev", None) is None
+        if deferred:
+            counters = (m.optimizer.t, dict(m.optimizer.seg_steps))
+            backend.depth_limit_request = "defer"
         if fused_step:
             backend.fused_step = m.optimizer.fused_request(skip, coef_dev=getattr(self, "_coef_dev", None))
             rows = getattr(self, "rows_override", None)  # parity tests: blend sums to use instead of stage 1
@@ -802,12 +828,18 @@ class Trainer:
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
                      clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci)
         mask = None if self.masks is None else self.masks[ci]
+        verdict = backend.take_deferred() if deferred else None
+        if verdict is not None:
+            rm = getattr(self.criterion, "dwt_running_mean", None)
+            rm = None if rm is None else rm.clone()
         if fused:
             loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
         else:
             loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
         loss.backward()
         radii = pkg["radii"]
+        if verdict is not None:
+            self._pending = dict(verdict=verdict, ci=ci, skip=skip, counters=counters, running_mean=rm, loss=loss.detach())
         if fused_step:
             # gs_backward_step has already applied the activation backward, the view statistics and Adam
             if backend.fused_step is not None:
@@ -1030,6 +1062,7 @@ class GraphedStep:
         self.graph = None
         self.key = None
         self.cam_orders = {}
+        self.cam_limits = {}
         self.replays = self.eager_steps = self.captures = 0
 
     # -- what the capture froze
@@ -1053,23 +1086,34 @@ class GraphedStep:
             mk = tr.masks[ci]
             self.s_mask.copy_(mk, non_blocking=True)
             self.s_mask._gs_n_sel.copy_(mk._gs_n_sel, non_blocking=True)
-        # the forward's per-camera tile-order hint (RasterBackend._order_hint keys it by the view matrix's address, which
-        # is the static tensor's here): bring in what this camera's last visit measured
-        ob = self._order_buf()
-        if ob is not None and ci in self.cam_orders:
-            ob[0].copy_(self.cam_orders[ci], non_blocking=True)
+        # the forward's per-camera hints (RasterBackend._camera_cache keys them by the view matrix's address, which is the
+        # static tensor's here): bring in what this camera's last visit measured - tile order and per-tile depth limits
+        cc = self._cam_cache()
+        if cc is not None:
+            if ci in self.cam_orders:
+                cc["order"].copy_(self.cam_orders[ci], non_blocking=True)
+            if ci in self.cam_limits:
+                cc["limit"].copy_(self.cam_limits[ci], non_blocking=True)
+            else:
+                cc["limit"].fill_(float("inf"))
 
-    def _order_buf(self):
+    def _cam_cache(self):
         be = self._backend()
         cam = self.s_cam
-        return be._order_bufs.get((self.s_view.device.index, int(cam.image_width), int(cam.image_height), self.s_view.data_ptr()))
+        return be._cam_cache.get((self.s_view.device.index, int(cam.image_width), int(cam.image_height), self.s_view.data_ptr()))
 
     def _save_order(self, ci):
-        ob = self._order_buf()
-        if ob is not None and ob[1]:
+        cc = self._cam_cache()
+        if cc is None:
+            return
+        if cc["order_ok"]:
             if ci not in self.cam_orders:
-                self.cam_orders[ci] = torch.empty_like(ob[0])
-            self.cam_orders[ci].copy_(ob[0], non_blocking=True)
+                self.cam_orders[ci] = torch.empty_like(cc["order"])
+            self.cam_orders[ci].copy_(cc["order"], non_blocking=True)
+        if cc["limit_ok"]:
+            if ci not in self.cam_limits:
+                self.cam_limits[ci] = torch.empty_like(cc["limit"])
+            self.cam_limits[ci].copy_(cc["limit"], non_blocking=True)
 
     def _capture(self, ci):
         import numpy as np
@@ -1093,11 +1137,12 @@ class GraphedStep:
         # binning capacity: the largest view seen so far with head-room
         self.capacity = int(self.fixed_capacity) if self.fixed_capacity is not None else \
             int(max(be._capacity_hint, 4096) * self.capacity_margin)
-        be._pinned_by_device.setdefault((dev.index, "static"), torch.empty((1,), dtype=torch.int32).pin_memory())
+        be._pinned_by_device.setdefault((dev.index, "static"), torch.zeros((4,), dtype=torch.int32).pin_memory())
         saved = (tr.cameras, tr.gts, tr.masks)
 
         def one_step():
             be.static_capacity = self.capacity
+            be.depth_limit_request = "graph" if tr.depth_limit else None
             tr.cameras, tr.gts, tr.masks = [self.s_cam], [self.s_gt], (None if self.s_mask is None else [self.s_mask])
             tr._coef_dev = self.coef
             try:
@@ -1126,7 +1171,7 @@ class GraphedStep:
                 one_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        fits = be.last_num_rendered() <= self.capacity
+        fits = self._view_ok(be)
         if fits:
             self.graph = torch.cuda.CUDAGraph()
             self._load(ci)
@@ -1136,10 +1181,12 @@ class GraphedStep:
             # the capture itself launched nothing: replay once so that this call ends with a step
             self.graph.replay()
             torch.cuda.synchronize(dev)
-            fits = be.last_num_rendered() <= self.capacity
+            fits = self._view_ok(be)
         if not fits:
-            # this view needs more instances than the capacity: none of the steps above changed anything on the device
-            # (gs_backward_step skips on overflow).  Put the counters back and take ONE eager step instead.
+            # this view needs more instances than the capacity (or its depth limits were stale): none of the steps above
+            # changed anything on the device (gs_backward_step skips on either flag).  Put the counters back and take ONE
+            # eager step instead.
+            self.cam_limits.pop(ci, None)
             opt.t, opt.seg_steps = counters[0], dict(counters[1])
             if rm0 is not None:
                 crit.dwt_running_mean.copy_(rm0)
@@ -1150,6 +1197,10 @@ class GraphedStep:
         self.captures += 1
         self._save_order(ci)
         return self.s_loss
+
+    def _view_ok(self, be):
+        num_rendered, overflow, trunc_failed = be.last_status()
+        return num_rendered <= self.capacity and not overflow and not trunc_failed
 
     def _coef_for_next(self):
         """Constants of the step the NEXT launch performs: the launch (eager inside one_step, or a replay) is step t + 1."""
@@ -1167,6 +1218,7 @@ class GraphedStep:
 
     def step(self, k):
         tr = self.tr
+        tr.sync()
         ci = tr.camera_index(k)
         cam = tr.cameras[ci]
         be = self._backend()
@@ -1188,9 +1240,11 @@ class GraphedStep:
         self.replays += 1
         # one host wait per step (the eager path has one too, inside the forward): did the view fit the capacity?
         torch.cuda.current_stream(tr.model.flat.device).synchronize()
-        if be.last_num_rendered() > self.capacity:
-            # the captured step was a no-op on the device (gs_backward_step skips on overflow): undo the counter,
-            # run the step eagerly (which also raises the capacity hint) and capture again next time
+        if not self._view_ok(be):
+            # the captured step was a no-op on the device (gs_backward_step skips on overflow and on depth limits that
+            # proved too tight): undo the counter, run the step eagerly (which also raises the capacity hint), forget this
+            # camera's limits and capture again next time
+            self.cam_limits.pop(ci, None)
             opt = tr.model.optimizer
             opt.t -= 1
             for name in opt.seg_steps:

@@ -25,7 +25,7 @@ bg = torch.zeros(3)
 
 def timed(cam_seq, hint_on, n=10):
     hip.order_hint_on = hint_on
-    hip._order_bufs.clear()
+    hip._cam_cache.clear()
     for c in cam_seq[:2]:
         fp.forward(hip, sc, cams[c], dev, bg)
     torch.cuda.synchronize()
