@@ -269,7 +269,9 @@ def main():
 
     # depth-limited instance lists (csrc/gs_tilecull.h; exact, verified by the forward, verdict collected one step later -
     # gsplat_amd.trainer.Trainer.depth_limit): GS_BENCH_DEPTH_LIMIT=0 switches them off
-    depth_limit = world == 1 and args.config not in NIR_CONFIGS and os.environ.get("GS_BENCH_DEPTH_LIMIT", "1") != "0"
+    # (default: on from 100 k Gaussians - on the 10 k scene of c1 there is nothing to cut and the two extra launches cost 3 %)
+    depth_limit = world == 1 and args.config not in NIR_CONFIGS and \
+        os.environ.get("GS_BENCH_DEPTH_LIMIT", "1" if P >= 100_000 else "0") != "0"
     if depth_limit:
         tr.depth_limit = "deferred"
 

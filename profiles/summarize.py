@@ -20,7 +20,7 @@ OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs
         "bin_prepare_kernel", "render_fwd_wave_kernel", "render_bwd_wave_kernel", "render_fwd_kernel", "render_bwd_kernel", "adam_kernel", "scan_small_kernel", "preprocess_bwd_kernel", "l1_fwd_kernel",
         "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
         "patch_dwt_kernel", "lgdwt_combine_kernel", "act_fwd_kernel", "act_bwd_kernel", "densify_stats_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel", "preprocess_bwd_step_kernel",
-        "tile_order_kernel", "zero_rows_kernel")
+        "tile_order_kernel", "zero_rows_kernel", "stop_depth_bounds_kernel")
 
 
 def short(name):

@@ -333,6 +333,7 @@ __global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, 
   const int tid = threadIdx.x;
   const int i = blockIdx.x * GS_BLOCK + tid;
   uint32_t tiles = 0, rows = 0;
+  s_dq[tid] = 0;  // (only Gaussians with culled spans AND depth limits carry a verdict; everything else: spans as they are)
   if (i < P) {
     const uint32_t id = order[i];
     const float4* rec = reinterpret_cast<const float4*>(&g.splat[id]);
@@ -381,8 +382,9 @@ __global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, 
         const uint32_t ty = (rmin >> 16) + (rs - s_rowoff[lo]);
         uint32_t tx0;
         n = tilecull_row_span(s_cull[lo], ty, rmin & 0xFFFFu, rmax & 0xFFFFu, tx0);
-        if (s_dq[lo] == 2) n = tilecull_trim_span(depth_limit, grid_x, ty, s_depth[lo], tx0, n);
-        if (s_dq[lo] == 3) n = tilecull_trim_span_segments(depth_limit + (size_t)grid_x * grid_y, grid_x, ty, s_depth[lo], tx0, n);
+        const int dq = depth_limit ? s_dq[lo] : 0;
+        if (dq == 2) n = tilecull_trim_span(depth_limit, grid_x, ty, s_depth[lo], tx0, n);
+        if (dq == 3) n = tilecull_trim_span_segments(depth_limit + (size_t)grid_x * grid_y, grid_x, ty, s_depth[lo], tx0, n);
         s_span_key[r] = ty * grid_x + tx0;
         s_span_own[r] = (uint32_t)lo;
       }

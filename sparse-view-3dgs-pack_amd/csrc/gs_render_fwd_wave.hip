@@ -280,32 +280,32 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* 
   }
 }
 
-// gs_export_tile_stop_depth: per tile the largest stop depth of its 3 x 3 neighbourhood (reasons: gs_tilecull.h)
+// gs_export_tile_stop_depth: per tile the largest stop depth of its 3 x 3 neighbourhood, then per aligned run of four
+// tiles of a row the largest of those bounds (reasons: gs_tilecull.h); one launch, both straight from the stop depths
 __global__ void __launch_bounds__(256) stop_depth_bounds_kernel(const float* __restrict__ stop, float* __restrict__ out,
                                                                 int grid_x, int grid_y) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= grid_x * grid_y) return;
-  const int tx = t % grid_x, ty = t / grid_x;
+  const int T = grid_x * grid_y, segs_x = (int)depth_limit_segs_x((uint32_t)grid_x);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T + segs_x * grid_y) return;
+  int x0, x1, ty;  // tile columns whose 3 x 3 neighbourhoods are merged
+  if (i < T) {
+    x0 = x1 = i % grid_x;
+    ty = i / grid_x;
+  } else {
+    const int j = i - T;
+    x0 = 4 * (j % segs_x);
+    x1 = min(x0 + 3, grid_x - 1);
+    ty = j / segs_x;
+  }
   float hi = -__builtin_inff();
   for (int y = max(ty - 1, 0); y <= min(ty + 1, grid_y - 1); y++)
-    for (int x = max(tx - 1, 0); x <= min(tx + 1, grid_x - 1); x++) hi = fmaxf(hi, stop[y * grid_x + x]);
-  out[t] = hi;
-}
-
-__global__ void __launch_bounds__(256) stop_depth_segments_kernel(float* __restrict__ out, int grid_x, int grid_y) {
-  const int segs_x = (int)depth_limit_segs_x((uint32_t)grid_x);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= segs_x * grid_y) return;
-  const int sx = i % segs_x, ty = i / segs_x;
-  float hi = -__builtin_inff();
-  for (int x = 4 * sx; x < min(4 * sx + 4, grid_x); x++) hi = fmaxf(hi, out[ty * grid_x + x]);
-  out[grid_x * grid_y + i] = hi;
+    for (int x = max(x0 - 1, 0); x <= min(x1 + 1, grid_x - 1); x++) hi = fmaxf(hi, stop[y * grid_x + x]);
+  out[i] = hi;
 }
 
 int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, int grid_y, hipStream_t s) {
-  const int T = grid_x * grid_y, S = (int)depth_limit_segs_x((uint32_t)grid_x) * grid_y;
-  hipLaunchKernelGGL(stop_depth_bounds_kernel, dim3((T + 255) / 256), dim3(256), 0, s, stop_depth, out, grid_x, grid_y);
-  hipLaunchKernelGGL(stop_depth_segments_kernel, dim3((S + 255) / 256), dim3(256), 0, s, out, grid_x, grid_y);
+  const int n = (int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y);
+  hipLaunchKernelGGL(stop_depth_bounds_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stop_depth, out, grid_x, grid_y);
   return 0;
 }
 

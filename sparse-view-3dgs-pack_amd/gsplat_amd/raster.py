@@ -341,6 +341,8 @@ class RasterBackend:
             binning = new_binning(cap)
             s = scratch_of(binning, cap, limit)
             render(s)
+            if limit is not None:
+                self.depth_limit_stats["used"] += 1  # (at capture time only: replays do not pass here)
             self.api.call("forward_status", C.byref(s), status.data_ptr(), stream)
             remember(s)
             return (cap, out_color, radii, geom, binning, img, out_invdepth) + tail
