@@ -446,7 +446,7 @@ def main():
             # the blend kernels are bound by VALU issue, not by HBM: report that roof for them
             blend = {}
             for kname in ("render_bwd", "render_fwd"):
-                if kname in stages:
+                if kname in stages and args.config == "c3":  # (the instruction counts are those of the C3 workload)
                     v = valu_roofline(kname, stages[kname]["ms_per_launch"])
                     if v:
                         blend[kname] = v

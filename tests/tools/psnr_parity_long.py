@@ -1,7 +1,11 @@
 """Developer tool / report generator: the PSNR-parity protocol of SURVEY 8d run LONGER than the test does - the same
 training run (BASELINE config-1 size: 10 k Gaussians, 400x400, 3 training views, full LGDWT loss, the reference's
 schedule incl. densification and opacity reset on a compressed timeline) on the HIP backend and on the CPU oracle.
-Writes profiles/r01_psnr_parity.json (per-checkpoint held-out PSNR, training PSNR, loss, number of Gaussians)."""
+Writes gpurun_out/<tag>_psnr_parity[_densify].json (per-checkpoint held-out PSNR, training PSNR, loss, number of
+Gaussians).  The HIP run is done TWICE: two runs of the very same HIP path differ too (float-atomic order of the blend
+backward -> sign flips of near-zero gradients -> Adam, eps 1e-15, turns each into a +-lr step), and that HIP-vs-HIP
+spread is the yardstick for the HIP-vs-oracle gap.
+    python tests/tools/psnr_parity_long.py [iterations] [densify|plain] [tag]"""
 import json
 import math
 import os
@@ -66,15 +70,21 @@ def run(device, Rasterizer, Settings, api, tag):
 
 
 hip, orc = hip_backend(), oracle_lib.get()
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r02"
 h, th = run(torch.device("cuda"), dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, hip.api, "hip   ")
+h2, _ = run(torch.device("cuda"), dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, hip.api, "hip #2")
 o, to = run(torch.device("cpu"), orc.Rasterizer, orc.Settings, orc.api, "oracle")
 rep = dict(protocol="SURVEY 8d PSNR parity, config-1 size (10k Gaussians, 400x400, 3 train / 3 held-out views), "
                     "L1+SSIM+DWT2+patchDWT, Adam, reference schedule%s" % (" with densification every 40 it from 60, "
                                                                         "opacity reset every 150" if DENSIFY else ""),
-           iterations=ITERS, hip=h, oracle=o, seconds=dict(hip=th, oracle=to),
+           iterations=ITERS, hip=h, hip_second_run=h2, oracle=o, seconds=dict(hip=th, oracle=to),
+           hip_vs_hip_max_abs_psnr_test_diff=max(abs(a["psnr_test"] - b["psnr_test"]) for a, b in zip(h, h2)),
+           hip_vs_hip_max_abs_psnr_train_diff=max(abs(a["psnr_train"] - b["psnr_train"]) for a, b in zip(h, h2)),
            max_abs_psnr_test_diff=max(abs(a["psnr_test"] - b["psnr_test"]) for a, b in zip(h, o)),
            max_abs_psnr_train_diff=max(abs(a["psnr_train"] - b["psnr_train"]) for a, b in zip(h, o)))
-name = "r01_psnr_parity%s.json" % ("_densify" if DENSIFY else "")
+name = "%s_psnr_parity%s.json" % (TAG, "_densify" if DENSIFY else "")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(rep, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
-print("max |dPSNR| test %.4f dB, train %.4f dB; %s" % (rep["max_abs_psnr_test_diff"], rep["max_abs_psnr_train_diff"], name))
+print("HIP vs oracle: max |dPSNR| test %.4f dB, train %.4f dB; HIP vs HIP: test %.4f dB, train %.4f dB; %s" % (
+    rep["max_abs_psnr_test_diff"], rep["max_abs_psnr_train_diff"], rep["hip_vs_hip_max_abs_psnr_test_diff"],
+    rep["hip_vs_hip_max_abs_psnr_train_diff"], name))
