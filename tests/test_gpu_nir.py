@@ -91,6 +91,38 @@ def test_fused_pass_equals_two_reference_passes(hip, oracle, kind, P, W, H, deg,
     check_grads({k: v.cpu() for k, v in f_g.items()}, o_g, tag + "_vs_oracle_two_pass")
 
 
+def test_fused_pass_at_c5_size_against_the_oracle_two_pass(hip, oracle):
+    """BASELINE configs[4] geometry - 1 M Gaussians, 1920x1080, SH degree 3 - through the fused 4-channel pass, against
+    the reference's two passes on the CPU oracle (about 10 s): radii equal, both images at 1e-4 up to a bounded number
+    of threshold pixels, every gradient at 1e-4 of its tensor's maximum except the conic -> scale / rotation chain, whose
+    fp32 conditioning at this size puts the ORACLE's own formula ~1e-3 from the float64 result (DESIGN.md 2,
+    tests/test_gpu_fullsize.py measures that chain separately): bounded here at 1e-2."""
+    P, W, H = 1_000_000, 1920, 1080
+    from simple_knn._C import distCUDA2
+    sc = synthetic.trained_like(P, seed=0, sh_degree=3, knn=lambda x: distCUDA2(x.cuda()).cpu())
+    cam = synthetic.orbit_cameras(W, H)[5]
+    bg = torch.zeros(3)
+    g = torch.Generator().manual_seed(9)
+    nir = nir_colors(torch.sigmoid(torch.randn((P, 1, 1), generator=g)), torch.tensor(1.3))
+    dL_rgb = torch.randn((3, H, W), generator=g)
+    dL_nir = torch.randn((1, H, W), generator=g)
+    f_rgb, f_nir, f_radii, f_g = fused(sc, cam, bg, nir, dL_rgb, dL_nir, False)
+    o_rgb, o_nir, o_radii, o_g = two_pass(oracle.Rasterizer, oracle.Settings, sc, cam, bg, nir, torch.device("cpu"),
+                                          dL_rgb, dL_nir, False)
+    assert torch.equal(f_radii, o_radii)
+    bad = ((f_nir - o_nir).abs() > TOL).sum() + ((f_rgb - o_rgb).abs().amax(0) > TOL * max(1.0, float(o_rgb.abs().max()))).sum()
+    print("pixels beyond 1e-4:", int(bad), "of", W * H)
+    assert int(bad) <= W * H // 20000
+    keep = (((f_nir - o_nir).abs()[0] <= 0.2 * TOL) & ((f_rgb - o_rgb).abs().amax(0) <= 0.2 * TOL)).float()
+    if float(keep.min()) == 0.0:  # threshold pixels took the other branch somewhere: compare gradients without them
+        dL_rgb, dL_nir = dL_rgb * keep, dL_nir * keep
+        _, _, _, f_g = fused(sc, cam, bg, nir, dL_rgb, dL_nir, False)
+        _, _, _, o_g = two_pass(oracle.Rasterizer, oracle.Settings, sc, cam, bg, nir, torch.device("cpu"), dL_rgb, dL_nir,
+                                False)
+    from helpers import check_grads
+    check_grads({k: v.cpu() for k, v in f_g.items()}, o_g, "nir_c5_size_vs_oracle_two_pass", chain_tol=1e-2)
+
+
 def test_extra_channel_argument_errors(hip):
     dev = torch.device("cuda")
     sc = synthetic.trained_like(100, seed=1, sh_degree=0)

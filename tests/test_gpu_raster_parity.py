@@ -207,7 +207,7 @@ def test_empty_and_all_culled(hip):
     assert vis.tolist() == [False, True]
 
 
-@pytest.mark.parametrize("P,seed", [(5, 0), (1000, 1), (4097, 2), (100000, 3)])
+@pytest.mark.parametrize("P,seed", [(5, 0), (1000, 1), (4097, 2), (100000, 3), (1000000, 4), (1000000, 5)])
 def test_knn_bit_exact_vs_oracle(hip, oracle, P, seed):
     import numpy as np
     from gsplat_amd.knn import dist2
@@ -216,6 +216,11 @@ def test_knn_bit_exact_vs_oracle(hip, oracle, P, seed):
     pts = torch.from_numpy((rng.random_sample((P, 3)) * 2.6 - 1.3).astype(np.float32))
     if P == 4097:
         pts[100:140] = pts[7]  # duplicates
+    if seed == 5:  # the size the metric is quoted on, clustered like a point cloud (dense blobs + sparse halo + repeats)
+        c = rng.random_sample((64, 3)).astype(np.float32) * 2.0 - 1.0
+        blob = c[rng.randint(0, 64, P)] + (rng.standard_normal((P, 3)) * 0.02).astype(np.float32)
+        pts = torch.where(torch.from_numpy(rng.random_sample((P, 1)) < 0.8), torch.from_numpy(blob), pts)
+        pts[5000:5200] = pts[17]
     ref = dist2(oracle.api, pts)
     out = distCUDA2(pts.cuda()).cpu()
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
