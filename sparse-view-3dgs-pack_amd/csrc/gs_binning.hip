@@ -469,10 +469,120 @@ int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small inputs (the depth order of <= 16 384 Gaussians: BASELINE config 1 has 10 000): the whole LSD sort in ONE workgroup.
+// Twelve launches of ~4.8 us each are pure launch latency at that size (58 of the 515 us of a C1 step); here the 16 waves
+// keep all keys in registers (16 per lane, wave w owns the contiguous slice [1024 w, 1024 w + 1024)), rank them per pass
+// with the same ballot multi-split as rs_scatter_kernel and exchange them through LDS.  Same stable LSD passes, same
+// result bit for bit.
+// ------------------------------------------------------------------------------------------------------------------
+#define RS_SMALL_ITEMS 16
+#define RS_SMALL_MAX (1024 * RS_SMALL_ITEMS)
+__global__ void __launch_bounds__(1024) rs_small_sort_kernel(const uint32_t* __restrict__ kin, const uint32_t* n_dev,
+                                                             uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                             int end_bit) {
+  constexpr int NT = 1024, NW = NT / 64, ITEMS = RS_SMALL_ITEMS;
+  __shared__ uint32_t s_hist[NW][RS_RADIX];
+  __shared__ uint32_t s_key[RS_SMALL_MAX];
+  __shared__ uint32_t s_val[RS_SMALL_MAX];
+  __shared__ uint32_t s_wtot[RS_RADIX / 64];
+  const uint32_t n = min(*n_dev, (uint32_t)RS_SMALL_MAX);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t w0 = (uint32_t)wid * (64 * ITEMS);
+  uint32_t key[ITEMS], val[ITEMS], pre[ITEMS];
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = w0 + r * 64 + lane;
+    key[r] = i < n ? kin[i] : 0xFFFFFFFFu;
+    val[r] = i;
+  }
+  for (int shift = 0; shift < end_bit; shift += RS_BITS) {
+    for (int k = tid; k < NW * RS_RADIX; k += NT) (&s_hist[0][0])[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      const bool valid = w0 + r * 64 + lane < n;
+      const uint32_t d = (key[r] >> shift) & 0xFFu;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < RS_BITS; b++) {
+        const unsigned long long bal = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? bal : ~bal;
+      }
+      const uint32_t rank = __popcll(peers & lt_mask);
+      const uint32_t before = s_hist[wid][d];  // (one wave, program order: see rs_scatter_kernel)
+      pre[r] = before + rank;
+      if (valid && rank == 0) s_hist[wid][d] = before + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    // thread d < 256 owns digit d: exclusive offset of the digit, then of each wave's share of it
+    const bool digit_thread = tid < RS_RADIX;
+    uint32_t cw[NW], tot = 0;
+    if (digit_thread) {
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        cw[w] = s_hist[w][tid];
+        tot += cw[w];
+      }
+    }
+    uint32_t inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (digit_thread && lane == 63) s_wtot[wid] = inc;
+    __syncthreads();
+    if (digit_thread) {
+      uint32_t run = inc - tot;
+      for (int w = 0; w < wid; w++) run += s_wtot[w];
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        s_hist[w][tid] = run;
+        run += cw[w];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      if (w0 + r * 64 + lane < n) {
+        const uint32_t lp = s_hist[wid][(key[r] >> shift) & 0xFFu] + pre[r];
+        s_key[lp] = key[r];
+        s_val[lp] = val[r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      const uint32_t i = w0 + r * 64 + lane;
+      key[r] = i < n ? s_key[i] : 0xFFFFFFFFu;
+      val[r] = i < n ? s_val[i] : 0u;
+    }
+    // (the next pass starts by zeroing s_hist, last read before the barrier above; s_key / s_val are rewritten only
+    // after two more barriers)
+  }
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = w0 + r * 64 + lane;
+    if (i < n) {
+      kout[i] = key[r];
+      vout[i] = val[r];
+    }
+  }
+}
+
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound, int end_bit, int start_buf,
                       const uint32_t* first_keys, hipStream_t s, int debug) {
   int cur = start_buf;
   if (n_bound <= 0) return 0;
+  if (first_keys != nullptr && n_bound <= RS_SMALL_MAX) {
+    const int passes = (end_bit + RS_BITS - 1) / RS_BITS;
+    const int fin = start_buf ^ (passes & 1);  // where the pass-by-pass form would leave the result
+    hipLaunchKernelGGL(rs_small_sort_kernel, dim3(1), dim3(1024), 0, s, first_keys, n_dev, b.keys[fin], b.vals[fin], end_bit);
+    GS_LAUNCH_CHECK(s, debug);
+    return 0;
+  }
   const uint32_t nblk = (uint32_t)((n_bound + RS_TILE - 1) / RS_TILE);
   bool first = true;
   for (int shift = 0; shift < end_bit; shift += RS_BITS) {
