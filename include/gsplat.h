@@ -92,6 +92,12 @@ typedef struct GsGaussians {
   const float* extra_channel;  /* [P] or NULL: a 4th per-Gaussian value blended with the same weights as the colour
                                   (gs_forward_render_x); replaces the reference's second rasterizer pass for the NIR
                                   albedo, mult-dwtgs/gaussian_renderer/__init__.py:151-258 */
+  int32_t raw_activations;     /* 0: opacities / scales / rotations are the activated values, as the reference's rasterizer
+                                  takes them.  1: they are the model's RAW rows (gaussian_model.py:60-78) and the kernels
+                                  apply sigmoid / exp / F.normalize on the fly, with gs_activations_fwd's arithmetic bit for
+                                  bit - so the activated copies are never written nor read.  Honoured by
+                                  gs_forward_geometry and gs_backward_step only (the plain backward returns gradients
+                                  with respect to the activated values: GS_E_UNSUPPORTED with this flag) */
 } GsGaussians;
 
 /* Caller-owned scratch.  geom and img sizes depend on (P, W, H); binning on the capacity in

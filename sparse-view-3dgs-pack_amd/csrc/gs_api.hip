@@ -73,6 +73,7 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   a.scale_modifier = v->scale_modifier;
   a.rotations = g->rotations;
   a.opacities = g->opacities;
+  a.raw_activations = g->raw_activations;
   a.shs = g->shs;
   a.cov3D_precomp = g->cov3D_precomp;
   a.colors_precomp = g->colors_precomp;
@@ -240,6 +241,7 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
   a.scales = g->scales;
   a.rotations = g->rotations;
   a.opacities = g->opacities;
+  a.raw_activations = g->raw_activations;
   a.colors_precomp = g->colors_precomp;
   a.scale_modifier = v->scale_modifier;
   a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : gv.cov3D;
@@ -289,6 +291,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !grads || !dL_dcolor) return GS_E_NULL;
+  if (g->raw_activations && !step) return GS_E_UNSUPPORTED;  // gradients w.r.t. activated values that were never formed
   StepArgs sa;
   if (step && g->P > 0) {
     rc = step_args(g, step, sa);
@@ -350,6 +353,7 @@ int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* 
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !grads) return GS_E_NULL;
+  if (g->raw_activations) return GS_E_UNSUPPORTED;
   if (depth_mode < 0 || depth_mode > 2) return GS_E_SHAPE;
   const int P = g->P;
   if (P == 0) return GS_OK;

@@ -271,7 +271,7 @@ GS_DEV void geometry_backward(const PreprocessBwdArgs& a, int idx, GeomBack& o) 
   }
   // slot GR_ID holds dL/d(inverse depth) (dr_aa) or dL/d(depth) (FSGS generation); only the former enters through t.z
   const Cov2DBack cb = cov2d_backward(mean, c3, a.viewmatrix, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy,
-                                      {g0.z, g0.w, g1.x}, g1.y, a.antialiasing ? a.opacities[idx] : 0.f,
+                                      {g0.z, g0.w, g1.x}, g1.y, a.antialiasing ? load_opacity(a.opacities, idx, a.raw_activations) : 0.f,
                                       a.antialiasing != 0, a.has_invdepth == 1 ? g2.y : 0.f);
   o.dop = cb.dop;
   o.dcov[0] = cb.G.xx; o.dcov[1] = 2.f * cb.G.xy; o.dcov[2] = 2.f * cb.G.xz;
@@ -288,9 +288,9 @@ GS_DEV void geometry_backward(const PreprocessBwdArgs& a, int idx, GeomBack& o) 
   o.dscale = {0.f, 0.f, 0.f};
   o.dq[0] = o.dq[1] = o.dq[2] = o.dq[3] = 0.f;
   if (a.scales) {
-    const V3 scl = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-    const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
-    cov3d_backward(cb.G, scl, a.scale_modifier, {q4.x, q4.y, q4.z, q4.w}, o.dscale, o.dq);
+    const V3 scl = load_scales(a.scales, idx, a.raw_activations);
+    const V4 rq = load_rotation(a.rotations, idx, a.raw_activations);
+    cov3d_backward(cb.G, scl, a.scale_modifier, rq, o.dscale, o.dq);
   }
 }
 

@@ -204,6 +204,7 @@ struct PreprocessArgs {
   const float* extra_channel;  // [P] or NULL
   int tile_cull;  // GsView.tile_cull: 1 = emit only tiles the alpha >= 1/255 ellipse can reach (gs_tilecull.h)
   const float* tile_depth_limit;  // [T] or NULL: depth-limited emission (gs_tilecull.h); only with tile_cull
+  int raw_activations;            // GsGaussians.raw_activations
 };
 int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_t s);
 int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s);
@@ -249,6 +250,7 @@ struct PreprocessBwdArgs {
   float focal_x, focal_y, tan_fovx, tan_fovy;
   int antialiasing;
   int has_invdepth;  // 0: none, 1: inverse-depth image gradient (dr_aa), 2: depth image gradient (FSGS generation)
+  int raw_activations;  // GsGaussians.raw_activations
   const float* grad_rows;  // [P][GR_STRIDE]
   const Splat* splat;
   GsGrads out;

@@ -147,6 +147,29 @@ GS_DEV void cov2d_common(V3 mean, float focal_x, float focal_y, float tan_fovx, 
   o.limy = limy;
 }
 
+// GsGaussians.raw_activations: the model's activations applied where the parameters are read, in the arithmetic of
+// act_fwd_kernel (gs_model.hip) - exp, F.normalize (v / max(|v|, 1e-12)), sigmoid - so that both forms give the same bits.
+// (raw rows live in the flat parameter buffer, where the rotation segment is 16-byte aligned only for P % 4 == 0: scalar loads)
+GS_DEV V3 load_scales(const float* p, int idx, int raw) {
+  const V3 s = {p[3 * (size_t)idx], p[3 * (size_t)idx + 1], p[3 * (size_t)idx + 2]};
+  if (!raw) return s;
+  return {expf(s.x), expf(s.y), expf(s.z)};
+}
+GS_DEV V4 load_rotation(const float* p, int idx, int raw) {
+  if (!raw) {
+    const float4 q4 = reinterpret_cast<const float4*>(p)[idx];
+    return {q4.x, q4.y, q4.z, q4.w};
+  }
+  const float* q = p + 4 * (size_t)idx;
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  const float n = fmaxf(sqrtf(x * x + y * y + z * z + w * w), 1e-12f);
+  return {x / n, y / n, z / n, w / n};
+}
+GS_DEV float load_opacity(const float* p, int idx, int raw) {
+  const float o = p[idx];
+  return raw ? 1.0f / (1.0f + expf(-o)) : o;
+}
+
 // auxiliary.h:21-38
 #define SH_C0 0.28209479177387814f
 #define SH_C1 0.4886025119029199f

@@ -100,9 +100,8 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
         for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[(size_t)idx * 6 + k];
       } else {
         // computeCov3D, forward.cu:114-148
-        V3 sc = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-        const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
-        V4 rq = {q4.x, q4.y, q4.z, q4.w};
+        const V3 sc = load_scales(a.scales, idx, a.raw_activations);
+        const V4 rq = load_rotation(a.rotations, idx, a.raw_activations);
         M3 S = mat3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
         S.c[0][0] = a.scale_modifier * sc.x;
         S.c[1][1] = a.scale_modifier * sc.y;
@@ -181,7 +180,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       sp.x = pix_x;
       sp.y = pix_y;
       sp.cxx = conic.x; sp.cxy = conic.y; sp.cyy = conic.z;
-      sp.opacity = a.opacities[idx] * h_convolution_scaling;
+      sp.opacity = load_opacity(a.opacities, idx, a.raw_activations) * h_convolution_scaling;
       sp.rect_min = minx | (miny << 16);
       sp.rect_max = maxx | (maxy << 16);
       if (a.tile_cull) {

@@ -42,6 +42,7 @@ class GsGaussians(C.Structure):
         ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p),
         ("extra_channel", C.c_void_p),
+        ("raw_activations", C.c_int32),
     ]
 
 

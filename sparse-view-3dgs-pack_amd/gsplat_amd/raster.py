@@ -79,6 +79,11 @@ class RasterBackend:
         # by the caller) - run gs_backward_step (backward + activation backward + view statistics + Adam in the same
         # per-Gaussian kernel) instead of gs_backward; the backward then returns no gradients at all
         self.fused_step = None
+        # one-shot, set together with fused_step by the train step: the opacities / scales / rotations of the next forward
+        # (and of its gs_backward_step) are the model's RAW rows, activated inside the kernels
+        # (GsGaussians.raw_activations): no activation kernel, no activated copies
+        self.raw_activations = False
+        self._raw_backward = False
         # parity probes: keep the backward workspace (the per-Gaussian 16-float gradient rows of the blend backward)
         self.keep_workspace = False
         self.last_workspace = None
@@ -109,8 +114,9 @@ class RasterBackend:
         v.bg, v.viewmatrix, v.projmatrix, v.campos = _ptr(bg), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
         return v
 
-    def _gauss(self, keep, device, means3D, sh, colors, opacities, scales, rotations, cov3D, extra=None):
+    def _gauss(self, keep, device, means3D, sh, colors, opacities, scales, rotations, cov3D, extra=None, raw=False):
         g = GsGaussians()
+        g.raw_activations = int(bool(raw))
         extra = _prep(extra, device)
         keep.append(extra)
         g.extra_channel = _ptr(extra)
@@ -265,6 +271,10 @@ class RasterBackend:
             e = torch.empty((0,), **u8)
             return (0, out_color, radii, e, e.clone(), e.clone(), out_invdepth) + tail
 
+        raw, self.raw_activations = self.raw_activations, False
+        self._raw_backward = raw
+        if raw and (fsgs or extra is not None):
+            raise RuntimeError("raw activations serve the plain RGB rasterizer only")
         cache = self._camera_cache(device, W, H, viewmatrix)
         static = self.static_capacity is not None
         use_order = cache is not None and self.order_hint_on
@@ -297,7 +307,7 @@ class RasterBackend:
         keep = []
         view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
                           degree, prefiltered, antialiasing, debug)
-        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra)
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra, raw=raw)
         stream = self._stream(device)
 
         gb, ib, _, _ = self.scratch_bytes(P, W, H, 0)
@@ -434,13 +444,16 @@ class RasterBackend:
         alloc = torch.empty if P != 0 else torch.zeros
         arena, self.grad_arena = self.grad_arena, None
         step, self.fused_step = self.fused_step, None
+        raw, self._raw_backward = self._raw_backward, False
+        if raw and (step is None or P == 0):
+            raise RuntimeError("a forward on raw activations must be followed by the fused train-step backward")
         if step is not None and P != 0:
             if fsgs or extra is not None:
                 raise RuntimeError("the fused train-step backward serves the plain RGB rasterizer only")
             keep = []
             view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
                               degree, False, antialiasing, debug)
-            g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+            g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, raw=raw)
             dL_dout_color = _prep(dL_dout_color, device)
             dL_dout_invdepth = _prep(dL_dout_invdepth, device)
             _, _, _, wsb = self.scratch_bytes(P, W, H, R)

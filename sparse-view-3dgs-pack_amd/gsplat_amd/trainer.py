@@ -625,11 +625,17 @@ class _TorchAdamWithFeatureSplit:
 
 
 def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifier=1.0, antialiasing=False,
-           debug=False, filter_as_indices=True, clamp=True, fused=False, use_trained_exp=False, camera_index=None):
+           debug=False, filter_as_indices=True, clamp=True, fused=False, use_trained_exp=False, camera_index=None,
+           raw_activations=False):
     """= render() of LGDWT-GS/gaussian_renderer/__init__.py:18-128 (SH evaluated by the rasterizer, scale +
-    rotation given, no exposure): returns {render, viewspace_points, visibility_filter, radii, depth}."""
-    act = pc.fused_activations() if fused else None
-    if act is None:
+    rotation given, no exposure): returns {render, viewspace_points, visibility_filter, radii, depth}.
+    raw_activations: hand the rasterizer the RAW scaling / rotation / opacity rows (the caller has told the backend,
+    RasterBackend.raw_activations: the kernels activate them on the fly) - the fused train step's form."""
+    act = pc.fused_activations() if fused and not raw_activations else None
+    if raw_activations:
+        act = (pc.params["scaling"], pc.params["rotation"], pc.params["opacity"])
+        screenspace_points = torch.empty_like(pc.get_xyz).requires_grad_(True)
+    elif act is None:
         screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
         try:
             screenspace_points.retain_grad()
@@ -793,6 +799,9 @@ class Trainer:
     # so it is simply taken again without limits; until then its loss tensor holds the value of the invalid image - it
     # is overwritten in place.  Anything that reads the model between steps goes through sync() first.
     depth_limit = None
+    # the fused step hands the rasterizer the raw scaling / rotation / opacity rows (GsGaussians.raw_activations): the
+    # activation kernel and its three output tensors disappear from the step; GS_RAW_ACTIVATIONS=0 keeps them
+    RAW_ACTIVATIONS = __import__("os").environ.get("GS_RAW_ACTIVATIONS", "1") != "0"
 
     def sync(self):
         """Settle the verdict of the last depth-limited step (redoing the step if its limits failed)."""
@@ -818,6 +827,7 @@ class Trainer:
             counters = (m.optimizer.t, dict(m.optimizer.seg_steps))
             backend.depth_limit_request = "defer"
         if fused_step:
+            backend.raw_activations = self.RAW_ACTIVATIONS
             backend.fused_step = m.optimizer.fused_request(skip, coef_dev=getattr(self, "_coef_dev", None))
             rows = getattr(self, "rows_override", None)  # parity tests: blend sums to use instead of stage 1
             if rows is not None:
@@ -826,7 +836,8 @@ class Trainer:
             m.arm_grad_arena(backend)
         fused = getattr(self.criterion, "fused", False)
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
-                     clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci)
+                     clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci,
+                     raw_activations=fused_step and self.RAW_ACTIVATIONS)
         mask = None if self.masks is None else self.masks[ci]
         verdict = backend.take_deferred() if deferred else None
         if verdict is not None:

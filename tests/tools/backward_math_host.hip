@@ -16,7 +16,7 @@ extern "C" int bm_backward_from_rows(const GsView* v, const GsGaussians* g, cons
     memset(&splat[i], 0, sizeof(Splat));
     splat[i].clamped = (clamped[3 * i] ? 1u : 0u) | (clamped[3 * i + 1] ? 2u : 0u) | (clamped[3 * i + 2] ? 4u : 0u);
   }
-  PreprocessBwdArgs a;
+  PreprocessBwdArgs a = {};
   a.P = P;
   a.D = v->sh_degree;
   a.M = g->M;
