@@ -187,6 +187,7 @@ def cpu_baseline(cfg, scene, cam, gt, log, views=5, warmups=2):
 
 # wave64 VALU issue peak: 1 024 SIMDs, one instruction per 2 cycles each, 2.4 GHz (MI355X_MICROARCH.md cycle constants)
 VALU_PEAK_GINST = 1024 * 2.4 / 2.0
+SHADER_CLOCK_HZ = 2.4e9
 
 
 def valu_roofline(kernel, ms_per_launch):
@@ -199,10 +200,19 @@ def valu_roofline(kernel, ms_per_launch):
     except Exception:
         return None
     ach = insts / (ms_per_launch * 1e-3) / 1e9
-    return {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-            "frac": ach / VALU_PEAK_GINST, "insts_per_launch": insts, "cycles_at_peak": insts * 2.0 / 1024,
-            "insts_from": "profiles/sq_insts.json (tag %s): SQ_INSTS_VALU per launch on the C3 workload; duration measured "
-                          "in this run" % d.get("tag", "?")}
+    out = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+           "frac": ach / VALU_PEAK_GINST, "insts_per_launch": insts, "cycles_at_peak": insts * 2.0 / 1024,
+           "insts_from": "profiles/sq_insts.json (tag %s): SQ_INSTS_VALU per launch on the C3 workload; duration measured "
+                         "in this run" % d.get("tag", "?")}
+    act = d.get(kernel + "_valu_active_cycles_per_simd")
+    if act:
+        # `frac` prices every wave64 VALU instruction at 2 cycles - the packed-FP32 rate behind the 157 TFLOP/s figure.  This
+        # kernel's instructions are single-issue f32 ops (4 cycles each, transcendentals 8: MI355X_MICROARCH.md "vector-
+        # instruction ISSUE cost"); SQ_ACTIVE_INST_VALU counts the cycles the VALU really spent on them:
+        out["valu_busy_frac"] = float(act) / (ms_per_launch * 1e-3 * SHADER_CLOCK_HZ)
+        out["valu_busy_note"] = ("share of all SIMD cycles of the launch in which the VALU was issuing this kernel's instructions "
+                                 "(SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs, profiles/sq_insts.json) at this run's duration")
+    return out
 
 
 def main():

@@ -124,5 +124,8 @@ if sq:
             for st, kn in (("render_bwd", "render_bwd_wave_kernel"), ("render_fwd", "render_fwd_wave_kernel")):
                 if k == kn:
                     sq_insts[st] = m.get("SQ_INSTS_VALU", 0)   # wave-instructions per launch (mean over the launches)
+                    # SIMD cycles the VALU spent issuing this kernel's instructions (SQ_ACTIVE_INST_VALU counts quad-cycles)
+                    sq_insts[st + "_valu_active_cycles_per_simd"] = m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024
+                    sq_insts[st + "_valu_active_share_under_profiler"] = m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles
     json.dump(sq_insts, open(os.path.join(here, "sq_insts.json"), "w"), indent=1)
     print(open(os.path.join(here, "%s_sq_counters.csv" % tag)).read())
