@@ -124,6 +124,10 @@ typedef struct GsScratch {
                                       were, every output and gradient equals that of the uncut lists.  When the flag is set
                                       the outputs are NOT valid: repeat gs_forward_geometry + gs_forward_render without
                                       limits.  The same pointer and contents must be passed to both forward calls. */
+  uint32_t* tile_order_out;        /* optional: gs_forward_render also writes what gs_export_tile_order would return here */
+  float* tile_depth_limit_out;     /* optional: ... and what gs_export_tile_stop_depth would return here (one launch serves
+                                      both; the buffers may be the ones passed as tile_order_hint / tile_depth_limit: they
+                                      are read before they are written) */
 } GsScratch;
 
 /* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by

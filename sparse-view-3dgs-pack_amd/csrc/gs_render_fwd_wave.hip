@@ -230,8 +230,20 @@ int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int 
 // that XCD walks its own band longest-first.  Slots past a band's end hold 0xFFFFFFFF (grid padded to 8 * ceil(T/8)).
 #define TO_THREADS 1024
 #define TO_BUCKETS 2048
+__device__ __forceinline__ void stop_depth_bound_item(const float* __restrict__ stop, float* __restrict__ out, int grid_x,
+                                                      int grid_y, int i);
+// The same launch also serves the two per-camera exports when the caller asked for them in GsScratch (tile_order_out,
+// tile_depth_limit_out): the order is written twice, and the eight workgroups share the depth bounds among them.
 __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* __restrict__ tile_work,
-                                                                uint32_t* __restrict__ tile_order, int T, int per_band) {
+                                                                uint32_t* __restrict__ tile_order, int T, int per_band,
+                                                                uint32_t* __restrict__ order_out,
+                                                                const float* __restrict__ stop_depth,
+                                                                float* __restrict__ limit_out, int grid_x, int grid_y) {
+  if (limit_out) {
+    const int n = (int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y);
+    for (int i = blockIdx.x * TO_THREADS + threadIdx.x; i < n; i += 8 * TO_THREADS)
+      stop_depth_bound_item(stop_depth, limit_out, grid_x, grid_y, i);
+  }
   __shared__ uint32_t s_cnt[TO_BUCKETS];
   __shared__ uint32_t s_part[TO_THREADS / 64];
   __shared__ uint32_t s_max;
@@ -244,7 +256,10 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* 
   for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
   if ((tid & 63) == 0) s_part[tid >> 6] = m;
   for (int b = tid; b < TO_BUCKETS; b += TO_THREADS) s_cnt[b] = 0;
-  for (int i = tid; i < per_band; i += TO_THREADS) tile_order[band + 8 * i] = 0xFFFFFFFFu;  // slots past the band's end
+  for (int i = tid; i < per_band; i += TO_THREADS) {  // slots past the band's end
+    tile_order[band + 8 * i] = 0xFFFFFFFFu;
+    if (order_out) order_out[band + 8 * i] = 0xFFFFFFFFu;
+  }
   __syncthreads();
   if (tid == 0) {
     uint32_t mm = 0;
@@ -277,16 +292,15 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* 
   for (int t = t_lo + tid; t < t_hi; t += TO_THREADS) {
     const uint32_t pos = atomicAdd(&s_cnt[TO_BUCKETS - 1 - (tile_work[t] >> shift)], 1u);
     tile_order[band + 8 * pos] = (uint32_t)t;
+    if (order_out) order_out[band + 8 * pos] = (uint32_t)t;
   }
 }
 
 // gs_export_tile_stop_depth: per tile the largest stop depth of its 3 x 3 neighbourhood, then per aligned run of four
 // tiles of a row the largest of those bounds (reasons: gs_tilecull.h); one launch, both straight from the stop depths
-__global__ void __launch_bounds__(256) stop_depth_bounds_kernel(const float* __restrict__ stop, float* __restrict__ out,
-                                                                int grid_x, int grid_y) {
+__device__ __forceinline__ void stop_depth_bound_item(const float* __restrict__ stop, float* __restrict__ out, int grid_x,
+                                                      int grid_y, int i) {
   const int T = grid_x * grid_y, segs_x = (int)depth_limit_segs_x((uint32_t)grid_x);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= T + segs_x * grid_y) return;
   int x0, x1, ty;  // tile columns whose 3 x 3 neighbourhoods are merged
   if (i < T) {
     x0 = x1 = i % grid_x;
@@ -302,6 +316,11 @@ __global__ void __launch_bounds__(256) stop_depth_bounds_kernel(const float* __r
     for (int x = max(x0 - 1, 0); x <= min(x1 + 1, grid_x - 1); x++) hi = fmaxf(hi, stop[y * grid_x + x]);
   out[i] = hi;
 }
+__global__ void __launch_bounds__(256) stop_depth_bounds_kernel(const float* __restrict__ stop, float* __restrict__ out,
+                                                                int grid_x, int grid_y) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < (int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y)) stop_depth_bound_item(stop, out, grid_x, grid_y, i);
+}
 
 int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, int grid_y, hipStream_t s) {
   const int n = (int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y);
@@ -309,7 +328,9 @@ int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, in
   return 0;
 }
 
-int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, hipStream_t s) {
-  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(TO_THREADS), 0, s, tile_work, tile_order, T, (T + 7) / 8);
+int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, uint32_t* order_out, const float* stop_depth,
+                      float* limit_out, int grid_x, int grid_y, hipStream_t s) {
+  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(TO_THREADS), 0, s, tile_work, tile_order, T, (T + 7) / 8, order_out,
+                     stop_depth, limit_out, grid_x, grid_y);
   return 0;
 }

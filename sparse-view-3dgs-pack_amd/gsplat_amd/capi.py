@@ -57,6 +57,8 @@ class GsScratch(C.Structure):
         ("binning_capacity", C.c_int64),
         ("tile_order_hint", C.c_void_p),
         ("tile_depth_limit", C.c_void_p),
+        ("tile_order_out", C.c_void_p),
+        ("tile_depth_limit_out", C.c_void_p),
     ]
 
 

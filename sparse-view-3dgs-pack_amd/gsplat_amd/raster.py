@@ -294,14 +294,18 @@ class RasterBackend:
         def render(scratch):
             if use_order and cache["order_ok"]:
                 scratch.tile_order_hint = cache["order"].data_ptr()
+            # what this view measures becomes the hint of this camera's next visit: written by the forward's last launch
+            # straight into the camera's buffers (they are read - as this view's hints - before they are written)
+            if use_order:
+                scratch.tile_order_out = cache["order"].data_ptr()
+            if use_limit:
+                scratch.tile_depth_limit_out = cache["limit"].data_ptr()
             self._render(scratch, fsgs, extra, view, g, out_color, out_invdepth, out_extra, stream)
 
-        def remember(scratch):  # what this view measured becomes the hint of this camera's next visit
+        def remember(scratch):
             if use_order:
-                self.api.call("export_tile_order", C.byref(scratch), W, H, cache["order"].data_ptr(), stream)
                 cache["order_ok"] = True
             if use_limit:
-                self.api.call("export_tile_stop_depth", C.byref(scratch), W, H, cache["limit"].data_ptr(), stream)
                 cache["limit_ok"] = True
 
         keep = []
