@@ -243,6 +243,7 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
   a.rotations = g->rotations;
   a.opacities = g->opacities;
   a.raw_activations = g->raw_activations;
+  a.skip_uninstanced = 0;
   a.colors_precomp = g->colors_precomp;
   a.scale_modifier = v->scale_modifier;
   a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : gv.cov3D;
@@ -328,6 +329,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     GS_LAUNCH_CHECK(s, v->debug);
   }
   PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, grads);
+  a.skip_uninstanced = v->tile_cull ? 1 : 0;  // (with the reference's lists every visible Gaussian has instances)
   if (step) {
     GS_PROF(ST_BWD_STEP, s);
     sa.hdr = gv.hdr;

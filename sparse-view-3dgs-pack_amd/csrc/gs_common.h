@@ -252,6 +252,8 @@ struct PreprocessBwdArgs {
   int antialiasing;
   int has_invdepth;  // 0: none, 1: inverse-depth image gradient (dr_aa), 2: depth image gradient (FSGS generation)
   int raw_activations;  // GsGaussians.raw_activations
+  int skip_uninstanced;  // rows come from the blend backward of THIS forward: a Gaussian that emitted no instance (culled spans,
+                         // depth limits) has all-zero sums and so all-zero gradients - its geometry / SH backward is skipped
   const float* grad_rows;  // [P][GR_STRIDE]
   const Splat* splat;
   GsGrads out;

@@ -144,35 +144,6 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       get_rect(pix_x, pix_y, radius_i, a.grid_x, a.grid_y, minx, miny, maxx, maxy);
       if ((maxx - minx) * (maxy - miny) == 0) break;
 
-      if (a.colors_precomp == nullptr) {
-        V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
-        V3 rgb;
-        uint32_t cl = 0;
-        if (a.M == 16) {
-          ShRegs sh;
-          const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
-          const int nvec = a.D == 0 ? 1 : (a.D == 1 ? 3 : (a.D == 2 ? 7 : 12));
-#pragma unroll
-          for (int k = 0; k < 12; k++) {
-            if (k < nvec) {
-              float4 v = src[k];
-              sh.f[4 * k] = v.x; sh.f[4 * k + 1] = v.y; sh.f[4 * k + 2] = v.z; sh.f[4 * k + 3] = v.w;
-            } else {
-              sh.f[4 * k] = sh.f[4 * k + 1] = sh.f[4 * k + 2] = sh.f[4 * k + 3] = 0.f;
-            }
-          }
-          rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
-        } else {
-          ShMem sh{a.shs + (size_t)idx * a.M * 3};
-          rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
-        }
-        sp.r = rgb.x; sp.g = rgb.y; sp.b = rgb.z;
-        sp.clamped = cl;
-      } else {
-        sp.r = a.colors_precomp[3 * idx];
-        sp.g = a.colors_precomp[3 * idx + 1];
-        sp.b = a.colors_precomp[3 * idx + 2];
-      }
       sp.depth = p_view.z;
       sp.invdepth = 1 / p_view.z;
       radius_out = radius_i;
@@ -234,6 +205,39 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
         }
       } else {
         tiles = (maxy - miny) * (maxx - minx);
+      }
+      // the colour comes last: a Gaussian whose every pair the depth limits removed is blended nowhere, so its 192 B of SH
+      // coefficients are neither read nor evaluated (its gradient is zero as well, see preprocess_bwd)
+      if (!(a.tile_depth_limit && tiles == 0)) {
+        if (a.colors_precomp == nullptr) {
+          V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
+          V3 rgb;
+          uint32_t cl = 0;
+          if (a.M == 16) {
+            ShRegs sh;
+            const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
+            const int nvec = a.D == 0 ? 1 : (a.D == 1 ? 3 : (a.D == 2 ? 7 : 12));
+  #pragma unroll
+            for (int k = 0; k < 12; k++) {
+              if (k < nvec) {
+                float4 v = src[k];
+                sh.f[4 * k] = v.x; sh.f[4 * k + 1] = v.y; sh.f[4 * k + 2] = v.z; sh.f[4 * k + 3] = v.w;
+              } else {
+                sh.f[4 * k] = sh.f[4 * k + 1] = sh.f[4 * k + 2] = sh.f[4 * k + 3] = 0.f;
+              }
+            }
+            rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
+          } else {
+            ShMem sh{a.shs + (size_t)idx * a.M * 3};
+            rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
+          }
+          sp.r = rgb.x; sp.g = rgb.y; sp.b = rgb.z;
+          sp.clamped |= cl;  // (bits 8-9 already hold the depth-limit verdict)
+        } else {
+          sp.r = a.colors_precomp[3 * idx];
+          sp.g = a.colors_precomp[3 * idx + 1];
+          sp.b = a.colors_precomp[3 * idx + 2];
+        }
       }
       sp.tiles = tiles;
     } while (false);

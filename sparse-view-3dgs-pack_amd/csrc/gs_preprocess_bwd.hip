@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_kernel(PreprocessB
     for (int k = 0; k < nfl_row; k++) dsh.p[k] = 0.f;
   }
 
-  if (visible) geometry_backward(a, idx, gb);
+  const bool active = visible && !(a.skip_uninstanced && a.splat[idx].tiles == 0);  // see PreprocessBwdArgs
+  if (active) geometry_backward(a, idx, gb);
 
   // geometry outputs leave first (their registers are free again before the 48 SH coefficients arrive); every row is
   // written, zeros when culled
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_kernel(PreprocessB
     }
   }
 
-  if (visible && a.shs) gb.dmean = gb.dmean + sh_backward_row(a, idx, gb.dcolor, dsh);
+  if (active && a.shs) gb.dmean = gb.dmean + sh_backward_row(a, idx, gb.dcolor, dsh);
   if (in_range && o.dL_dmeans3D) {
     o.dL_dmeans3D[3 * idx] = gb.dmean.x;
     o.dL_dmeans3D[3 * idx + 1] = gb.dmean.y;
@@ -203,7 +204,10 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   ShSink dsh{s_sh + tid * SH_LDS_ROW, true};
 #pragma unroll
   for (int k = 0; k < SH_LDS_ROW; k++) dsh.p[k] = 0.f;
-  if (visible) geometry_backward(a, idx, gb);
+  // a Gaussian that emitted no instance (culled spans, depth limits) has all-zero blend sums, hence zero gradients: it
+  // still counts as seen (statistics) and still takes its Adam step, but its records, sums and SH row are not read
+  const bool active = visible && !(a.skip_uninstanced && a.splat[idx].tiles == 0);
+  if (active) geometry_backward(a, idx, gb);
 
   // ---- view statistics (train.py:266-268, gaussian_model.py:471-473)
   if (in_range && visible && st.max_radii2D) {
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
     for (int k = 0; k < 4; k++) s_g[SG_ROT + 4 * tid + k] = g[k];
   }
   // ---- SH half: basis values and colour gradient to the LDS row; the view-direction part completes dL_dmean
-  if (visible) gb.dmean = gb.dmean + sh_backward_row(a, idx, gb.dcolor, dsh);
+  if (active) gb.dmean = gb.dmean + sh_backward_row(a, idx, gb.dcolor, dsh);
   s_g[SG_XYZ + 3 * tid] = gb.dmean.x;
   s_g[SG_XYZ + 3 * tid + 1] = gb.dmean.y;
   s_g[SG_XYZ + 3 * tid + 2] = gb.dmean.z;
