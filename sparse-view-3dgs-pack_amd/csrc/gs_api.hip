@@ -161,7 +161,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
     {  // 1. depth order of the P Gaussians: 4 passes; pass 0 reads the keys preprocess wrote (kept intact, so the
        //    phase can be re-run), then half 1 -> 0 -> 1 -> 0: the order ends in gsort.vals[0]
       GS_PROF(ST_SORT_DEPTH, s);
-      rc = launch_radix_sort(gv.gsort, &gv.hdr->P, P, 32, 0, gv.depth_keys, s, v->debug);
+      rc = launch_radix_sort(gv.gsort, &gv.hdr->P, P, 32, 0, gv.depth_keys, s, v->debug, &gv.hdr->n_ordered);
       if (rc) return rc;
     }
     // 2. instances in depth order; 3. stable partition by tile id.  The unsorted list goes into the ping-pong
@@ -171,7 +171,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
     const int start = passes & 1;
     {
       GS_PROF(ST_DUPLICATE, s);
-      rc = launch_emit_instances(gv, P, gx, gy, v->tile_cull, sc->tile_depth_limit, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
+      rc = launch_emit_instances(gv, P, &gv.hdr->n_ordered, gx, gy, v->tile_cull, sc->tile_depth_limit, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
       if (rc) return rc;
     }
     {

@@ -47,8 +47,12 @@ __global__ void __launch_bounds__(GS_BLOCK) bin_prepare_kernel(GeomHeader* hdr, 
 // chain: global load -> LDS atomics, serialised where lanes share a digit -> barrier -> store), so the chain is made
 // short rather than the workgroup small: with 256 threads (16 rounds per wave) a pass took 18 us at 9.8 M keys.
 #define RS_HIST_THREADS 1024
+// drop_max (first pass of the depth sort): keys 0xFFFFFFFF - Gaussians that emit no instance: culled, or cut away entirely
+// by the depth limits, 80 % of them at the bench workload - are not counted and not scattered: the pass filters while it
+// sorts, and the later passes (and everything downstream of the order) handle the survivors only.
 __global__ void __launch_bounds__(RS_HIST_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* n_dev,
-                                                                  int shift, uint32_t* __restrict__ hist, uint32_t nblk) {
+                                                                  int shift, uint32_t* __restrict__ hist, uint32_t nblk,
+                                                                  int drop_max) {
   __shared__ uint32_t h[RS_HIST_THREADS / 64][RS_RADIX];  // one private histogram per wave
   const uint32_t n = *n_dev;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -67,7 +71,7 @@ __global__ void __launch_bounds__(RS_HIST_THREADS) rs_hist_kernel(const uint32_t
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
       const uint32_t i = w0 + r * 64 + lane;
-      if (i < n) atomicAdd(&h[wid][(k[r] >> shift) & 0xFFu], 1u);
+      if (i < n && !(drop_max && k[r] == 0xFFFFFFFFu)) atomicAdd(&h[wid][(k[r] >> shift) & 0xFFu], 1u);
     }
   }
   __syncthreads();
@@ -158,7 +162,8 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                         const uint32_t* n_dev, int shift,
                                                         const uint32_t* __restrict__ hist, uint32_t nblk,
-                                                        const uint32_t* __restrict__ totals) {
+                                                        const uint32_t* __restrict__ totals, int drop_max,
+                                                        uint32_t* __restrict__ n_kept) {
   constexpr int NW = NT / 64;               // waves; wave w ranks the contiguous RS_TILE / NW keys [w0, w0 + ...)
   constexpr int ITEMS = RS_TILE / NT;       // keys per thread = ranking rounds per wave
   static_assert(NT >= RS_RADIX && RS_TILE % NT == 0, "one thread per digit in phase 2");
@@ -180,10 +185,11 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
     key[r] = valid ? kin[i] : 0xFFFFFFFFu;
     val[r] = valid ? (vin ? vin[i] : i) : 0u;
   }
+  __shared__ uint32_t s_cnt;  // keys of this tile that take part (all of them unless drop_max)
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = w0 + r * 64 + lane;
-    const bool valid = i < n;
+    const bool valid = i < n && !(drop_max && key[r] == 0xFFFFFFFFu);
     const uint32_t d = (key[r] >> shift) & 0xFFu;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -237,6 +243,10 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
       gbase += s_gtot[w];
     }
     s_delta[tid] = gbase + hist[(size_t)tid * nblk + blockIdx.x] - loc;
+    if (tid == RS_RADIX - 1) {
+      s_cnt = loc + tot;                                     // end of the last digit's run = keys that take part
+      if (n_kept && blockIdx.x == 0) *n_kept = gbase + gt;   // ... and in the whole array
+    }
     uint32_t run = loc;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
@@ -259,7 +269,7 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
     }
   }
   __syncthreads();
-  const uint32_t cnt = min((uint32_t)RS_TILE, n - t0);
+  const uint32_t cnt = s_cnt;
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = r * NT + tid;
@@ -277,11 +287,12 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
 // ------------------------------------------------------------------------------------------------
 // per-workgroup sums of tiles_touched in depth order
 __global__ void __launch_bounds__(GS_BLOCK) sorted_block_sums_kernel(const uint32_t* __restrict__ order,
-                                                                     const uint32_t* __restrict__ tiles_touched, int P,
+                                                                     const uint32_t* __restrict__ tiles_touched,
+                                                                     const uint32_t* __restrict__ n_ordered,
                                                                      uint32_t* __restrict__ sums) {
   __shared__ uint32_t red[GS_BLOCK / 64];
-  const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
-  uint32_t v = (i < P) ? tiles_touched[order[i]] : 0u;
+  const uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
+  uint32_t v = (i < *n_ordered) ? tiles_touched[order[i]] : 0u;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -313,7 +324,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t
   return woff + inc - v;
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, uint32_t grid_x, uint32_t grid_y, int tile_cull,
+__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, const uint32_t* __restrict__ n_ordered, uint32_t grid_x,
+                                                             uint32_t grid_y, int tile_cull,
                                                              const float* __restrict__ depth_limit,
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ block_base,
@@ -331,10 +343,10 @@ __global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, int P, 
   __shared__ uint32_t s_span_own[DUP_RC];      // owner (index into s_id)
   if (g.hdr->overflow) return;
   const int tid = threadIdx.x;
-  const int i = blockIdx.x * GS_BLOCK + tid;
+  const uint32_t i = blockIdx.x * GS_BLOCK + tid;
   uint32_t tiles = 0, rows = 0;
   s_dq[tid] = 0;  // (only Gaussians with culled spans AND depth limits carry a verdict; everything else: spans as they are)
-  if (i < P) {
+  if (i < *n_ordered) {
     const uint32_t id = order[i];
     const float4* rec = reinterpret_cast<const float4*>(&g.splat[id]);
     const uint4 tail = reinterpret_cast<const uint4*>(rec)[3];  // rect_min, rect_max, tiles, clamped
@@ -480,7 +492,7 @@ int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T
 #define RS_SMALL_MAX (1024 * RS_SMALL_ITEMS)
 __global__ void __launch_bounds__(1024) rs_small_sort_kernel(const uint32_t* __restrict__ kin, const uint32_t* n_dev,
                                                              uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                             int end_bit) {
+                                                             int end_bit, uint32_t* __restrict__ n_kept) {
   constexpr int NT = 1024, NW = NT / 64, ITEMS = RS_SMALL_ITEMS;
   __shared__ uint32_t s_hist[NW][RS_RADIX];
   __shared__ uint32_t s_key[RS_SMALL_MAX];
@@ -488,6 +500,7 @@ __global__ void __launch_bounds__(1024) rs_small_sort_kernel(const uint32_t* __r
   __shared__ uint32_t s_wtot[RS_RADIX / 64];
   const uint32_t n = min(*n_dev, (uint32_t)RS_SMALL_MAX);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (n_kept && tid == 0) *n_kept = n;  // (nothing is dropped at this size: Gaussians without instances sort to the end)
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint32_t w0 = (uint32_t)wid * (64 * ITEMS);
   uint32_t key[ITEMS], val[ITEMS], pre[ITEMS];
@@ -573,13 +586,14 @@ __global__ void __launch_bounds__(1024) rs_small_sort_kernel(const uint32_t* __r
 }
 
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound, int end_bit, int start_buf,
-                      const uint32_t* first_keys, hipStream_t s, int debug) {
+                      const uint32_t* first_keys, hipStream_t s, int debug, uint32_t* n_kept) {
   int cur = start_buf;
   if (n_bound <= 0) return 0;
   if (first_keys != nullptr && n_bound <= RS_SMALL_MAX) {
     const int passes = (end_bit + RS_BITS - 1) / RS_BITS;
     const int fin = start_buf ^ (passes & 1);  // where the pass-by-pass form would leave the result
-    hipLaunchKernelGGL(rs_small_sort_kernel, dim3(1), dim3(1024), 0, s, first_keys, n_dev, b.keys[fin], b.vals[fin], end_bit);
+    hipLaunchKernelGGL(rs_small_sort_kernel, dim3(1), dim3(1024), 0, s, first_keys, n_dev, b.keys[fin], b.vals[fin], end_bit,
+                       n_kept);
     GS_LAUNCH_CHECK(s, debug);
     return 0;
   }
@@ -589,28 +603,31 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
     const bool ext = first && first_keys != nullptr;
     const uint32_t* kin = ext ? first_keys : b.keys[cur];
     const uint32_t* vin = ext ? nullptr : b.vals[cur];
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, kin, n_dev, shift, b.hist, nblk);
+    const int drop = ext && n_kept ? 1 : 0;  // the first pass of the depth sort filters (see rs_hist_kernel)
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, kin, n_dev, shift, b.hist, nblk, drop);
     GS_LAUNCH_CHECK(s, debug);
     hipLaunchKernelGGL(rs_rowscan_kernel, dim3(RS_RADIX), dim3(GS_BLOCK), 0, s, b.hist, nblk, b.scan_tmp);
     GS_LAUNCH_CHECK(s, debug);
     // 512 threads per 4096-key tile (8 ranking rounds per wave): 0.213 ms for the two instance passes against 0.226 with
     // 256 threads and 0.217 with 1024 - the pass is bound by one workgroup's dependent chain, not by throughput
     hipLaunchKernelGGL(rs_scatter_kernel<RS_SCATTER_THREADS>, dim3(nblk), dim3(RS_SCATTER_THREADS), 0, s, kin, vin,
-                       b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, shift, b.hist, nblk, b.scan_tmp);
+                       b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, shift, b.hist, nblk, b.scan_tmp, drop, drop ? n_kept : nullptr);
     GS_LAUNCH_CHECK(s, debug);
+    if (drop) n_dev = n_kept;  // the later passes see the survivors only
     cur ^= 1;
     first = false;
   }
   return 0;
 }
 
-int launch_emit_instances(const GeomView& g, int P, int grid_x, int grid_y, int tile_cull, const float* tile_depth_limit,
-                          const uint32_t* order, uint32_t* tkeys, uint32_t* tvals, hipStream_t s, int debug) {
+int launch_emit_instances(const GeomView& g, int P, const uint32_t* n_ordered, int grid_x, int grid_y, int tile_cull,
+                          const float* tile_depth_limit, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals, hipStream_t s,
+                          int debug) {
   const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
-  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, order, g.tiles_touched, P, g.sorted_sums);
+  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, order, g.tiles_touched, n_ordered, g.sorted_sums);
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, g.sorted_sums, nb);
   GS_LAUNCH_CHECK(s, debug);
-  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, P, (uint32_t)grid_x, (uint32_t)grid_y,
+  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, n_ordered, (uint32_t)grid_x, (uint32_t)grid_y,
                      tile_cull, tile_cull ? tile_depth_limit : nullptr, order, g.sorted_sums, tkeys, tvals);
   GS_LAUNCH_CHECK(s, debug);
   return 0;

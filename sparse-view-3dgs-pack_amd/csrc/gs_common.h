@@ -30,7 +30,8 @@ struct GeomHeader {
   uint32_t zero;          // (the first 16 bytes are what gs_forward_status copies out)
   uint32_t P;
   uint32_t sort_n;        // instances the binning stage really processes: overflow ? 0 : num_rendered
-  uint32_t pad[58];
+  uint32_t n_ordered;     // Gaussians in the depth order = those that emit instances (the sort's first pass drops the rest)
+  uint32_t pad[57];
 };
 static_assert(sizeof(GeomHeader) == 256, "header is one 256-B block");
 
@@ -213,8 +214,8 @@ int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, ui
 int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T, hipStream_t s);
 // first_keys != NULL: the first pass reads its keys from there (left untouched) and takes value = index
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
-                      const uint32_t* first_keys, hipStream_t s, int debug);
-int launch_emit_instances(const GeomView& g, int P, int grid_x, int grid_y, int tile_cull, const float* tile_depth_limit,
+                      const uint32_t* first_keys, hipStream_t s, int debug, uint32_t* n_kept = nullptr);
+int launch_emit_instances(const GeomView& g, int P, const uint32_t* n_ordered, int grid_x, int grid_y, int tile_cull, const float* tile_depth_limit,
                           const uint32_t* order, uint32_t* tkeys, uint32_t* tvals, hipStream_t s, int debug);
 int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
                        hipStream_t s);
