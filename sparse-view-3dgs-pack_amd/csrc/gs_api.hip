@@ -244,6 +244,7 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
   a.opacities = g->opacities;
   a.raw_activations = g->raw_activations;
   a.skip_uninstanced = 0;
+  a.tiles_touched = gv.tiles_touched;
   a.colors_precomp = g->colors_precomp;
   a.scale_modifier = v->scale_modifier;
   a.cov3D = g->cov3D_precomp ? g->cov3D_precomp : gv.cov3D;
@@ -318,7 +319,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     rows = const_cast<float*>(step->rows_override);
   } else {
     GS_PROF(ST_BWD_MEMSET, s);
-    launch_zero_rows(rows, (size_t)P * GR_STRIDE, s);
+    launch_zero_rows(rows, (size_t)P, v->tile_cull ? gv.tiles_touched : nullptr, s);
   }
   if (num_rendered > 0 && !given_rows) {
     {

@@ -348,9 +348,12 @@ __global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, const u
   s_dq[tid] = 0;  // (only Gaussians with culled spans AND depth limits carry a verdict; everything else: spans as they are)
   if (i < *n_ordered) {
     const uint32_t id = order[i];
+    // (the count comes from tiles_touched: a Gaussian the depth limits removed entirely has no record at all, and the
+    // one-workgroup sort of small scenes keeps such Gaussians in the order)
+    tiles = g.tiles_touched[id];
     const float4* rec = reinterpret_cast<const float4*>(&g.splat[id]);
-    const uint4 tail = reinterpret_cast<const uint4*>(rec)[3];  // rect_min, rect_max, tiles, clamped
-    tiles = tail.z;
+    uint4 tail = make_uint4(0u, 0u, 0u, 0u);
+    if (tiles) tail = reinterpret_cast<const uint4*>(rec)[3];  // rect_min, rect_max, tiles, clamped
     s_id[tid] = id;
     s_rmin[tid] = tail.x;
     s_rmax[tid] = tail.y;

@@ -229,7 +229,7 @@ int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int 
 int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, int grid_y, hipStream_t s);
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, uint32_t* order_out, const float* stop_depth,
                       float* limit_out, int grid_x, int grid_y, hipStream_t s);
-int launch_zero_rows(float* rows, size_t n_floats, hipStream_t s);
+int launch_zero_rows(float* rows, size_t P, const uint32_t* tiles_touched, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                            const uint32_t* tile_work, const uint32_t* tile_order, const float* dL_dpix,
@@ -256,6 +256,7 @@ struct PreprocessBwdArgs {
   int skip_uninstanced;  // rows come from the blend backward of THIS forward: a Gaussian that emitted no instance (culled spans,
                          // depth limits) has all-zero sums and so all-zero gradients - its geometry / SH backward is skipped
   const float* grad_rows;  // [P][GR_STRIDE]
+  const uint32_t* tiles_touched;  // [P] instances each Gaussian emitted in this forward (skip_uninstanced)
   const Splat* splat;
   GsGrads out;
 };

@@ -242,10 +242,15 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       sp.tiles = tiles;
     } while (false);
 
-    float4* dst = reinterpret_cast<float4*>(&g.splat[idx]);
-    const float4* srcv = reinterpret_cast<const float4*>(&sp);
-    dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2]; dst[3] = srcv[3];
-    if (a.cov3D_precomp == nullptr) {
+    // a Gaussian the depth limits removed entirely leaves no record and no covariance behind: nothing downstream reads
+    // them (it is not in the depth order, no list names it, and the backward skips it on tiles_touched == 0)
+    const bool write_record = !(a.tile_depth_limit && tiles == 0 && radius_out > 0);
+    if (write_record) {
+      float4* dst = reinterpret_cast<float4*>(&g.splat[idx]);
+      const float4* srcv = reinterpret_cast<const float4*>(&sp);
+      dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2]; dst[3] = srcv[3];
+    }
+    if (a.cov3D_precomp == nullptr && write_record) {
       float2* cd = reinterpret_cast<float2*>(g.cov3D + (size_t)idx * 6);
       if (!write_cov) { cov3D[0] = cov3D[1] = cov3D[2] = cov3D[3] = cov3D[4] = cov3D[5] = 0.f; }
       cd[0] = make_float2(cov3D[0], cov3D[1]);

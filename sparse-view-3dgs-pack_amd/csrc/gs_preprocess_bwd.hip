@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_kernel(PreprocessB
     for (int k = 0; k < nfl_row; k++) dsh.p[k] = 0.f;
   }
 
-  const bool active = visible && !(a.skip_uninstanced && a.splat[idx].tiles == 0);  // see PreprocessBwdArgs
+  const bool active = visible && !(a.skip_uninstanced && a.tiles_touched[idx] == 0);  // see PreprocessBwdArgs
   if (active) geometry_backward(a, idx, gb);
 
   // geometry outputs leave first (their registers are free again before the 48 SH coefficients arrive); every row is
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   for (int k = 0; k < SH_LDS_ROW; k++) dsh.p[k] = 0.f;
   // a Gaussian that emitted no instance (culled spans, depth limits) has all-zero blend sums, hence zero gradients: it
   // still counts as seen (statistics) and still takes its Adam step, but its records, sums and SH row are not read
-  const bool active = visible && !(a.skip_uninstanced && a.splat[idx].tiles == 0);
+  const bool active = visible && !(a.skip_uninstanced && a.tiles_touched[idx] == 0);
   if (active) geometry_backward(a, idx, gb);
 
   // ---- view statistics (train.py:266-268, gaussian_model.py:471-473)

@@ -244,15 +244,18 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
   }
 }
 
-// zero fill of the gradient rows
-__global__ void __launch_bounds__(GS_BLOCK) zero_rows_kernel(float4* __restrict__ p, size_t n4) {
+// zero fill of the gradient rows (GR_STRIDE = 16 floats = four float4 per row).  With tiles_touched given only the rows of
+// Gaussians that emitted instances are cleared: no atomic lands anywhere else and the per-Gaussian stage does not read the
+// others (PreprocessBwdArgs.skip_uninstanced) - a fifth of the rows with depth-limited lists.
+__global__ void __launch_bounds__(GS_BLOCK) zero_rows_kernel(float4* __restrict__ p, size_t n4,
+                                                             const uint32_t* __restrict__ tiles_touched) {
   const size_t i = (size_t)blockIdx.x * GS_BLOCK + threadIdx.x;
-  if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4 && (!tiles_touched || tiles_touched[i >> 2] != 0)) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-int launch_zero_rows(float* rows, size_t n_floats, hipStream_t s) {
-  const size_t n4 = n_floats / 4;  // GR_STRIDE = 16 floats per row
+int launch_zero_rows(float* rows, size_t P, const uint32_t* tiles_touched, hipStream_t s) {
+  const size_t n4 = P * (GR_STRIDE / 4);
   if (n4) hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n4 + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, s,
-                             reinterpret_cast<float4*>(rows), n4);
+                             reinterpret_cast<float4*>(rows), n4, tiles_touched);
   return 0;
 }
 

@@ -461,7 +461,9 @@ class RasterBackend:
             dL_dout_color = _prep(dL_dout_color, device)
             dL_dout_invdepth = _prep(dL_dout_invdepth, device)
             _, _, _, wsb = self.scratch_bytes(P, W, H, R)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
+            # (the backward clears only the rows of Gaussians that emitted instances; a probe that reads the rows gets zeros
+            # for the others too)
+            ws = (torch.zeros if self.keep_workspace else torch.empty)((wsb,), dtype=torch.uint8, device=device)
             if self.keep_workspace:
                 self.last_workspace = ws
             s = self._scratch(geomBuffer, imgBuffer, binningBuffer, self._capacity_for(binningBuffer, P, W, H, R))
@@ -504,7 +506,7 @@ class RasterBackend:
         dL_dout_invdepth = _prep(dL_dout_invdepth, device)
         radii = radii.contiguous()
         _, _, _, wsb = self.scratch_bytes(P, W, H, R)
-        ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
+        ws = (torch.zeros if self.keep_workspace else torch.empty)((wsb,), dtype=torch.uint8, device=device)
         if self.keep_workspace:
             self.last_workspace = ws
         cap = self._capacity_for(binningBuffer, P, W, H, R)
