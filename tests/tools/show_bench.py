@@ -1,3 +1,5 @@
+"""Developer tool: one-line digest of bench.py JSON lines (step time, views/s, launch form, depth-limit counters, stage times).
+    python tests/tools/show_bench.py gpurun_out/*.log"""
 import json,sys
 for f in sys.argv[1:]:
     j=json.loads(open(f).read().strip().splitlines()[-1])
