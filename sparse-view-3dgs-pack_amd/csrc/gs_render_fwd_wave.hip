@@ -238,10 +238,14 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* 
                                                                 uint32_t* __restrict__ tile_order, int T, int per_band,
                                                                 uint32_t* __restrict__ order_out,
                                                                 const float* __restrict__ stop_depth,
-                                                                float* __restrict__ limit_out, int grid_x, int grid_y) {
+                                                                float* __restrict__ limit_out, int grid_x, int grid_y,
+                                                                const GeomHeader* __restrict__ hdr) {
+  // a forward that ran out of binning capacity blended nothing and is about to be repeated with the SAME hints and
+  // bounds (the geometry phase has already counted with them): it must not overwrite them with what it did not measure
+  if (hdr->overflow) order_out = nullptr;
   if (blockIdx.x >= 8) {  // workgroups past the eight bands: the depth bounds, one item per thread
     const int i = (int)(blockIdx.x - 8) * TO_THREADS + (int)threadIdx.x;
-    if (i < (int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y)) stop_depth_bound_item(stop_depth, limit_out, grid_x, grid_y, i);
+    if (!hdr->overflow && i < (int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y)) stop_depth_bound_item(stop_depth, limit_out, grid_x, grid_y, i);
     return;
   }
   __shared__ uint32_t s_cnt[TO_BUCKETS];
@@ -329,9 +333,9 @@ int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, in
 }
 
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, uint32_t* order_out, const float* stop_depth,
-                      float* limit_out, int grid_x, int grid_y, hipStream_t s) {
+                      float* limit_out, int grid_x, int grid_y, const GeomHeader* hdr, hipStream_t s) {
   const int extra = limit_out ? ((int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y) + TO_THREADS - 1) / TO_THREADS : 0;
   hipLaunchKernelGGL(tile_order_kernel, dim3(8 + extra), dim3(TO_THREADS), 0, s, tile_work, tile_order, T, (T + 7) / 8, order_out,
-                     stop_depth, limit_out, grid_x, grid_y);
+                     stop_depth, limit_out, grid_x, grid_y, hdr);
   return 0;
 }

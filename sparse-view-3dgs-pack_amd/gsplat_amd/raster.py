@@ -44,6 +44,7 @@ class RasterBackend:
         # optimistic binning capacity (instances): skips the forward's host sync when the previous
         # call's num_rendered is a good predictor; see rasterize_gaussians().
         self._capacity_hint = 0
+        self._capacity_hint_limited = 0
         self.optimistic = os.environ.get("GS_SYNC_FORWARD", "0") != "1"
         # instance lists: True = drop (tile, Gaussian) pairs no pixel of which can reach alpha >= 1/255
         # (csrc/gs_tilecull.h; same images / gradients, ~2.6x fewer instances); GS_TILE_CULL=0 = the
@@ -129,13 +130,20 @@ class RasterBackend:
         g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D)
         return g
 
-    def _update_hint(self, num_rendered):
+    def _update_hint(self, num_rendered, limited=False):
         # 25 % head-room over the largest recent instance count; decays slowly so one huge view does not pin
         # the capacity (and the 16 B/instance buffer) forever.  Quantised to 1/8-octave steps so that consecutive steps
         # ask for the SAME number of bytes: the caching allocator then hands back the same block every step.
+        # Depth-limited views keep their own hint: their lists are several times shorter, and the sort's grids, its
+        # histogram tables and the row scan are sized by the capacity, not by the count on the device.
         import math
-        want = max(int(num_rendered * 1.25) + 4096, int(self._capacity_hint * 0.98))
-        self._capacity_hint = int(2.0 ** (math.ceil(math.log2(want) * 8.0) / 8.0))
+        old = self._capacity_hint_limited if limited else self._capacity_hint
+        want = max(int(num_rendered * 1.25) + 4096, int(old * 0.98))
+        new = int(2.0 ** (math.ceil(math.log2(want) * 8.0) / 8.0))
+        if limited:
+            self._capacity_hint_limited = new
+        else:
+            self._capacity_hint = new
 
     def _remember_capacity(self, binning, cap):
         """The binning buffer travels through autograd as a bare byte tensor; its capacity (instances) is kept here, keyed
@@ -364,6 +372,8 @@ class RasterBackend:
         for limit in ((limit, None) if limit is not None else (None,)):
             geometry(limit)
             cap = self._capacity_hint if self.optimistic else 0
+            if cap > 0 and limit is not None and self._capacity_hint_limited > 0:
+                cap = self._capacity_hint_limited
             binning = None
             if cap > 0:
                 # Optimistic path: the reference blocks the host on a D2H copy of num_rendered before it can
@@ -381,8 +391,7 @@ class RasterBackend:
             else:
                 cur.synchronize()  # the reference's blocking D2H (rasterizer_impl.cu:284)
             num_rendered = int(status[0])
-            if limit is None:
-                self._update_hint(num_rendered)
+            self._update_hint(num_rendered, limited=limit is not None)
             if binning is None or num_rendered > cap:
                 binning = new_binning(num_rendered)
                 s = scratch_of(binning, num_rendered, limit)

@@ -99,6 +99,13 @@ def test_second_visit_blends_the_same_pixels_from_shorter_lists(hip, P, W, H, de
     # third visit: the stop depths exported from cut lists are the same numbers
     c = forward_state(hip, sc, cam, DEV, bg, aa)
     assert c["num_rendered"] == b["num_rendered"] and torch.equal(c["color"], a["color"])
+    # a limited forward that runs out of binning capacity is repeated with the same bounds (its geometry phase has counted
+    # with them): the overflowed attempt must not have overwritten them with what it did not measure
+    hip._capacity_hint_limited = 4096
+    d = forward_state(hip, sc, cam, DEV, bg, aa)
+    assert d["num_rendered"] == b["num_rendered"]
+    for k in ("color", "invdepth", "final_T", "n_contrib"):
+        assert torch.equal(d[k], a[k]), k
     # gradients: same pairs in the same per-tile order, different float-atomic order across tiles
     g = torch.Generator().manual_seed(5)
     dL = torch.randn((3, H, W), generator=g)
