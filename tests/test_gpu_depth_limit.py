@@ -160,6 +160,35 @@ def test_stale_limits_are_detected_and_the_view_is_rendered_again(hip):
         assert torch.equal(d[k], ref2[k]), k
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_any_parameter_motion_between_visits_gives_the_unlimited_image(hip, seed):
+    """Whatever happens to the model between two visits of a camera - small steps, large steps, opacity resets, Gaussians
+    moved across the scene, a capacity hint that is far too small - the limited forward either passes its own check or is
+    repeated, and the caller gets the bits of the un-limited forward."""
+    P, W, H = 20000, 640, 480
+    g = torch.Generator().manual_seed(100 + seed)
+    sc = synthetic.trained_like(P, seed=seed, sh_degree=1)
+    cam = device_camera(synthetic.orbit_cameras(W, H)[2 + 5 * seed])
+    bg = torch.tensor([0.1, 0.0, 0.2])
+    forward_state(hip, sc, cam, DEV, bg, False)
+    for step, (dpos, dop, dscale) in enumerate([(1e-3, 0.01, 0.01), (1e-2, 0.1, 0.05), (0.1, 0.5, 0.3), (1e-3, 0.0, 0.0),
+                                                (0.5, 0.9, 0.5), (1e-4, 0.02, 0.0)]):
+        sc = dict(sc, means3D=sc["means3D"] + dpos * torch.randn((P, 3), generator=g),
+                  opacities=(sc["opacities"] * (1 + dop * (2 * torch.rand((P, 1), generator=g) - 1))).clamp(1e-3, 0.999),
+                  scales=sc["scales"] * torch.exp(dscale * torch.randn((P, 3), generator=g)))
+        if step == 3:
+            sc["opacities"] = sc["opacities"].clamp(max=0.01)  # an opacity reset
+        if step == 4:
+            hip._capacity_hint_limited = 4096
+        got = forward_state(hip, sc, cam, DEV, bg, False)
+        hip.depth_limit_on = False
+        ref = forward_state(hip, sc, cam, DEV, bg, False)
+        hip.depth_limit_on = True
+        for k in ("color", "invdepth", "final_T", "radii", "n_contrib"):
+            assert torch.equal(got[k], ref[k]), (step, k)
+        assert torch.equal(last_contributor_id(got, W, H), last_contributor_id(ref, W, H)), step
+
+
 def test_foreign_limits_cannot_change_a_result(hip):
     """Limits of ANOTHER camera planted under this camera's key (what an address re-used by the allocator would do), and
     absurd ones (everything cut): the image is still the un-limited image."""
