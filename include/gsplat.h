@@ -127,7 +127,8 @@ typedef struct GsScratch {
   uint32_t* tile_order_out;        /* optional: gs_forward_render also writes what gs_export_tile_order would return here */
   float* tile_depth_limit_out;     /* optional: ... and what gs_export_tile_stop_depth would return here (one launch serves
                                       both; the buffers may be the ones passed as tile_order_hint / tile_depth_limit: they
-                                      are read before they are written) */
+                                      are read before they are written; a forward that overflowed its binning capacity
+                                      writes neither, so that it can be repeated with the same hint and bounds) */
 } GsScratch;
 
 /* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by
