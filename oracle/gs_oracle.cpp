@@ -14,7 +14,10 @@
  *  and its CUDA cannot be built here (no nvcc, no NVIDIA device).  This file
  * is pinned by (1) golden vectors generated from the importable reference Python
  * (utils/sh_utils.eval_sh + autograd for SH colour fwd/bwd, utils/graphics_utils for the
- * camera matrices: tests/golden/make_golden.py), (2) an independent float64 dense autograd
+ * camera matrices and geom_transform_points, utils/general_utils + scene/gaussian_model
+ * build_covariance_from_scaling_rotation with autograd for computeCov3D forward and the
+ * cov3D -> scale / quaternion backward, the renderer's python-covariance path:
+ * tests/golden/make_golden.py, tests/golden/geometry.npz), (2) an independent float64 dense autograd
  * formulation in tests/dense_reference.py, (3) analytic known-answer tests.
  *
  * Deliberate, documented deviations from a literal transcription:
