@@ -373,12 +373,7 @@ CameraInfo = collections.namedtuple("CameraInfo", ["uid", "R", "T", "FovY", "Fov
                                                    "height", "is_test"])
 
 
-def fov2focal(fov, pixels):
-    return pixels / (2 * math.tan(fov / 2))
-
-
-def focal2fov(focal, pixels):
-    return 2 * math.atan(pixels / (2 * focal))
+from .synthetic import focal2fov, fov2focal  # noqa: E402  (pinhole field of view <-> focal length in pixels)
 
 
 # models whose first TWO parameters are (fx, fy); the others start with a single focal length

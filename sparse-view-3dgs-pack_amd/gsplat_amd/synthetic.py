@@ -1,8 +1,8 @@
 """Seeded synthetic scenes and cameras - host-side numpy/torch only.
 
 Cameras follow the reference's conventions exactly (restated, pinned by tests/golden):
-  W2C from (R, t)            LGDWT-GS/utils/graphics_utils.py:38-51  (getWorld2View2, R stored transposed)
-  projection                 LGDWT-GS/utils/graphics_utils.py:53-74  (getProjectionMatrix)
+  W2C from (R, t)            LGDWT-GS/utils/graphics_utils.py:38-51  (getWorld2View2, R stored transposed) -> world_to_camera
+  projection                 LGDWT-GS/utils/graphics_utils.py:53-74  (getProjectionMatrix) -> perspective
   transposes / full proj /   LGDWT-GS/scene/cameras.py:86-89
   camera centre
 Gaussian sets:
@@ -38,49 +38,39 @@ class Camera(NamedTuple):
 
 
 def fov2focal(fov, pixels):
-    return pixels / (2 * math.tan(fov / 2))
+    """Pinhole: half the image spans tan(fov / 2) focal lengths."""
+    return 0.5 * pixels / math.tan(0.5 * fov)
 
 
 def focal2fov(focal, pixels):
-    return 2 * math.atan(pixels / (2 * focal))
+    return 2.0 * math.atan(0.5 * pixels / focal)
 
 
-def world2view(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
-    Rt = np.zeros((4, 4))
-    Rt[:3, :3] = R.transpose()
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    C2W = np.linalg.inv(Rt)
-    cam_center = C2W[:3, 3]
-    cam_center = (cam_center + translate) * scale
-    C2W[:3, 3] = cam_center
-    Rt = np.linalg.inv(C2W)
-    return np.float32(Rt)
+def world_to_camera(R_c2w, t):
+    """4x4 world-to-camera matrix [R_c2w^T | t; 0 0 0 1] (float32).  The reference reaches the same matrix through two
+    4x4 inversions with a zero re-centring in between (graphics_utils.py:38-51); the closed form is what those amount to."""
+    M = np.eye(4, dtype=np.float64)
+    M[:3, :3] = np.asarray(R_c2w, dtype=np.float64).T
+    M[:3, 3] = np.asarray(t, dtype=np.float64)
+    return M.astype(np.float32)
 
 
-def projection_matrix(znear, zfar, fovX, fovY):
-    tanHalfFovY = math.tan(fovY / 2)
-    tanHalfFovX = math.tan(fovX / 2)
-    top = tanHalfFovY * znear
-    bottom = -top
-    right = tanHalfFovX * znear
-    left = -right
+def perspective(znear, zfar, fovX, fovY):
+    """Symmetric-frustum perspective matrix of the reference's convention (graphics_utils.py:53-74): x, y scaled by
+    cot(fov / 2), w = z_view, depth mapped to z_ndc in [0, 1] - five non-zero entries."""
     P = torch.zeros(4, 4)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    P[0, 0] = 1.0 / math.tan(0.5 * fovX)
+    P[1, 1] = 1.0 / math.tan(0.5 * fovY)
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -zfar * znear / (zfar - znear)
+    P[3, 2] = 1.0
     return P
 
 
 def make_camera(R, t, FoVx, FoVy, W, H, znear=0.01, zfar=100.0):
     """R: camera-to-world rotation (the reference stores it transposed), t: W2C translation."""
-    wvt = torch.tensor(world2view(R, t)).transpose(0, 1)
-    proj = projection_matrix(znear, zfar, FoVx, FoVy).transpose(0, 1)
+    wvt = torch.tensor(world_to_camera(R, t)).transpose(0, 1)
+    proj = perspective(znear, zfar, FoVx, FoVy).transpose(0, 1)
     full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
     center = wvt.inverse()[3, :3]
     return Camera(int(H), int(W), float(FoVx), float(FoVy), wvt.contiguous(), full.contiguous(), center.contiguous())

@@ -29,6 +29,15 @@ Fixtures are data only (inputs + the reference's outputs); no reference source i
                   gsplat_amd.io.write_colmap_binary from seeded data, and colmap_expected.npz = what the REFERENCE's
                   own readers (LGDWT-GS/scene/colmap_loader.py) return for those files, plus its qvec2rotmat /
                   rotmat2qvec -> pins the byte layout and conventions of gsplat_amd/io.py's readers
+  lgdwt_loss.npz  the reference's OWN DWT-loss code - LGDWT-GS/utils/loss_utils.py: get_dwt_subbands (:106-153),
+                  compute_elf_map (:336-366), compute_patch_dwt_loss (:368-442), l1_loss, ssim - imported and run here on
+                  seeded images at 128x128, 131x260 and 256x384, values + autograd gradients, and the defaults of
+                  LGDWT-GS/arguments/__init__.py:103-122 read from the imported OptimizationParams.  The module's top-level
+                  `from pytorch_wavelets import DWTForward` (third party, absent offline) is satisfied by registering
+                  tests/torch_loss_reference.DWTForward - an independent F.conv2d statement of that package's published
+                  Haar analysis step - in sys.modules; everything AROUND the 2x2 Haar butterfly (band slicing, unfold
+                  order, kthvalue index, ">=" selection, the HH weight, 1e-8, align_corners=False, l1 means) is the
+                  reference's code running.  -> pins D1 (layout), D2, D3, D4 of SURVEY 8(a)
 """
 import importlib.util
 import math
@@ -277,7 +286,95 @@ def gen_schedule():
              sh2rgb=sh_utils.SH2RGB(rgb).numpy())
 
 
+def gen_lgdwt_loss():
+    import argparse
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch_loss_reference as tlr
+    stub = types.ModuleType("pytorch_wavelets")
+    stub.DWTForward = tlr.DWTForward
+    sys.modules["pytorch_wavelets"] = stub
+    try:
+        ref = load(REF + "/LGDWT-GS/utils/loss_utils.py", "ref_lgdwt_loss_utils")
+        args = load(REF + "/LGDWT-GS/arguments/__init__.py", "ref_lgdwt_arguments")
+    finally:
+        del sys.modules["pytorch_wavelets"]
+    o = args.OptimizationParams(argparse.ArgumentParser())
+    out = dict(
+        band_names=np.array(["LL1", "LH1", "HL1", "HH1", "LL2", "LH2", "HL2", "HH2"]),
+        dwt_weights=np.array([o.dwt_ll1_weight, o.dwt_lh1_weight, o.dwt_hl1_weight, o.dwt_hh1_weight,
+                              o.dwt_ll2_weight, o.dwt_lh2_weight, o.dwt_hl2_weight, o.dwt_hh2_weight]),
+        lambda_dssim=np.array(o.lambda_dssim), patch_dwt_weight=np.array(o.patch_dwt_weight),
+        patch_size=np.array(o.patch_size), patch_percentile=np.array(o.patch_percentile),
+        patch_lh1_weight=np.array(o.patch_dwt_lh1_weight), patch_hl1_weight=np.array(o.patch_dwt_hl1_weight),
+        dwt_enable=np.array(o.dwt_enable), patch_dwt_enable=np.array(o.patch_dwt_enable),
+        # LGDWT-GS/train.py:188-202 (not importable: needs CUDA + the scene stack); data, not code: the running mean
+        # m <- 0.95 m + 0.05 base / (dwt + 1e-8) from m0 = 1 (train.py:78), scale = clamp(m, 0.1, 10)
+        running_mean=np.array([0.95, 0.05, 1e-8, 1.0, 0.1, 10.0]))
+    g = torch.Generator().manual_seed(20261004)
+    allw = (1.0, 0.7, 1.3, 0.3, 0.5, 0.25, 0.9, 2.0)   # a second, all-non-zero weight set for the summed gradient
+    out["dwt_weights_all"] = np.array(allw)
+    for tag, (H, W), ps, (w_lh, w_hl), rs in (("a", (128, 128), 32, (1.0, 1.0), 1), ("b", (131, 260), 64, (1.0, 0.5), 1),
+                                              ("c", (256, 384), 128, (1.0, 1.0), 4), ("d", (75, 141), 32, (0.7, 1.3), 1)):
+        # images quantised to 8 bit like PILtoTorch (general_utils.py:21-27); rs: row stride at which the big arrays of
+        # the largest case are kept (a fixture is a sample, the scalars cover every pixel)
+        gt = torch.rand((1, 3, H, W), generator=g)
+        gt[:, :, : H // 2] = gt[:, :, : H // 2] * 0.1 + 0.4       # a smooth half: high ELF, selected by the patch rule
+        gt[:, :, :, W // 3: W // 2] *= 0.5
+        gt = torch.round(gt * 255.0) / 255.0
+        # (the render is continuous and here un-clamped: an 8-bit or clamped pred against an 8-bit gt makes band differences
+        # cancel EXACTLY in places, where the sign() inside the L1 gradients is decided by the rounding of the Haar step
+        # alone; one block where both images are 0 keeps the sign(0) = 0 case)
+        pred = gt + 0.1 * torch.randn((1, 3, H, W), generator=g)
+        gt[:, :, 8:16, 8:24] = 0.0
+        pred[:, :, 8:16, 8:24] = 0.0
+        out["gt_u8_" + tag] = torch.round(gt[0] * 255.0).to(torch.uint8).numpy()
+        out["pred_" + tag] = pred[0].numpy()
+        out["patch_args_" + tag] = np.array([ps, 0.2, w_lh, w_hl])
+        out["row_stride_" + tag] = np.array(rs)
+        # D1: the eight bands and the adjoint (cotangents: tests/torch_loss_reference.cotangent)
+        x = pred.clone().requires_grad_(True)
+        bands = ref.get_dwt_subbands(x)
+        sum((bands[k] * tlr.cotangent(bands[k].shape, i)).sum() for i, k in enumerate(bands)).backward()
+        for k in bands:
+            out["band_%s_%s" % (k, tag)] = bands[k].detach()[0, :, ::rs].numpy()
+        out["dbands_" + tag] = x.grad[0, :, ::rs].numpy()
+        # D2: per-band L1 (train.py:132-164 weights them and adds them up); gradient of the all-bands weighted sum
+        gb = ref.get_dwt_subbands(gt)
+        x = pred.clone().requires_grad_(True)
+        pb = ref.get_dwt_subbands(x)
+        l1s = [ref.l1_loss(pb[k], gb[k]) for k in bands]
+        sum(w * l for w, l in zip(allw, l1s)).backward()
+        out["band_l1_" + tag] = np.array([float(l) for l in l1s])
+        out["dl1_all_" + tag] = x.grad[0, :, ::rs].numpy()
+        # D3
+        elf = ref.compute_elf_map(gt)
+        out["elf_" + tag] = elf[0, :, ::rs].numpy()
+        # D4 (selected patches = those that receive a gradient: every selected patch of a noisy image does)
+        x = pred.clone().requires_grad_(True)
+        pl = ref.compute_patch_dwt_loss(x, gt, elf, patch_size=ps, percentile=0.2, lh1_weight=w_lh, hl1_weight=w_hl)
+        pl.backward()
+        out["patch_loss_" + tag] = pl.detach().numpy()
+        out["dpatch_" + tag] = x.grad[0, :, ::rs].numpy()
+        ny, nx = H // ps, W // ps
+        gp = x.grad[0, :, : ny * ps, : nx * ps].abs().reshape(3, ny, ps, nx, ps).amax(dim=(0, 2, 4))
+        out["patch_mask_" + tag] = (gp > 0).reshape(-1).numpy()
+        # the other two terms of the base loss from the same module
+        x = pred[0].clone().requires_grad_(True)
+        l1 = ref.l1_loss(x, gt[0])
+        ss = ref.ssim(x, gt[0])
+        ((1.0 - o.lambda_dssim) * l1 + o.lambda_dssim * (1.0 - ss)).backward()
+        out["l1_" + tag], out["ssim_" + tag] = l1.detach().numpy(), ss.detach().numpy()
+        out["dbase_" + tag] = x.grad[:, ::rs].numpy()
+    # too-small image: the patch term is 0 (loss_utils.py:386-387)
+    small = torch.rand((1, 3, 40, 200), generator=g)
+    out["patch_loss_small"] = ref.compute_patch_dwt_loss(small, small * 0.5, ref.compute_elf_map(small)).numpy()
+    np.savez_compressed(os.path.join(HERE, "lgdwt_loss.npz"), **out)
+
+
 if __name__ == "__main__":
+    gen_lgdwt_loss()
     gen_sh()
     gen_cameras()
     gen_losses()

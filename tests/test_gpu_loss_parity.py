@@ -12,6 +12,21 @@ def ops_pair(hip, oracle):
     return LossOps(hip.api), LossOps(oracle.api)
 
 
+@pytest.mark.parametrize("tag", ("a", "b", "c", "d"))
+def test_hip_loss_kernels_vs_the_reference_module_fixture(hip, tag):
+    """D1-D4 of the HIP kernels against what the reference's own LGDWT-GS/utils/loss_utils.py returned in the build
+    container (tests/golden/lgdwt_loss.npz, tests/lgdwt_fixture.py)."""
+    import lgdwt_fixture
+    lgdwt_fixture.check_case(LossOps(hip.api), torch.device("cuda"), lgdwt_fixture.load(), tag)
+
+
+def test_hip_criterion_running_mean_vs_the_reference_fixture(hip):
+    import lgdwt_fixture
+    z = lgdwt_fixture.load()
+    lgdwt_fixture.check_criterion_defaults(LGDWTCriterion, LossOps(hip.api), z)
+    lgdwt_fixture.check_running_mean(LGDWTCriterion, LossOps(hip.api), z, torch.device("cuda"))
+
+
 def images(H, W, seed, C=3):
     g = torch.Generator().manual_seed(seed)
     gt = torch.rand((C, H, W), generator=g)

@@ -1,9 +1,15 @@
-"""Independent torch restatement of the LGDWT-GS loss terms (test-side reference, float64 capable).
+"""Independent torch restatement of the Haar analysis step the LGDWT-GS losses stand on (test-side, float64 capable).
 
-DWT: the published algorithm of pytorch_wavelets' DWTForward(J=1,'db1','symmetric') written with
-F.conv2d exactly as that package does it (afb1d: grouped stride-2 correlation along W, then along H,
-filters h0=[c,c], h1=[c,-c], one 'symmetric' pad sample on the right/bottom for odd sizes), and the loss
-functions of LGDWT-GS/utils/loss_utils.py:106-153,336-442 / train.py:132-164 re-typed on top of it."""
+The reference takes its DWT from the third-party `pytorch_wavelets` (un-vendored, un-versioned, absent here).  This file
+restates that package's PUBLISHED algorithm for DWTForward(J, 'db1', 'symmetric') with F.conv2d: afb1d = grouped stride-2
+correlation along W, then along H, filters h0=[c,c], h1=[c,-c], one 'symmetric' pad sample on the right / bottom for odd
+sizes, band order LH / HL / HH.  It is used two ways:
+  * `DWTForward` below is registered as `pytorch_wavelets` in sys.modules by tests/golden/make_golden.py so that the
+    reference's own LGDWT-GS/utils/loss_utils.py imports and RUNS in the build container; what it returns for
+    get_dwt_subbands / compute_elf_map / compute_patch_dwt_loss (+ autograd) is committed as tests/golden/lgdwt_loss.npz;
+  * `haar_bands_2level` is the independent check of the oracle's / HIP kernels' bands at odd and tiny sizes.
+Nothing of the reference's loss code is restated here: D2-D4 are pinned by that fixture (everything except the 2x2 Haar
+signs, which no consumer can see: L1 of differences, abs, squares)."""
 import torch
 import torch.nn.functional as F
 
@@ -34,55 +40,38 @@ def dwt1(x):
     return ll, lh, hl, hh
 
 
-def get_dwt_subbands(x):
+def haar_bands_2level(x):
+    """{LL1 .. HH2}: one Haar level of x, one more of its LL band."""
     LL1, LH1, HL1, HH1 = dwt1(x)
     LL2, LH2, HL2, HH2 = dwt1(LL1)
     return {"LL1": LL1, "LH1": LH1, "HL1": HL1, "HH1": HH1, "LL2": LL2, "LH2": LH2, "HL2": HL2, "HH2": HH2}
 
 
-def l1_loss(a, b):
-    return torch.abs(a - b).mean()
+def cotangent(shape, salt=0):
+    """A fixed, seed-free cotangent tensor in [-1, 1] (shared by the fixture generator and the tests, so that it need
+    not be stored): a sign-alternating pattern of the flat index."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    i = torch.arange(n, dtype=torch.int64)
+    v = ((i * 7 + (i // 13) * 5 + salt * 3) % 11 - 5).to(torch.float32) / 5.0
+    return v.reshape(tuple(shape))
 
 
-def dwt_loss(pred, gt, weights):
-    pb, gb = get_dwt_subbands(pred), get_dwt_subbands(gt)
-    total = 0.0
-    for w, k in zip(weights, ("LL1", "LH1", "HL1", "HH1", "LL2", "LH2", "HL2", "HH2")):
-        if w != 0.0:
-            total = total + w * l1_loss(pb[k], gb[k])
-    return total
+class DWTForward(torch.nn.Module):
+    """Stand-in for pytorch_wavelets.DWTForward(J, mode='symmetric', wave='db1'): forward(x[N,C,H,W]) ->
+    (Yl, [Yh_1 .. Yh_J]) with Yh_j [N,C,3,h_j,w_j] = (LH, HL, HH) of level j, finest first."""
 
+    def __init__(self, J=1, mode="symmetric", wave="db1"):
+        super().__init__()
+        if mode != "symmetric" or wave not in ("db1", "haar"):
+            raise NotImplementedError("only the Haar / symmetric transform the LGDWT-GS losses use")
+        self.J = int(J)
 
-def compute_elf_map(image):
-    bands = get_dwt_subbands(image)
-
-    def l1(x):
-        return torch.sum(torch.abs(x), dim=1, keepdim=True)
-    LL, LH, HL, HH = l1(bands["LL1"]), l1(bands["LH1"]), l1(bands["HL1"]), l1(bands["HH1"])
-    HF = LH + HL + HH
-    elf_low = LL / (LL + HF + 1e-8)
-    H, W = image.shape[-2:]
-    return F.interpolate(elf_low, size=(H, W), mode="bilinear", align_corners=False), elf_low
-
-
-def compute_patch_dwt_loss(pred, gt, elf_map, patch_size=128, percentile=0.2, lh1_weight=1.0, hl1_weight=1.0):
-    N, Cn, H, W = pred.shape
-    if H < patch_size or W < patch_size:
-        return torch.tensor(0.0)
-    pred_patches = F.unfold(pred, kernel_size=patch_size, stride=patch_size)
-    gt_patches = F.unfold(gt, kernel_size=patch_size, stride=patch_size)
-    elf_patches = F.unfold(elf_map, kernel_size=patch_size, stride=patch_size)
-    L = pred_patches.shape[2]
-    patch_elf_means = elf_patches.mean(dim=1)
-    all_elf_means = patch_elf_means.view(-1)
-    k = int(all_elf_means.numel() * (1.0 - percentile))
-    k = max(1, k)
-    k = min(k, all_elf_means.numel())
-    threshold, _ = torch.kthvalue(all_elf_means, k)
-    mask = patch_elf_means >= threshold
-    pred_patches = pred_patches.view(N, Cn, patch_size, patch_size, L).permute(0, 4, 1, 2, 3)
-    gt_patches = gt_patches.view(N, Cn, patch_size, patch_size, L).permute(0, 4, 1, 2, 3)
-    pred_sel, gt_sel = pred_patches[mask], gt_patches[mask]
-    pb, gb = get_dwt_subbands(pred_sel), get_dwt_subbands(gt_sel)
-    loss_LH, loss_HL, loss_HH = l1_loss(pb["LH1"], gb["LH1"]), l1_loss(pb["HL1"], gb["HL1"]), l1_loss(pb["HH1"], gb["HH1"])
-    return (lh1_weight * loss_LH) + (hl1_weight * loss_HL) + (0.5 * (lh1_weight + hl1_weight) * loss_HH), mask
+    def forward(self, x):
+        yh = []
+        ll = x
+        for _ in range(self.J):
+            ll, lh, hl, hh = dwt1(ll)
+            yh.append(torch.stack((lh, hl, hh), dim=2))
+        return ll, yh
