@@ -409,6 +409,8 @@ def main():
     gc.enable()
     dl1 = dict(_hb0().depth_limit_stats)
     R_timed = int(_hb0()._pinned[0]) if _hb0()._pinned is not None else 0
+    if depth_limit and _hb0().last_deferred_num_rendered is not None:  # (deferred forwards report their count with the verdict)
+        R_timed = int(_hb0().last_deferred_num_rendered)
     if not args.no_stage_timers:
         if graphed is None:
             api.call("profile_enable", 0)
@@ -479,7 +481,9 @@ def main():
             dx = (time.perf_counter() - t1) / nx
             d1 = dict(be2.depth_limit_stats)
             e = {"scene": SCENES[kind]["what"], "sh_degree": SCENES[kind]["sh_degree"], "ms_per_step": dx * 1e3,
-                 "views_per_s": 1.0 / dx, "steps": nx, "num_rendered_last_view": int(be2._pinned[0]),
+                 "views_per_s": 1.0 / dx, "steps": nx,
+                 "num_rendered_last_view": int(be2.last_deferred_num_rendered if (depth_limit and be2.last_deferred_num_rendered
+                                                                                   is not None) else be2._pinned[0]),
                  "limited_views": d1["used"] - d0["used"], "fallbacks": d1["failed"] - d0["failed"]}
             if depth_limit:   # and with the full (culled) lists
                 tr2.depth_limit = None

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 
 /* error codes (negative = caller error) */
 #define GS_OK 0
@@ -69,7 +69,11 @@ typedef struct GsView {
   int32_t debug;       /* bool: synchronise + check after every launch (auxiliary.h:178-185) */
   int32_t tile_cull;   /* 0: instance lists = the reference's bounding-square rule (rasterizer_impl.cu:70-111), bit-identical
                           point_list / ranges / num_rendered; 1: additionally drop (tile, Gaussian) pairs on which alpha <
-                          1/255 for every pixel (csrc/gs_tilecull.h) - same images and gradients, ~2.6x fewer instances */
+                          1/255 for every pixel (csrc/gs_tilecull.h) - same images and gradients, ~2.6x fewer instances;
+                          2: the lists of 1 - every tile's list holds the same Gaussians in the same (depth, index) order -
+                          built by REGION BINNING (csrc/gs_regionbin.hip: two launches instead of twenty-three; the lists of
+                          different tiles lie in point_list in no particular order, ranges[] says where).  With 2 the
+                          binning buffer must be given to gs_forward_geometry already (scratch->binning / binning_capacity) */
   const float* bg;         /* [3] */
   const float* viewmatrix; /* [16] */
   const float* projmatrix; /* [16] */
@@ -129,6 +133,9 @@ typedef struct GsScratch {
                                       both; the buffers may be the ones passed as tile_order_hint / tile_depth_limit: they
                                       are read before they are written; a forward that overflowed its binning capacity
                                       writes neither, so that it can be repeated with the same hint and bounds) */
+  int32_t binned;                  /* 1: gs_forward_bin has already built the instance lists of this view in these buffers;
+                                      gs_forward_render* then only blends */
+  int32_t _pad;
 } GsScratch;
 
 /* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by
@@ -172,6 +179,12 @@ int gs_forward_geometry(const GsView* view, const GsGaussians* g, GsScratch* scr
  * out_color [3,H,W], out_invdepth [H,W] (may be NULL). */
 int gs_forward_render(const GsView* view, const GsGaussians* g, GsScratch* scratch,
                       float* out_color, float* out_invdepth, void* stream);
+
+/* The binning stage of gs_forward_render on its own (instance lists + tile ranges), followed by an asynchronous copy of
+ * the four status words of gs_forward_status to status_host (pinned; may be NULL).  A caller that wants to know whether
+ * the lists fitted the binning capacity without waiting for the blend calls this, records an event, calls
+ * gs_forward_render* with scratch->binned = 1 and waits for the event while the blend runs. */
+int gs_forward_bin(const GsView* view, const GsGaussians* g, GsScratch* scratch, uint32_t* status_host, void* stream);
 
 /* gs_forward_render with a 4th blended channel: out_extra[H,W] = sum_i extra_i alpha_i T_i + T_final * bg[0], i.e.
  * channel 0 of a second rasterizer pass with colors_precomp = extra.repeat(1,3) - what the reference's render_nir
@@ -291,8 +304,19 @@ int gs_export_tile_stop_depth(const GsScratch* scratch, int32_t W, int32_t H, fl
 /* Asynchronous read-back of the last forward's counters into host memory (pinned for a true async copy):
  * out[0] = instances emitted (num_rendered), out[1] = overflow (binning capacity exceeded: nothing was blended),
  * out[2] = trunc_failed (a depth-limited tile ran out of list entries: outputs invalid, see GsScratch.tile_depth_limit),
- * out[3] = 0.  Valid after `stream` has been synchronised. */
+ * out[3] = 0, or with GsView.tile_cull = 2 the largest number of Gaussians any 4 x 4-tile region received (the region
+ * buckets hold binning_capacity / regions entries each, at most 16 384: a larger value set `overflow` too).  Valid after
+ * `stream` has been synchronised. */
 int gs_forward_status(const GsScratch* scratch, uint32_t* out /*[4] host*/, void* stream);
+/* Developer statistics of the last forward on this scratch: what the backward blend's loop meets.  out (device, 8 x u64,
+ * zeroed by the caller) += [entries visited, entries with a valid pixel, (entry, quadrant) pairs with a valid pixel,
+ * valid (entry, pixel) pairs, tiles with work, list entries of those tiles, 0, 0].  tests/tools/blend_stats.py */
+int gs_debug_blend_stats(const GsScratch* scratch, int32_t P, int32_t W, int32_t H, uint64_t* out, void* stream);
+/* gs_export_binning for lists built by region binning (GsView.tile_cull = 2; gs_export_binning returns GS_E_UNSUPPORTED
+ * for their keys): keys_sorted[i] = (tile << 32 | depth bits) of list entry i, rebuilt from ranges[] - the lists of
+ * different tiles lie in point_list in no particular order, inside a tile the order is the reference's. */
+int gs_export_binning_region(const GsScratch* scratch, int32_t W, int32_t H, int64_t num_rendered, uint64_t* keys_sorted,
+                             uint32_t* point_list, void* stream);
 
 /* ---- simple-knn ---- */
 /* out[i] = mean of the 3 smallest squared distances from point i to the other points.

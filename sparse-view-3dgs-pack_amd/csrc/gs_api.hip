@@ -29,6 +29,35 @@ static inline void tile_grid(const GsView* v, int& gx, int& gy) {
   gy = (v->image_height + TILE_Y - 1) / TILE_Y;
 }
 
+// where region binning (GsView.tile_cull = 2, gs_regionbin.hip) keeps its state inside the caller's scratch buffers
+struct RegionLayout {
+  uint32_t* count;     // [rg_x * rg_y]  (image buffer)
+  uint2* bucket;       // [rg_x * rg_y][cap]  (the two key halves of the binning buffer: 8 B x capacity)
+  uint32_t* point_list;  // (Gaussian ids[0] of the binning buffer: where the backward looks for it)
+  uint32_t cap;
+  int rg_x, rg_y;
+};
+static int region_layout(const GsView* v, const GsScratch* sc, RegionLayout& rl) {
+  int gx, gy;
+  tile_grid(v, gx, gy);
+  const size_t T = (size_t)gx * gy, N = (size_t)v->image_width * v->image_height;
+  if (!sc->img || !sc->binning) return GS_E_NULL;
+  if (sc->img_bytes < img_bytes(N, T)) return GS_E_SCRATCH;
+  const int64_t cap = sc->binning_capacity;
+  if (cap <= 0 || cap > 0xFFFFFFFFll) return GS_E_SHAPE;
+  if (sc->binning_bytes < bin_bytes((size_t)cap)) return GS_E_SCRATCH;
+  rl.rg_x = (gx + RG_TILES - 1) / RG_TILES;
+  rl.rg_y = (gy + RG_TILES - 1) / RG_TILES;
+  rl.cap = region_capacity(cap, rl.rg_x * rl.rg_y);
+  if (rl.cap == 0) return GS_E_SHAPE;  // fewer instances of capacity than regions
+  ImgView iv = img_view(sc->img, N, T);
+  SortBufs bv = sort_view(sc->binning, (size_t)cap);
+  rl.count = iv.region_count;
+  rl.bucket = reinterpret_cast<uint2*>(bv.keys[0]);  // keys[0] and keys[1] are adjacent: 2 x align(4 cap) >= 8 regions cap_r
+  rl.point_list = bv.vals[0];
+  return GS_OK;
+}
+
 extern "C" {
 
 int gs_abi_version(void) { return GS_ABI_VERSION; }
@@ -93,12 +122,29 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   a.extra_channel = g->extra_channel;
   a.tile_cull = v->tile_cull;
   a.tile_depth_limit = v->tile_cull ? sc->tile_depth_limit : nullptr;
+  a.region_count = nullptr;
+  a.region_bucket = nullptr;
+  a.region_cap = 0;
+  a.rg_x = a.rg_y = 0;
+  if (v->tile_cull == 2) {
+    // region binning: the buckets live in the binning buffer, the counters in the image buffer - both must be here already
+    RegionLayout rl;
+    rc = region_layout(v, sc, rl);
+    if (rc) return rc;
+    a.region_count = rl.count;
+    a.region_bucket = rl.bucket;
+    a.region_cap = rl.cap;
+    a.rg_x = rl.rg_x;
+    a.rg_y = rl.rg_y;
+    launch_region_prepare(gv, rl.count, rl.rg_x * rl.rg_y, (uint32_t)P, s);
+    GS_LAUNCH_CHECK(s, v->debug);
+  }
   {
     GS_PROF(ST_PREPROCESS_FWD, s);
     launch_preprocess_fwd(a, gv, s);
   }
   GS_LAUNCH_CHECK(s, v->debug);
-  {
+  if (v->tile_cull != 2) {  // (region binning needs no prefix sum: num_rendered is known when the lists are)
     GS_PROF(ST_SCAN, s);
     launch_scan_block_sums(gv, P, s);
   }
@@ -113,8 +159,87 @@ int gs_forward_render(const GsView* v, const GsGaussians* g, GsScratch* sc, floa
   return gs_forward_render_x(v, g, sc, out_color, out_invdepth, nullptr, stream);
 }
 
+// The binning stage: instance lists (point_list = Gaussian ids[0] of the binning buffer) and ranges[] of the view whose
+// geometry phase has run on these buffers.
+static int forward_bin_stage(const GsView* v, const GsScratch* sc, const GeomView& gv, const ImgView& iv, const SortBufs& bv, int P,
+                             int gx, int gy, hipStream_t s) {
+  int rc;
+  const int64_t cap = sc->binning_capacity;
+  const size_t T = (size_t)gx * gy;
+  if (v->tile_cull == 2) {
+    RegionLayout rl;
+    rc = region_layout(v, sc, rl);
+    if (rc) return rc;
+    GS_PROF(ST_SORT, s);
+    rc = launch_region_bin(gv, rl.count, rl.bucket, rl.cap, rl.rg_x, rl.rg_y, gx, gy, sc->tile_depth_limit, iv.ranges, rl.point_list,
+                           cap, s);
+    if (rc) return rc;
+    GS_LAUNCH_CHECK(s, v->debug);
+    return GS_OK;
+  }
+  launch_bin_prepare(gv, cap, iv.ranges, (int)T, s);
+  GS_LAUNCH_CHECK(s, v->debug);
+  if (cap > 0) {
+    {  // 1. depth order of the P Gaussians: 4 passes; pass 0 reads the keys preprocess wrote (kept intact, so the
+       //    phase can be re-run), then half 1 -> 0 -> 1 -> 0: the order ends in gsort.vals[0]
+      GS_PROF(ST_SORT_DEPTH, s);
+      rc = launch_radix_sort(gv.gsort, &gv.hdr->P, P, 32, 0, gv.depth_keys, s, v->debug, &gv.hdr->n_ordered);
+      if (rc) return rc;
+    }
+    // 2. instances in depth order; 3. stable partition by tile id.  The unsorted list goes into the ping-pong
+    // half from which `passes` passes end in half 0, so backward / exports always find the result in half 0.
+    const int bit = (int)gs_higher_msb((uint32_t)(gx * gy));
+    const int passes = (bit + RS_BITS - 1) / RS_BITS;
+    const int start = passes & 1;
+    {
+      GS_PROF(ST_DUPLICATE, s);
+      rc = launch_emit_instances(gv, P, &gv.hdr->n_ordered, gx, gy, v->tile_cull, sc->tile_depth_limit, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
+      if (rc) return rc;
+    }
+    {
+      GS_PROF(ST_SORT, s);
+      rc = launch_radix_sort(bv, &gv.hdr->sort_n, cap, bit, start, nullptr, s, v->debug);
+      if (rc) return rc;
+    }
+  }
+  {
+    GS_PROF(ST_RANGES, s);
+    rc = launch_tile_ranges(bv.keys[0], &gv.hdr->sort_n, cap, iv.ranges, (int)T, s);
+  }
+  if (rc) return rc;
+  GS_LAUNCH_CHECK(s, v->debug);
+  return GS_OK;
+}
+
 static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_invdepth,
                                float* out_extra, int fsgs, void* stream);
+
+int gs_forward_bin(const GsView* v, const GsGaussians* g, GsScratch* sc, uint32_t* status_host, void* stream) {
+  int rc = check_args(v, g);
+  if (rc) return rc;
+  if (!sc || !sc->geom || !sc->img) return GS_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = g->P, W = v->image_width, H = v->image_height;
+  int gx, gy;
+  tile_grid(v, gx, gy);
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  if (sc->img_bytes < img_bytes(N, T)) return GS_E_SCRATCH;
+  if (P > 0) {
+    if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
+    const int64_t cap = sc->binning_capacity;
+    if (cap < 0) return GS_E_SHAPE;
+    if (cap > 0 && (!sc->binning || sc->binning_bytes < bin_bytes((size_t)cap))) return GS_E_SCRATCH;
+    if (cap > 0xFFFFFFFFll) return GS_E_UNSUPPORTED;
+    GeomView gv = geom_view(sc->geom, (size_t)P);
+    ImgView iv = img_view(sc->img, N, T);
+    SortBufs bv = sort_view(sc->binning, (size_t)cap);
+    rc = forward_bin_stage(v, sc, gv, iv, bv, P, gx, gy, s);
+    if (rc) return rc;
+  }
+  sc->binned = 1;
+  if (status_host) GS_HIP_CHECK(hipMemcpyAsync(status_host, sc->geom, 16, hipMemcpyDeviceToHost, s));
+  return GS_OK;
+}
 
 int gs_forward_render_x(const GsView* v, const GsGaussians* g, GsScratch* sc, float* out_color, float* out_invdepth,
                         float* out_extra, void* stream) {
@@ -155,37 +280,10 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
   ImgView iv = img_view(sc->img, N, T);
   SortBufs bv = sort_view(sc->binning, (size_t)cap);
 
-  launch_bin_prepare(gv, cap, iv.ranges, (int)T, s);
-  GS_LAUNCH_CHECK(s, v->debug);
-  if (cap > 0) {
-    {  // 1. depth order of the P Gaussians: 4 passes; pass 0 reads the keys preprocess wrote (kept intact, so the
-       //    phase can be re-run), then half 1 -> 0 -> 1 -> 0: the order ends in gsort.vals[0]
-      GS_PROF(ST_SORT_DEPTH, s);
-      rc = launch_radix_sort(gv.gsort, &gv.hdr->P, P, 32, 0, gv.depth_keys, s, v->debug, &gv.hdr->n_ordered);
-      if (rc) return rc;
-    }
-    // 2. instances in depth order; 3. stable partition by tile id.  The unsorted list goes into the ping-pong
-    // half from which `passes` passes end in half 0, so backward / exports always find the result in half 0.
-    const int bit = (int)gs_higher_msb((uint32_t)(gx * gy));
-    const int passes = (bit + RS_BITS - 1) / RS_BITS;
-    const int start = passes & 1;
-    {
-      GS_PROF(ST_DUPLICATE, s);
-      rc = launch_emit_instances(gv, P, &gv.hdr->n_ordered, gx, gy, v->tile_cull, sc->tile_depth_limit, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
-      if (rc) return rc;
-    }
-    {
-      GS_PROF(ST_SORT, s);
-      rc = launch_radix_sort(bv, &gv.hdr->sort_n, cap, bit, start, nullptr, s, v->debug);
-      if (rc) return rc;
-    }
+  if (!sc->binned) {
+    rc = forward_bin_stage(v, sc, gv, iv, bv, P, gx, gy, s);
+    if (rc) return rc;
   }
-  {
-    GS_PROF(ST_RANGES, s);
-    rc = launch_tile_ranges(bv.keys[0], &gv.hdr->sort_n, cap, iv.ranges, (int)T, s);
-  }
-  if (rc) return rc;
-  GS_LAUNCH_CHECK(s, v->debug);
   {
     GS_PROF(ST_RENDER_FWD, s);
     launch_render_fwd_wave(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, v->bg, iv.final_T, iv.n_contrib, iv.tile_work,
@@ -504,12 +602,60 @@ int gs_export_binning(const GsScratch* sc, int64_t R, uint64_t* keys_sorted, uin
   SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
   if (keys_sorted) {
     // the product keeps (tile id) and (depth bits) in separate arrays; rebuild the reference's 64-bit key
-    const GeomHeader* hdr = (const GeomHeader*)sc->geom;
     const Splat* splat = (const Splat*)((const char*)sc->geom + sizeof(GeomHeader));
-    (void)hdr;
+    GeomHeader hdr;  // (parity export: a blocking read of the header is fine here)
+    GS_HIP_CHECK(hipStreamSynchronize(s));
+    GS_HIP_CHECK(hipMemcpy(&hdr, sc->geom, sizeof(hdr), hipMemcpyDeviceToHost));
     (void)hipGetLastError();
+    if (hdr.region_mode) {
+      // region binning: no tile-key array exists; every list entry's key from ranges[] (needs the image buffer: W x H
+      // are not known here, so the ranges pointer is recovered the way gs_export_img lays the buffer out is not possible -
+      // the caller passes them through gs_export_binning_region instead)
+      return GS_E_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, bv.keys[0], bv.vals[0], splat,
                        R, keys_sorted);
+    GS_LAUNCH_CHECK(s, 0);
+  }
+  if (point_list) GS_HIP_CHECK(hipMemcpyAsync(point_list, bv.vals[0], 4 * (size_t)R, hipMemcpyDeviceToDevice, s));
+  return GS_OK;
+}
+
+int gs_debug_blend_stats(const GsScratch* sc, int32_t P, int32_t W, int32_t H, uint64_t* out /* device, 8 words, zeroed by the caller */,
+                         void* stream) {
+  if (!sc || !sc->geom || !sc->img || !sc->binning || !out) return GS_E_NULL;
+  if (P <= 0 || W <= 0 || H <= 0) return GS_E_SHAPE;
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  GeomView gv = geom_view(sc->geom, (size_t)P);
+  ImgView iv = img_view(sc->img, N, T);
+  SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
+  (void)hipGetLastError();
+  launch_blend_stats(iv.ranges, bv.vals[0], W, H, gx, gy, gv.splat, iv.n_contrib, iv.tile_work, (unsigned long long*)out,
+                     (hipStream_t)stream);
+  GS_LAUNCH_CHECK((hipStream_t)stream, 0);
+  return GS_OK;
+}
+
+/* gs_export_binning for lists built by region binning (GsView.tile_cull = 2): the key of every list entry is rebuilt from
+ * ranges[] (tile) and the Gaussian's depth; point_list as it lies in the buffer (tile lists in no particular order). */
+int gs_export_binning_region(const GsScratch* sc, int32_t W, int32_t H, int64_t R, uint64_t* keys_sorted, uint32_t* point_list,
+                             void* stream) {
+  if (!sc || !sc->geom || !sc->img) return GS_E_NULL;
+  if (R <= 0) return GS_OK;
+  if (!sc->binning) return GS_E_NULL;
+  if (W <= 0 || H <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  if (sc->img_bytes < img_bytes(N, T)) return GS_E_SCRATCH;
+  ImgView iv = img_view(sc->img, N, T);
+  SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
+  const Splat* splat = (const Splat*)((const char*)sc->geom + sizeof(GeomHeader));
+  (void)hipGetLastError();
+  if (keys_sorted) {
+    GS_HIP_CHECK(hipMemsetAsync(keys_sorted, 0xFF, 8 * (size_t)R, s));  // (entries no tile owns would show as all-ones)
+    launch_export_keys_region(iv.ranges, bv.vals[0], splat, (int)T, keys_sorted, s);
     GS_LAUNCH_CHECK(s, 0);
   }
   if (point_list) GS_HIP_CHECK(hipMemcpyAsync(point_list, bv.vals[0], 4 * (size_t)R, hipMemcpyDeviceToDevice, s));

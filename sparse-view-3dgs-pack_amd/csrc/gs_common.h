@@ -8,8 +8,10 @@
 //           tiles_touched[P] u32
 //           block_sums / sorted_sums [ceil(P/256)+1] u32   workgroup sums of tiles_touched (index / depth order)
 //           gsort            radix-sort buffers of the per-Gaussian depth sort (16 B x P + histograms)
-//  img    : final_T[N] f32 | n_contrib[N] u32 | ranges[T] uint2 | tile_work[T] u32 | tile_order[T] u32
+//  img    : final_T[N] f32 | n_contrib[N] u32 | ranges[T] uint2 | tile_work[T] u32 | tile_order[T] u32 | region_count[<= T] u32
 //  binning: tile keys[2][cap] u32 | Gaussian ids[2][cap] u32 | radix histograms   (16 B per instance)
+//           region binning (GsView.tile_cull = 2): the key halves hold the region buckets [regions][cap / regions] of
+//           (depth bits, Gaussian index), Gaussian ids[0] is point_list
 //
 // All sub-arrays start on 256-byte boundaries.
 #pragma once
@@ -27,11 +29,12 @@ struct GeomHeader {
   uint32_t num_rendered;  // R = sum tiles_touched
   uint32_t overflow;      // set by the duplicate kernel when R > binning capacity
   uint32_t trunc_failed;  // depth-limited emission (gs_tilecull.h): a bounded tile ran out of list entries before saturating
-  uint32_t zero;          // (the first 16 bytes are what gs_forward_status copies out)
+  uint32_t zero;          // 0; region binning: the largest region_count (the first 16 bytes are what gs_forward_status copies out)
   uint32_t P;
   uint32_t sort_n;        // instances the binning stage really processes: overflow ? 0 : num_rendered
   uint32_t n_ordered;     // Gaussians in the depth order = those that emit instances (the sort's first pass drops the rest)
-  uint32_t pad[57];
+  uint32_t region_mode;   // 1: the lists of this view were built by region binning (gs_regionbin.hip), 0: by the LSD path
+  uint32_t pad[56];
 };
 static_assert(sizeof(GeomHeader) == 256, "header is one 256-B block");
 
@@ -117,6 +120,7 @@ static inline __host__ __device__ GeomView geom_view(void* buf, size_t P) {
   return g;
 }
 
+#define RG_COUNT_STRIDE 32  // u32 words between two region counters (one 128-B line per counter)
 struct ImgView {
   float* final_T;
   uint32_t* n_contrib;
@@ -124,9 +128,12 @@ struct ImgView {
   uint32_t* tile_work;   // [T] list entries the backward blend will visit in this tile = max last contributor (forward)
   uint32_t* tile_order;  // [8 ceil(T/8)] launch order of the backward blend: per XCD band, by decreasing tile_work
   float* tile_stop_depth;  // [T] view depth of the list entry at which the tile's last pixel saturated (+inf: never)
+  uint32_t* region_count;  // [regions <= T][RG_COUNT_STRIDE] region binning: Gaussians each 4 x 4-tile region received
+                           // (gs_regionbin.hip; word 0 of a 128-B line each - sixteen hot counters on one line serialise)
 };
 static inline __host__ __device__ size_t img_bytes(size_t N, size_t T) {
-  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T) + gs_align(4 * T) + gs_align(4 * (T + 8)) + gs_align(4 * T);
+  return gs_align(4 * N) + gs_align(4 * N) + gs_align(8 * T) + gs_align(4 * T) + gs_align(4 * (T + 8)) + gs_align(4 * T) +
+         gs_align(4 * RG_COUNT_STRIDE * T);
 }
 static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T) {
   char* p = (char*)buf;
@@ -136,7 +143,8 @@ static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T
   v.ranges = (uint2*)p; p += gs_align(8 * T);
   v.tile_work = (uint32_t*)p; p += gs_align(4 * T);
   v.tile_order = (uint32_t*)p; p += gs_align(4 * (T + 8));
-  v.tile_stop_depth = (float*)p;
+  v.tile_stop_depth = (float*)p; p += gs_align(4 * T);
+  v.region_count = (uint32_t*)p;
   return v;
 }
 
@@ -203,9 +211,15 @@ struct PreprocessArgs {
   int grid_x, grid_y;
   int antialiasing;
   const float* extra_channel;  // [P] or NULL
-  int tile_cull;  // GsView.tile_cull: 1 = emit only tiles the alpha >= 1/255 ellipse can reach (gs_tilecull.h)
+  int tile_cull;  // GsView.tile_cull: 1 = emit only tiles the alpha >= 1/255 ellipse can reach (gs_tilecull.h); 2 = region binning
   const float* tile_depth_limit;  // [T] or NULL: depth-limited emission (gs_tilecull.h); only with tile_cull
   int raw_activations;            // GsGaussians.raw_activations
+  // region binning (tile_cull == 2, gs_regionbin.hip): every Gaussian is dropped into the bucket of each 4 x 4-tile region
+  // its alpha >= 1/255 ellipse may reach
+  uint32_t* region_count;         // [rg_x * rg_y][RG_COUNT_STRIDE], zeroed by launch_region_prepare
+  uint2* region_bucket;           // [rg_x * rg_y][region_cap]: (depth bits, Gaussian index)
+  uint32_t region_cap;
+  int rg_x, rg_y;
 };
 int launch_preprocess_fwd(const PreprocessArgs& a, const GeomView& g, hipStream_t s);
 int launch_scan_block_sums(const GeomView& g, int P, hipStream_t s);
@@ -219,6 +233,20 @@ int launch_emit_instances(const GeomView& g, int P, const uint32_t* n_ordered, i
                           const uint32_t* order, uint32_t* tkeys, uint32_t* tvals, hipStream_t s, int debug);
 int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
                        hipStream_t s);
+
+// ---- region binning (gs_regionbin.hip) ----
+#define RG_TILES 4            // a region is RG_TILES x RG_TILES tiles (64 x 64 pixels)
+#define RG_MAX_ENTRIES 16384  // Gaussians one region's workgroup can sort in LDS (128 KB of 64-bit keys)
+static inline __host__ __device__ uint32_t region_capacity(int64_t capacity, int regions) {
+  const int64_t c = regions > 0 ? capacity / regions : 0;
+  return (uint32_t)(c > RG_MAX_ENTRIES ? RG_MAX_ENTRIES : (c < 0 ? 0 : c));
+}
+int launch_region_prepare(const GeomView& g, uint32_t* region_count, int regions, uint32_t P, hipStream_t s);
+int launch_region_bin(const GeomView& g, const uint32_t* region_count, const uint2* region_bucket, uint32_t region_cap, int rg_x,
+                      int rg_y, int grid_x, int grid_y, const float* tile_depth_limit, uint2* ranges, uint32_t* point_list,
+                      int64_t capacity, hipStream_t s);
+int launch_export_keys_region(const uint2* ranges, const uint32_t* point_list, const Splat* splat, int T, uint64_t* keys_sorted,
+                              hipStream_t s);
 
 
 int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
@@ -234,6 +262,9 @@ int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int 
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                            const uint32_t* tile_work, const uint32_t* tile_order, const float* dL_dpix,
                            const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs, hipStream_t s);
+
+int launch_blend_stats(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y, const Splat* splat,
+                       const uint32_t* n_contrib, const uint32_t* tile_work, unsigned long long* out, hipStream_t s);
 
 struct PreprocessBwdArgs {
   int P, D, M;

@@ -154,7 +154,48 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       sp.opacity = load_opacity(a.opacities, idx, a.raw_activations) * h_convolution_scaling;
       sp.rect_min = minx | (miny << 16);
       sp.rect_max = maxx | (maxy << 16);
-      if (a.tile_cull) {
+      if (a.tile_cull == 2) {
+        // Region binning (gs_regionbin.hip): into the bucket of every 4 x 4-tile region that the bounding box of the
+        // alpha >= 1/255 ellipse reaches (inside the reference rectangle) and, with depth limits, whose largest tile bound the
+        // Gaussian is not beyond.  `tiles` counts the regions: non-zero = "may have instances" for everything downstream.
+        const TileCull tc = tilecull_setup(1, sp.x, sp.y, sp.cxx, sp.cxy, sp.cyy, sp.opacity);
+        if (tc.mode != 1) {
+          int tx0 = (int)minx, tx1 = (int)maxx, ty0 = (int)miny, ty1 = (int)maxy;  // tile rectangle [t0, t1)
+          if (tc.mode == 2) {  // one pixel of slack around the ellipse's extents (tilecull_row_span: 0.05 px + 1e-5 relative)
+            const float big = 1.0e6f;
+            const float xl = fminf(fmaxf(sp.x - tc.ex - 1.0f, -big), big), xh = fminf(fmaxf(sp.x + tc.ex + 1.0f, -big), big);
+            const float yl = fminf(fmaxf(sp.y - tc.ey - 1.0f, -big), big), yh = fminf(fmaxf(sp.y + tc.ey + 1.0f, -big), big);
+            tx0 = max(tx0, (int)floorf(xl * 0.0625f));
+            tx1 = min(tx1, (int)floorf(xh * 0.0625f) + 1);
+            ty0 = max(ty0, (int)floorf(yl * 0.0625f));
+            ty1 = min(ty1, (int)floorf(yh * 0.0625f) + 1);
+          }
+          if (tx1 > tx0 && ty1 > ty0) {
+            const uint32_t dbits = __float_as_uint(sp.depth);
+            const int segs_x = (int)depth_limit_segs_x((uint32_t)a.grid_x);
+            for (int ry = ty0 >> 2; ry <= (ty1 - 1) >> 2; ry++) {
+              for (int rx = tx0 >> 2; rx <= (tx1 - 1) >> 2; rx++) {
+                if (a.tile_depth_limit) {
+                  // the region's bound = the largest of its (up to) four row-segment bounds: a pair within its TILE's
+                  // bound lies in a region it is not beyond
+                  float bound = -__builtin_inff();
+#pragma unroll
+                  for (int k = 0; k < RG_TILES; k++) {
+                    const int ty = min(ry * RG_TILES + k, a.grid_y - 1);
+                    const float v = lds_floats ? lds_seg[ty * segs_x + rx] : a.tile_depth_limit[(size_t)T + ty * segs_x + rx];
+                    bound = fmaxf(bound, v);
+                  }
+                  if (depth_beyond_limit(sp.depth, bound)) continue;
+                }
+                const int r = ry * a.rg_x + rx;
+                const uint32_t slot = atomicAdd(&a.region_count[(size_t)r * RG_COUNT_STRIDE], 1u);
+                if (slot < a.region_cap) a.region_bucket[(size_t)r * a.region_cap + slot] = make_uint2(dbits, (uint32_t)idx);
+                tiles++;
+              }
+            }
+          }
+        }
+      } else if (a.tile_cull) {
         const TileCull tc = tilecull_setup(1, sp.x, sp.y, sp.cxx, sp.cxy, sp.cyy, sp.opacity);
         if (tc.mode == 0) {
           tiles = (maxy - miny) * (maxx - minx);
@@ -259,7 +300,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
     }
     g.tiles_touched[idx] = tiles;
     // key of the per-Gaussian depth sort (gs_binning.hip): culled Gaussians sort behind everything
-    g.depth_keys[idx] = tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
+    if (a.tile_cull != 2) g.depth_keys[idx] = tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
     a.radii[idx] = radius_out;
   }
   // per-workgroup partial sum of tiles_touched for the prefix sum
@@ -304,6 +345,7 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(GeomView g, int n
     g.hdr->num_rendered = carry_s;
     g.hdr->overflow = 0;
     g.hdr->P = P;
+    g.hdr->region_mode = 0;
   }
 }
 

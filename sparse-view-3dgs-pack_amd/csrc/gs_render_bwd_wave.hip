@@ -244,6 +244,69 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Developer statistics (gs_debug_blend_stats): what the backward blend's loop meets.  Walks every tile's list exactly as
+// render_bwd_wave_kernel does (same entries, same alpha test) and counts:
+//   0 entries visited | 1 entries with at least one valid pixel | 2 (entry, quadrant) pairs with a valid pixel |
+//   3 valid (entry, pixel) pairs | 4 tiles with work | 5 list entries in those tiles | 6 entries whose every quadrant is
+//   behind its last contributor or untouched by the ellipse's bounding box (what a cheap scalar pre-test would skip)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) blend_stats_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                                                         int W, int H, int grid_x, const Splat* __restrict__ splat,
+                                                         const uint32_t* __restrict__ n_contrib,
+                                                         const uint32_t* __restrict__ tile_work,
+                                                         unsigned long long* __restrict__ out) {
+  const int tile = blockIdx.x;
+  const uint32_t lmax = tile_work[tile];
+  if (lmax == 0) return;
+  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+  const int lane = threadIdx.x;
+  const uint2 range = ranges[tile];
+  const int n = (int)(range.y - range.x);
+  if (n == 0) return;
+  const int px0 = tile_x * TILE_X + (lane & 7), py0 = tile_y * TILE_Y + (lane >> 3);
+  uint32_t lastc[4];
+  for (int s = 0; s < 4; s++) {
+    const int px = px0 + (s & 1) * 8, py = py0 + (s >> 1) * 8;
+    lastc[s] = (px < W && py < H) ? n_contrib[W * py + px] : 0u;
+  }
+  unsigned long long c_vis = 0, c_any = 0, c_quad = 0, c_pix = 0;
+  for (int q = n - (int)lmax; q < n; q++) {
+    const uint32_t contributor = (uint32_t)(n - 1 - q);
+    const uint32_t id = point_list[range.y - q - 1];
+    const float4* rec = reinterpret_cast<const float4*>(&splat[id]);
+    const float4 ra = rec[0];
+    const float4 co = blend_stage_conic(rec[1]);
+    c_vis++;
+    int quads = 0;
+    for (int s = 0; s < 4; s++) {
+      const float dx = ra.x - (float)(px0 + (s & 1) * 8), dy = ra.y - (float)(py0 + (s >> 1) * 8);
+      const float p2 = blend_power2(co, dx, dy);
+      const float alpha = fminf(0.99f, co.w * blend_exp2(p2));
+      const bool valid = contributor < lastc[s] && p2 <= 0.0f && alpha >= 1.0f / 255.0f;
+      const unsigned long long m = __ballot(valid);
+      if (m) quads++;
+      c_pix += (unsigned long long)__popcll(m);
+    }
+    c_quad += quads;
+    c_any += quads ? 1 : 0;
+  }
+  if (lane == 0) {
+    atomicAdd(&out[0], c_vis);
+    atomicAdd(&out[1], c_any);
+    atomicAdd(&out[2], c_quad);
+    atomicAdd(&out[3], c_pix);
+    atomicAdd(&out[4], 1ull);
+    atomicAdd(&out[5], (unsigned long long)n);
+  }
+}
+int launch_blend_stats(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y, const Splat* splat,
+                       const uint32_t* n_contrib, const uint32_t* tile_work, unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(blend_stats_kernel, dim3(grid_x * grid_y), dim3(64), 0, s, ranges, point_list, W, H, grid_x, splat, n_contrib,
+                     tile_work, out);
+  return 0;
+}
+
 // zero fill of the gradient rows (GR_STRIDE = 16 floats = four float4 per row).  With tiles_touched given only the rows of
 // Gaussians that emitted instances are cleared: no atomic lands anywhere else and the per-Gaussian stage does not read the
 // others (PreprocessBwdArgs.skip_uninstanced) - a fifth of the rows with depth-limited lists.

@@ -59,6 +59,8 @@ class GsScratch(C.Structure):
         ("tile_depth_limit", C.c_void_p),
         ("tile_order_out", C.c_void_p),
         ("tile_depth_limit_out", C.c_void_p),
+        ("binned", C.c_int32),
+        ("_pad", C.c_int32),
     ]
 
 
@@ -128,6 +130,9 @@ PROTOTYPES = {
     "export_tile_order": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _P, _P]),
     "export_tile_stop_depth": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _P, _P]),
     "forward_status": (C.c_int, [C.POINTER(GsScratch), _P, _P]),
+    "forward_bin": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P]),
+    "export_binning_region": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _I64, _P, _P, _P]),
+    "debug_blend_stats": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _I32, _P, _P]),
     "tile_depth_limit_floats": (C.c_size_t, [_I32, _I32]),
     "knn_tmp_bytes": (_SZ, [_I32]),
     "knn_mean_dist2": (C.c_int, [_P, _I32, _P, _P, _SZ, _P]),
@@ -168,7 +173,7 @@ PROTOTYPES = {
 # entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
 # (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
 # reference's two 3-channel passes, so the checker does not need it)
-DEVICE_ONLY = ("backward_step", "export_tile_order", "export_tile_stop_depth", "forward_status", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
+DEVICE_ONLY = ("backward_step", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
                "forward_render_x", "backward_x")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}

@@ -50,11 +50,17 @@ class RasterBackend:
         # (csrc/gs_tilecull.h; same images / gradients, ~2.6x fewer instances); GS_TILE_CULL=0 = the
         # reference's bounding-square lists, bit-identical point_list / ranges / num_rendered
         self.tile_cull = os.environ.get("GS_TILE_CULL", "1") != "0"
+        # how the culled lists are built: "region" = region binning (csrc/gs_regionbin.hip, GsView.tile_cull = 2: two launches),
+        # "lsd" = depth sort + emission + partition by tile (csrc/gs_binning.hip, 23 launches).  Same lists tile by tile.
+        self.binning = os.environ.get("GS_BINNING", "region")
+        self.last_deferred_num_rendered = None  # instance count of the last deferred forward whose verdict was collected
+        self._region_off = set()   # (P, W, H) whose regions hold more Gaussians than one workgroup sorts: LSD path
         self._cap_memo = {}
         self._cap_by_buffer = {}
         self._cam_cache = {}
         # one-shot identity of the camera of the NEXT forward (GaussianRasterizer.camera_key); None = hash the view matrix
         self.camera_key = None
+        self._region_key = None    # (P, W, H) of the call being served (see _region_off)
         self._vm_ids = {}
         self.camera_cache_stats = dict(hits=0, misses=0, hashed=0)
         self.order_hint_on = os.environ.get("GS_FWD_ORDER_HINT", "1") != "0"
@@ -114,6 +120,9 @@ class RasterBackend:
         v.sh_degree = int(degree)
         v.prefiltered, v.antialiasing, v.debug = int(bool(prefiltered)), int(bool(antialiasing)), int(bool(debug))
         v.tile_cull = int(self.tile_cull)
+        if self.tile_cull and self.binning == "region" and device.type == "cuda" and \
+                (self._region_key is None or self._region_key not in self._region_off):
+            v.tile_cull = 2
         bg, viewmatrix, projmatrix, campos = (_prep(x, device) for x in (bg, viewmatrix, projmatrix, campos))
         keep += [bg, viewmatrix, projmatrix, campos]
         v.bg, v.viewmatrix, v.projmatrix, v.campos = _ptr(bg), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
@@ -192,10 +201,19 @@ class RasterBackend:
 
         def verdict():
             d["event"].synchronize()
-            ok = int(d["status"][1]) == 0 and int(d["status"][2]) == 0
+            st = tuple(int(x) for x in d["status"][:4])
+            ok = st[1] == 0 and st[2] == 0
+            if "regions" in d:
+                # region binning learns the instance count only here: keep the capacity hint current, and tell a capacity
+                # overflow (render again with more room, the limits were fine) from limits that proved too tight
+                if st[3] > self.REGION_MAX_ENTRIES:
+                    self._region_off.add(d.get("size"))
+                self._update_hint(max(st[0], st[3] * d["regions"]), limited=d.get("limited", False))
+                self.last_deferred_num_rendered = st[0]
             if not ok:
                 self.depth_limit_stats["failed"] += 1
-                d["cache"]["limit_ok"] = False
+                if st[2] != 0 or "regions" not in d:
+                    d["cache"]["limit_ok"] = False
             return ok
         return verdict
 
@@ -320,6 +338,7 @@ class RasterBackend:
         self._check_device(means3D)
         device = means3D.device
         P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+        self._region_key = (P, W, H)
         f32 = dict(dtype=torch.float32, device=device)
         u8 = dict(dtype=torch.uint8, device=device)
         # every pixel and every radius is written by the kernels (gs_forward_geometry / gs_forward_render): empty, not
@@ -411,6 +430,15 @@ class RasterBackend:
             self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(scratch_of(empty, 0, limit)),
                           radii.data_ptr(), status.data_ptr(), stream)
 
+        if view.tile_cull == 2:
+            out = self._forward_region(P, W, H, cache, limit, defer, static, status, cur, geom, img, view, g, radii, stream,
+                                       new_binning, scratch_of, render, remember)
+            if out is not None:
+                num_rendered, binning = out
+                return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
+            # a region holds more Gaussians than one workgroup sorts: this size goes through the LSD path from now on
+            view.tile_cull = 1
+
         if static:
             # capture-safe: fixed capacity, no host wait, no re-run; the caller reads last_status() after the stream drained
             cap = int(self.static_capacity)
@@ -480,6 +508,94 @@ class RasterBackend:
             remember(s)
             return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
 
+    REGION_MAX_ENTRIES = 16384  # csrc/gs_common.h RG_MAX_ENTRIES
+
+    def _forward_region(self, P, W, H, cache, limit, defer, static, status, cur, geom, img, view, g, radii, stream,
+                        new_binning, scratch_of, render, remember):
+        """The forward with region binning (GsView.tile_cull = 2, csrc/gs_regionbin.hip).  The region buckets live in the
+        binning buffer, so it is allocated BEFORE the geometry phase, from the capacity the previous views needed; the
+        instance count is known once the lists are built (gs_forward_bin copies the status words out), which is what
+        the host waits for - the blend is already running then.  Too small a capacity (or a bucket that overflowed)
+        sets the overflow flag: nothing valid was produced and the view is rendered again with what the status asks for.
+        -> (num_rendered, binning buffer), or None when a region holds more Gaussians than one workgroup can sort."""
+        regions = ((((W + 15) // 16) + 3) // 4) * ((((H + 15) // 16) + 3) // 4)
+
+        def needed(st):
+            return max(int(st[0]), int(st[3]) * regions)
+
+        def geometry(s):
+            self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(s), radii.data_ptr(), None, stream)
+
+        if static:
+            cap = max(int(self.static_capacity), regions)
+            binning = new_binning(cap)
+            s = scratch_of(binning, cap, limit)
+            geometry(s)
+            self.api.call("forward_bin", C.byref(view), C.byref(g), C.byref(s), None, stream)
+            render(s)
+            if limit is not None:
+                self.depth_limit_stats["used"] += 1
+            self.api.call("forward_status", C.byref(s), status.data_ptr(), stream)
+            remember(s)
+            return cap, binning
+
+        limits = (limit, None) if limit is not None else (None,)
+        for limit in limits:
+            limited = limit is not None
+            hint = self._capacity_hint_limited if (limited and self._capacity_hint_limited > 0) else self._capacity_hint
+            cap = hint if hint > 0 else max(8 * P, 1 << 20)
+            for attempt in range(6):
+                cap = max(cap, regions)
+                binning = new_binning(cap)
+                s = scratch_of(binning, cap, limit)
+                geometry(s)
+                if limited and defer:
+                    # the caller collects the verdict (capacity AND limits) later: no host wait at all in this forward
+                    self.api.call("forward_bin", C.byref(view), C.byref(g), C.byref(s), None, stream)
+                    render(s)
+                    self.depth_limit_stats["used"] += 1
+                    ring = self._status_ring.setdefault(cur.device.index if hasattr(cur, "device") else 0, [[], 0])
+                    if len(ring[0]) < 8:
+                        ring[0].append(torch.zeros((4,), dtype=torch.int32).pin_memory())
+                    block = ring[0][ring[1] % len(ring[0])]
+                    ring[1] += 1
+                    self.api.call("forward_status", C.byref(s), block.data_ptr(), stream)
+                    done = torch.cuda.Event()
+                    done.record(cur)
+                    self.deferred = dict(status=block, event=done, cache=cache, regions=regions, limited=True, size=(P, W, H))
+                    remember(s)
+                    return cap, binning
+                self.api.call("forward_bin", C.byref(view), C.byref(g), C.byref(s), status.data_ptr(), stream)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                render(s)
+                ev.synchronize()  # the lists are built (the blend is running): did they fit?
+                st = tuple(int(x) for x in status[:4])
+                if st[1] == 0:
+                    break
+                if st[3] > self.REGION_MAX_ENTRIES:
+                    self._region_off.add((P, W, H))
+                    return None
+                cap = int(needed(st) * 1.25) + 4096
+                del binning
+            else:
+                raise RuntimeError("region binning: the capacity did not settle (status %r)" % (st,))
+            self._update_hint(needed(st), limited=limited)
+            num_rendered = st[0]
+            if limited:
+                # depth-limited lists: the blend checks that every bounded tile saturated inside the part of its list
+                # that is certainly complete; the host has to know before it hands the image out
+                self.depth_limit_stats["used"] += 1
+                self.api.call("forward_status", C.byref(s), status.data_ptr(), stream)
+                cur.synchronize()
+                if int(status[2]) != 0:
+                    self.depth_limit_stats["failed"] += 1
+                    cache["limit_ok"] = False
+                    del binning
+                    continue
+            remember(s)
+            return num_rendered, binning
+
     def _render(self, scratch, fsgs, extra, view, g, out_color, out_invdepth, out_extra, stream):
         if fsgs:
             self.api.call("forward_render_fsgs", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
@@ -506,6 +622,7 @@ class RasterBackend:
         device = means3D.device
         P = int(means3D.shape[0])
         H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+        self._region_key = (P, W, H)
         M = int(sh.shape[1]) if (sh is not None and sh.numel() != 0) else 0
         f32 = dict(dtype=torch.float32, device=device)
         # every row is written by gs_backward (culled rows become 0): empty, not zeros
@@ -677,7 +794,14 @@ class RasterBackend:
         self.api.call("export_geom", C.byref(s), P, _ptr(o["depths"]), _ptr(o["means2D"]), _ptr(o["cov3D"]),
                       _ptr(o["conic_opacity"]), _ptr(o["rgb"]), _ptr(o["clamped"]), _ptr(o["tiles_touched"]),
                       _ptr(o["point_offsets"]), st)
-        self.api.call("export_binning", C.byref(s), R, _ptr(o["keys_sorted"]), _ptr(o["point_list"]), st)
+        from .capi import GsError
+        try:
+            self.api.call("export_binning", C.byref(s), R, _ptr(o["keys_sorted"]), _ptr(o["point_list"]), st)
+        except GsError as e:
+            if e.code != -5:
+                raise
+            # lists built by region binning: keys rebuilt from ranges[] (tile lists lie in point_list in no particular order)
+            self.api.call("export_binning_region", C.byref(s), W, H, R, _ptr(o["keys_sorted"]), _ptr(o["point_list"]), st)
         self.api.call("export_img", C.byref(s), W, H, _ptr(o["final_T"]), _ptr(o["n_contrib"]), _ptr(o["ranges"]), st)
         if device.type == "cuda":
             torch.cuda.current_stream(device).synchronize()

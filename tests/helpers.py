@@ -92,3 +92,24 @@ def check_grads(hg, og, name, tol=TOL, chain_tol=CHAIN_TOL):
         t = chain_tol if k in CHAIN_TENSORS else tol
         assert e <= t, "%s: dL_d%s rel err %.3e > %.0e" % (name, k, e, t)
     return errs
+
+
+# ---- instance lists, independent of where a tile's list lies inside point_list ---------------------------------------
+def canonical_lists(st):
+    """-> (counts[T], keys[R]): keys = (tile << 32 | Gaussian id) of every list entry, tile after tile, each tile's entries
+    in list order.  The LSD binning stores the lists in tile order; region binning (GsView.tile_cull = 2) places them
+    wherever its regions reserved room - ranges[] is the only map.  Also checks that the ranges tile [0, R) exactly."""
+    import numpy as np
+    T = st["ranges"].reshape(-1, 2).long().numpy()
+    counts = T[:, 1] - T[:, 0]
+    pl = st["point_list"].long().numpy()
+    assert (counts >= 0).all() and int(counts.sum()) == pl.size, (int(counts.sum()), pl.size)
+    nz = counts > 0
+    if nz.any():
+        order = np.argsort(T[nz, 0], kind="stable")
+        s0, c0 = T[nz, 0][order], counts[nz][order]
+        assert s0[0] == 0 and (s0[1:] == s0[:-1] + c0[:-1]).all(), "tile ranges overlap or leave holes"
+    tiles = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+    first = np.cumsum(counts) - counts                       # canonical start of each tile
+    src = np.repeat(T[:, 0] - first, counts) + np.arange(int(counts.sum()), dtype=np.int64)
+    return counts, (tiles << 32) | pl[src]

@@ -34,15 +34,9 @@ def culled_lists(hip):
 
 
 def pair_keys(st):
-    """(tile << 32 | gaussian id) of every list entry, in list order."""
-    T = st["ranges"].reshape(-1, 2).long()
-    counts = (T[:, 1] - T[:, 0]).numpy()
-    tiles = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
-    # lists are stored tile after tile, so entry i belongs to tiles[i]
-    assert int(counts.sum()) == st["point_list"].numel()
-    starts = T[:, 0].numpy()[counts > 0]
-    assert np.array_equal(np.sort(starts), starts)
-    return (tiles << 32) | st["point_list"].long().numpy()
+    """(tile << 32 | gaussian id) of every list entry, tile after tile, in list order (helpers.canonical_lists)."""
+    from helpers import canonical_lists
+    return canonical_lists(st)[1]
 
 
 def check_lists(h, o, W, H, name):
