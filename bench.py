@@ -319,7 +319,9 @@ def main():
         return graphed.step(kk) if graphed is not None else tr.step(kk)
 
     def settle():
-        if hasattr(tr, "sync"):
+        if graphed is not None:
+            graphed.sync()
+        elif hasattr(tr, "sync"):
             tr.sync()
 
     k = 0
@@ -368,18 +370,21 @@ def main():
         for _ in range(cycle):
             graphed.step(k)
             k += 1
+        graphed.sync()
         barrier()
         if graph_mode == "auto":
             t1 = time.perf_counter()
             for _ in range(8):
                 graphed.step(k)
                 k += 1
+            graphed.sync()
             barrier()
             trial["graph"] = (time.perf_counter() - t1) / 8 * 1e3
             graph_choice = {"graph_ms_per_step": trial["graph"], "eager_ms_per_step": trial["eager"],
                             "chosen": "graph" if trial["graph"] < trial["eager"] else "eager"}
             log("launch form: graph %.3f ms, eager %.3f ms per step -> %s" % (trial["graph"], trial["eager"], graph_choice["chosen"]))
             if graph_choice["chosen"] == "eager":
+                graphed.sync()
                 graphed = None
                 for _ in range(3):  # back on the eager allocator state before timing
                     tr.step(k)

@@ -136,6 +136,11 @@ typedef struct GsScratch {
   int32_t binned;                  /* 1: gs_forward_bin has already built the instance lists of this view in these buffers;
                                       gs_forward_render* then only blends */
   int32_t _pad;
+  const uint32_t* step_tag;        /* optional, device: gs_forward_status then copies TWELVE words out - the four status words,
+                                      four reserved ones, *step_tag, three reserved - so that a caller that replays a
+                                      captured graph of the step can tell, by polling its pinned block for the tag it
+                                      uploaded before the replay, that the status of THAT replay has arrived (no stream
+                                      synchronisation, no event inside the graph) */
 } GsScratch;
 
 /* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by
@@ -268,6 +273,17 @@ typedef struct GsStepState {
   const float* rows_override; /* parity probe, normally NULL: [P,16] blend sums to use INSTEAD of running stage 1 (layout:
                                 gs_backward_from_rows) - lets a test hand the fused tail and the three-kernel tail the
                                 very same sums and compare them bit for bit */
+  /* ---- data-parallel form (N > 1): gradients OUT instead of the Adam step ----
+   * grad_out[0] != NULL: the gradients with respect to the RAW rows (xyz [P,3], features [P,16,3], opacity [P], scaling [P,3],
+   * rotation [P,4]: the five pointers, typically into one flat buffer that is then all-reduced) are WRITTEN there and no
+   * parameter or moment is touched; m[] / v[] / lr[] / step[] are ignored.  The statistics are then this view's
+   * INCREMENTS, assigned: xyz_gradient_accum[i] = |dL/dmean2D_i| (0 when culled), denom[i] = visible ? 1 : 0 (summed over
+   * ranks by the caller); max_radii2D is updated in place as always.  fail_flag (device, may be NULL): set to 1.0f when
+   * the forward had flagged overflow or trunc_failed - the call then writes ZERO statistic increments and no gradients -
+   * else to 0.0f; reduced (sum) with the gradients it tells every rank whether any rank's view was invalid
+   * (gs_adam_step_gated takes it as its gate). */
+  float* grad_out[5];
+  float* fail_flag;
 } GsStepState;
 int gs_backward_step(const GsView* view, const GsGaussians* g, const int32_t* radii,
                      const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
@@ -425,9 +441,13 @@ typedef struct GsLgdwtParams {
   float patch_weight;        /* beta = 0.1 */
   float patch_elems_per_sel; /* C * (patch/2)^2 */
   int32_t dwt_enable, patch_enable;
+  int32_t reset_sums;        /* 1: the call zeroes sums[0..12] after it has read them (the accumulators of the next view:
+                                a caller that keeps ONE sums buffer per camera, word 13 preset, then needs no fill kernel) */
+  int32_t _pad;
 } GsLgdwtParams;
 /* sums[16]: 0 l1 | 1 ssim | 2..9 bands | 10..12 patch | 13 selected patches.  running_mean: device scalar,
- * updated in place (train.py:193-195).  out[24]: 0 loss 1 base 2 dwt 3 patch 4 dwt_scale 5 l1 6 ssim;
+ * updated in place (train.py:193-195).  out[24]: 0 loss 1 base 2 dwt 3 patch 4 dwt_scale 5 l1 6 ssim 7 the running mean
+ * before the call;
  * 8 c_l1, 9 c_ssim, 10..17 c_band, 18..20 c_patch = dLoss/d(term sum). */
 int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* params /*host*/, float* out,
                      void* stream);
@@ -453,6 +473,12 @@ typedef struct GsAdamSeg {
 int gs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                  const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
                  void* stream);
+/* the same, but a no-op on the device when *gate != 0 (gate: device float, may be NULL = gs_adam_step): the data-parallel
+ * step passes the all-reduced GsStepState.fail_flag - if any rank rendered from lists that proved too short, no replica
+ * steps, and every rank repeats the step once its host has seen the flag */
+int gs_adam_step_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
+                       const float* gate, void* stream);
 
 /* ---- per-Gaussian elementwise work of the train step outside the rasterizer ----
  * Parameter activations of GaussianModel (LGDWT-GS/scene/gaussian_model.py:40-60,102-117): scales = exp(scaling),

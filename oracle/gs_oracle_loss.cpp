@@ -543,6 +543,7 @@ int gso_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParam
   const float base = (1.0f - p.lambda_dssim) * l1 + p.lambda_dssim * (1.0f - ssim);
   float loss = base, dwt = 0.f, scale = 0.f, patch = 0.f;
   for (int k = 0; k < 24; k++) out[k] = 0.f;
+  out[7] = running_mean[0];
   if (p.dwt_enable) {
     for (int k = 0; k < 8; k++) dwt += p.dwt_w[k] * (sums[2 + k] / (k < 4 ? p.n_band1 : p.n_band2));
     const float ratio = base / (dwt + 1e-8f);
@@ -563,6 +564,8 @@ int gso_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParam
   out[0] = loss; out[1] = base; out[2] = dwt; out[3] = patch; out[4] = scale; out[5] = l1; out[6] = ssim;
   out[8] = (1.0f - p.lambda_dssim) / p.n_pix;
   out[9] = -p.lambda_dssim / p.n_pix;
+  if (p.reset_sums)
+    for (int k = 0; k < 13; k++) const_cast<float*>(sums)[k] = 0.f;
   return GS_OK;
 }
 int gso_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_partials, float* running_mean,
@@ -574,6 +577,9 @@ int gso_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n
   double add = 0;
   for (int64_t i = 0; i < n_partials; i++) add += (double)ssim_partials[i];
   s2[1] += (float)add;
-  return gso_lgdwt_combine(s2, running_mean, pp, out, nullptr);
+  const int rc = gso_lgdwt_combine(s2, running_mean, pp, out, nullptr);
+  if (rc == GS_OK && pp->reset_sums)
+    for (int k = 0; k < 13; k++) const_cast<float*>(sums)[k] = 0.f;
+  return rc;
 }
 }

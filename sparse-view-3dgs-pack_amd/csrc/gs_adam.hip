@@ -39,7 +39,9 @@ __device__ __forceinline__ bool adam_coef(const AdamSegs& s, long long i, float&
 
 __global__ void __launch_bounds__(GS_BLOCK) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
-                                                        AdamSegs segs, float b1, float b2, float eps) {
+                                                        AdamSegs segs, float b1, float b2, float eps,
+                                                        const float* __restrict__ gate) {
+  if (gate && *gate != 0.0f) return;  // gs_adam_step_gated: some rank's view was invalid - nobody steps
   const long long n4 = n >> 2;
   for (long long i4 = (long long)blockIdx.x * GS_BLOCK + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * GS_BLOCK) {
     float4 pp = reinterpret_cast<float4*>(p)[i4];
@@ -100,9 +102,17 @@ __global__ void __launch_bounds__(GS_BLOCK) adam_kernel(float* __restrict__ p, c
   }
 }
 
+extern "C" int gs_adam_step_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
+                                  const float* gate, void* stream);
 extern "C" int gs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                             const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
                             void* stream) {
+  return gs_adam_step_gated(params, grads, exp_avg, exp_avg_sq, n, segs, nseg, beta1, beta2, eps, step, nullptr, stream);
+}
+extern "C" int gs_adam_step_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
+                                  const float* gate, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || (nseg > 0 && !segs)) return GS_E_NULL;
   if (n < 0 || nseg < 0 || nseg > ADAM_MAX_SEG || step < 1) return GS_E_SHAPE;
   if (n == 0) return GS_OK;
@@ -131,7 +141,7 @@ extern "C" int gs_adam_step(float* params, const float* grads, float* exp_avg, f
   // grid-stride loop (and 0.331 with 2048) - short-lived workgroups keep more requests in flight
   if (blocks > (1ll << 20)) blocks = 1ll << 20;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(GS_BLOCK), 0, s, params, grads, exp_avg, exp_avg_sq,
-                     (long long)n, a, beta1, beta2, eps);
+                     (long long)n, a, beta1, beta2, eps, gate);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }

@@ -364,8 +364,10 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
 // host half of gs_backward_step: argument rules and the bias corrections (as gs_adam_step computes them)
 static int step_args(const GsGaussians* g, const GsStepState* st, StepArgs& sa) {
   if (!st->xyz || !st->features || !st->opacity || !st->scaling || !st->rotation) return GS_E_NULL;
-  for (int k = 0; k < 5; k++)
-    if (!st->m[k] || !st->v[k]) return GS_E_NULL;
+  const bool grads_out = st->grad_out[0] != nullptr;
+  for (int k = 0; k < 5; k++) {
+    if (grads_out ? !st->grad_out[k] : (!st->m[k] || !st->v[k])) return GS_E_NULL;
+  }
   const bool any_stat = st->max_radii2D || st->xyz_gradient_accum || st->denom;
   if (any_stat && !(st->max_radii2D && st->xyz_gradient_accum && st->denom)) return GS_E_NULL;
   if (g->means3D != st->xyz || g->shs != st->features) return GS_E_SHAPE;  // no activation between them
@@ -586,10 +588,20 @@ size_t gs_tile_depth_limit_floats(int32_t W, int32_t H) {
   return depth_limit_floats((uint32_t)((W + TILE_X - 1) / TILE_X), (uint32_t)((H + TILE_Y - 1) / TILE_Y));
 }
 
+__global__ void status_tag_kernel(GeomHeader* hdr, const uint32_t* __restrict__ tag) { hdr->step_tag = *tag; }
+
 int gs_forward_status(const GsScratch* sc, uint32_t* out, void* stream) {
   if (!sc || !sc->geom || !out) return GS_E_NULL;
   if (sc->geom_bytes < sizeof(GeomHeader)) return GS_E_SCRATCH;
-  GS_HIP_CHECK(hipMemcpyAsync(out, sc->geom, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  hipStream_t s = (hipStream_t)stream;
+  size_t bytes = 16;
+  if (sc->step_tag) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(status_tag_kernel, dim3(1), dim3(1), 0, s, (GeomHeader*)sc->geom, sc->step_tag);
+    GS_LAUNCH_CHECK(s, 0);
+    bytes = 48;
+  }
+  GS_HIP_CHECK(hipMemcpyAsync(out, sc->geom, bytes, hipMemcpyDeviceToHost, s));
   return GS_OK;
 }
 

@@ -34,7 +34,8 @@ struct GeomHeader {
   uint32_t sort_n;        // instances the binning stage really processes: overflow ? 0 : num_rendered
   uint32_t n_ordered;     // Gaussians in the depth order = those that emit instances (the sort's first pass drops the rest)
   uint32_t region_mode;   // 1: the lists of this view were built by region binning (gs_regionbin.hip), 0: by the LSD path
-  uint32_t pad[56];
+  uint32_t step_tag;      // word 8: GsScratch.step_tag as gs_forward_status found it
+  uint32_t pad[55];
 };
 static_assert(sizeof(GeomHeader) == 256, "header is one 256-B block");
 

@@ -902,7 +902,7 @@ int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t
 // host with .item() every iteration; here the running mean lives in device memory and the coefficient vector of
 // the backward kernels is produced in the same launch.
 //   sums[16] : 0 l1_sum | 1 ssim_sum | 2..9 band_sums | 10..12 patch_sums | 13 n_selected_patches
-//   out[24]  : 0 loss | 1 base | 2 dwt | 3 patch | 4 dwt_scale | 5 l1 | 6 ssim |
+//   out[24]  : 0 loss | 1 base | 2 dwt | 3 patch | 4 dwt_scale | 5 l1 | 6 ssim | 7 running mean before the call |
 //              8 c_l1 | 9 c_ssim | 10..17 c_band[8] | 18..20 c_patch[3]      (dL/d term-sum, for upstream grad 1)
 __global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __restrict__ sums, float* running_mean,
                                                              GsLgdwtParams p, float* __restrict__ out,
@@ -924,6 +924,7 @@ __global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __rest
   float loss = base;
   float dwt = 0.f, scale = 0.f, patch = 0.f;
   for (int k = 0; k < 24; k++) out[k] = 0.f;
+  out[7] = running_mean[0];  // the running mean BEFORE this view (a caller that has to take the view back restores it)
   if (p.dwt_enable) {
     for (int k = 0; k < 8; k++) {
       const float cnt = k < 4 ? p.n_band1 : p.n_band2;
@@ -947,6 +948,10 @@ __global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __rest
   out[0] = loss; out[1] = base; out[2] = dwt; out[3] = patch; out[4] = scale; out[5] = l1; out[6] = ssim;
   out[8] = (1.0f - p.lambda_dssim) / p.n_pix;
   out[9] = -p.lambda_dssim / p.n_pix;
+  if (p.reset_sums) {  // every sum has been read (this thread read them all): ready for the next view's accumulation
+    float* z = const_cast<float*>(sums);
+    for (int k = 0; k < 13; k++) z[k] = 0.f;
+  }
 }
 
 int gs_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_partials, float* running_mean,

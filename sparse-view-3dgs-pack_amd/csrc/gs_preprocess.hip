@@ -173,6 +173,11 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
           if (tx1 > tx0 && ty1 > ty0) {
             const uint32_t dbits = __float_as_uint(sp.depth);
             const int segs_x = (int)depth_limit_segs_x((uint32_t)a.grid_x);
+            // A returning atomic takes a microsecond or two to come back: the (up to four: a footprint within 2 x 2 regions,
+            // nearly all of them) atomics of a Gaussian are issued back to back, their bucket writes follow; larger
+            // footprints take the rest one by one.
+            int p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // (selects, not an indexed array: that would live in scratch memory)
+            int n_pend = 0;
             for (int ry = ty0 >> 2; ry <= (ty1 - 1) >> 2; ry++) {
               for (int rx = tx0 >> 2; rx <= (tx1 - 1) >> 2; rx++) {
                 if (a.tile_depth_limit) {
@@ -188,11 +193,29 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
                   if (depth_beyond_limit(sp.depth, bound)) continue;
                 }
                 const int r = ry * a.rg_x + rx;
-                const uint32_t slot = atomicAdd(&a.region_count[(size_t)r * RG_COUNT_STRIDE], 1u);
-                if (slot < a.region_cap) a.region_bucket[(size_t)r * a.region_cap + slot] = make_uint2(dbits, (uint32_t)idx);
                 tiles++;
+                if (n_pend < 4) {
+                  p0 = n_pend == 0 ? r : p0;
+                  p1 = n_pend == 1 ? r : p1;
+                  p2 = n_pend == 2 ? r : p2;
+                  p3 = n_pend == 3 ? r : p3;
+                  n_pend++;
+                } else {
+                  const uint32_t slot = atomicAdd(&a.region_count[(size_t)r * RG_COUNT_STRIDE], 1u);
+                  if (slot < a.region_cap) a.region_bucket[(size_t)r * a.region_cap + slot] = make_uint2(dbits, (uint32_t)idx);
+                }
               }
             }
+            uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
+            if (n_pend > 0) s0 = atomicAdd(&a.region_count[(size_t)p0 * RG_COUNT_STRIDE], 1u);
+            if (n_pend > 1) s1 = atomicAdd(&a.region_count[(size_t)p1 * RG_COUNT_STRIDE], 1u);
+            if (n_pend > 2) s2 = atomicAdd(&a.region_count[(size_t)p2 * RG_COUNT_STRIDE], 1u);
+            if (n_pend > 3) s3 = atomicAdd(&a.region_count[(size_t)p3 * RG_COUNT_STRIDE], 1u);
+            const uint2 entry = make_uint2(dbits, (uint32_t)idx);
+            if (s0 < a.region_cap) a.region_bucket[(size_t)p0 * a.region_cap + s0] = entry;
+            if (s1 < a.region_cap) a.region_bucket[(size_t)p1 * a.region_cap + s1] = entry;
+            if (s2 < a.region_cap) a.region_bucket[(size_t)p2 * a.region_cap + s2] = entry;
+            if (s3 < a.region_cap) a.region_bucket[(size_t)p3 * a.region_cap + s3] = entry;
           }
         }
       } else if (a.tile_cull) {

@@ -171,6 +171,19 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
   }
 }
 
+// data-parallel form: the workgroup's piece of one gradient row array written out (same element order as adam_block reads)
+template <int N, typename G>
+__device__ __forceinline__ void grad_block(float* __restrict__ out, int first, int cnt, const G& grad) {
+  float* of = out + (size_t)first * N;
+  const int nfl = cnt * N;
+  if ((((uintptr_t)of) & 15) == 0 && (nfl % 4 == 0)) {
+    for (int j = 4 * threadIdx.x; j < nfl; j += 4 * GS_BLOCK)
+      *reinterpret_cast<float4*>(of + j) = make_float4(grad(j), grad(j + 1), grad(j + 2), grad(j + 3));
+  } else {
+    for (int j = threadIdx.x; j < nfl; j += GS_BLOCK) of[j] = grad(j);
+  }
+}
+
 // LDS image of the 11 non-SH gradients of the workgroup's Gaussians, row arrays back to back in their own element order
 #define SG_XYZ 0
 #define SG_OPAC (3 * GS_BLOCK)
@@ -182,9 +195,21 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   __shared__ float s_sh[GS_BLOCK * SH_LDS_ROW];
   __shared__ float s_g[SG_TOTAL];
   const GsStepState& st = sa.st;
+  const bool grads_out = st.grad_out[0] != nullptr;  // data-parallel form: gradients out, no Adam (gsplat.h)
   // the forward ran out of binning capacity (possible only when the caller did not re-run it: a replayed graph): the
   // image was not rendered, so nothing may be updated - the host sees the flag and repeats the step eagerly
-  if (sa.hdr->overflow | sa.hdr->trunc_failed) return;
+  const bool failed = (sa.hdr->overflow | sa.hdr->trunc_failed) != 0u;
+  if (grads_out && st.fail_flag && blockIdx.x == 0 && threadIdx.x == 0) *st.fail_flag = failed ? 1.0f : 0.0f;
+  if (failed) {
+    if (grads_out && st.max_radii2D) {  // this view contributes no statistics (the sum over ranks must stay finite)
+      const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+      if (i < a.P) {
+        st.xyz_gradient_accum[i] = 0.f;
+        st.denom[i] = 0.f;
+      }
+    }
+    return;
+  }
   // step-dependent constants from device memory when the launch is replayed from a captured graph
   if (st.coef_dev) {
 #pragma unroll
@@ -210,10 +235,17 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   if (active) geometry_backward(a, idx, gb);
 
   // ---- view statistics (train.py:266-268, gaussian_model.py:471-473)
-  if (in_range && visible && st.max_radii2D) {
-    st.max_radii2D[idx] = fmaxf(st.max_radii2D[idx], (float)radius);
-    st.xyz_gradient_accum[idx] += sqrtf(gb.dmean2D_x * gb.dmean2D_x + gb.dmean2D_y * gb.dmean2D_y);
-    st.denom[idx] += 1.0f;
+  if (in_range && st.max_radii2D) {
+    const float gnorm = sqrtf(gb.dmean2D_x * gb.dmean2D_x + gb.dmean2D_y * gb.dmean2D_y);
+    if (grads_out) {  // this view's increments, assigned (the caller sums them over ranks)
+      if (visible) st.max_radii2D[idx] = fmaxf(st.max_radii2D[idx], (float)radius);
+      st.xyz_gradient_accum[idx] = visible ? gnorm : 0.f;
+      st.denom[idx] = visible ? 1.0f : 0.f;
+    } else if (visible) {
+      st.max_radii2D[idx] = fmaxf(st.max_radii2D[idx], (float)radius);
+      st.xyz_gradient_accum[idx] += gnorm;
+      st.denom[idx] += 1.0f;
+    }
   }
   // ---- activation backward of this Gaussian's rows into the LDS gradient image
   {
@@ -265,6 +297,15 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
       return src[k] * src[16 + ch];
     }
   };
+  if (grads_out) {
+    // the workgroup's contiguous piece of each gradient row array, straight from the LDS image
+    grad_block<3>(st.grad_out[0], first, cnt, Lds{s_g + SG_XYZ});
+    grad_block<1>(st.grad_out[2], first, cnt, Lds{s_g + SG_OPAC});
+    grad_block<3>(st.grad_out[3], first, cnt, Lds{s_g + SG_SCALE});
+    grad_block<4>(st.grad_out[4], first, cnt, Lds{s_g + SG_ROT});
+    grad_block<48>(st.grad_out[1], first, cnt, ShGrad{s_sh});
+    return;
+  }
   if (st.step[0] > 0)
     adam_block<3, 0>(st.xyz, st.m[0], st.v[0], first, cnt, Lds{s_g + SG_XYZ}, sa.lr_bc1[0], 0.f, sa.inv_sqrt_bc2[0], b1, b2, eps);
   if (st.step[2] > 0)

@@ -61,6 +61,7 @@ class GsScratch(C.Structure):
         ("tile_depth_limit_out", C.c_void_p),
         ("binned", C.c_int32),
         ("_pad", C.c_int32),
+        ("step_tag", C.c_void_p),
     ]
 
 
@@ -81,7 +82,8 @@ class GsGrads(C.Structure):
 class GsLgdwtParams(C.Structure):
     _fields_ = [("lambda_dssim", C.c_float), ("n_pix", C.c_float), ("n_band1", C.c_float), ("n_band2", C.c_float),
                 ("dwt_w", C.c_float * 8), ("patch_w", C.c_float * 3), ("patch_weight", C.c_float),
-                ("patch_elems_per_sel", C.c_float), ("dwt_enable", C.c_int32), ("patch_enable", C.c_int32)]
+                ("patch_elems_per_sel", C.c_float), ("dwt_enable", C.c_int32), ("patch_enable", C.c_int32),
+                ("reset_sums", C.c_int32), ("_pad", C.c_int32)]
 
 
 class GsAdamSeg(C.Structure):
@@ -94,7 +96,8 @@ class GsStepState(C.Structure):
                 ("rotation", C.c_void_p), ("m", C.c_void_p * 5), ("v", C.c_void_p * 5), ("lr", C.c_float * 6),
                 ("step", C.c_int32 * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_radii2D", C.c_void_p), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
-                ("coef_dev", C.c_void_p), ("rows_override", C.c_void_p)]
+                ("coef_dev", C.c_void_p), ("rows_override", C.c_void_p), ("grad_out", C.c_void_p * 5),
+                ("fail_flag", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -159,6 +162,7 @@ PROTOTYPES = {
     "ssim_partials_count": (C.c_int64, [_I32, _I32, _I32, _I32]),
     "ssim_fwd_partials": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "adam_step": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P]),
+    "adam_step_gated": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P, _P]),
     "activations_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P]),
     "activations_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "densify_stats": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P]),
@@ -173,7 +177,7 @@ PROTOTYPES = {
 # entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
 # (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
 # reference's two 3-channel passes, so the checker does not need it)
-DEVICE_ONLY = ("backward_step", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
+DEVICE_ONLY = ("backward_step", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "adam_step_gated", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
                "forward_render_x", "backward_x")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}

@@ -29,6 +29,7 @@ def _p(t):
 class LossOps:
     def __init__(self, api):
         self.api = api
+        self._unit = {}   # device -> the constant 1 handed to autograd as the seed gradient (unit_grad)
         ops = self
 
         class _L1(torch.autograd.Function):
@@ -163,6 +164,16 @@ class LossOps:
         self._L1, self._Haar, self._Dwt2L1, self._PatchDwt, self._SSIMMap = _L1, _Haar, _Dwt2L1, _PatchDwt, _SSIMMap
 
     # ---------------------------------------------------------------- loss_utils.py names
+    def unit_grad(self, device):
+        """A cached scalar 1 on `device`: `torch.autograd.backward(loss, ops.unit_grad(loss.device))` instead of
+        `loss.backward()` saves the fill kernel autograd launches for its implicit seed, and FusedLGDWTLoss recognises
+        the tensor and skips its own multiply by the upstream gradient."""
+        device = torch.device(device)
+        u = self._unit.get(device)
+        if u is None:
+            u = self._unit[device] = torch.ones((), dtype=torch.float32, device=device)
+        return u
+
     def l1_loss(self, network_output, gt):
         return self._L1.apply(network_output, gt)
 
@@ -240,13 +251,15 @@ class FusedLGDWTLoss(torch.autograd.Function):
     No torch elementwise pass over an image, no host synchronisation."""
 
     @staticmethod
-    def forward(ctx, ops, raw, gt, mask, n_sel, running_mean, params):
+    def forward(ctx, ops, raw, gt, mask, sums, running_mean, params):
+        """sums: the camera's persistent 16-float accumulator (LGDWTCriterion.sums_for): words 0..12 are zero on entry -
+        gs_lgdwt_combine_p re-zeroes them after reading (GsLgdwtParams.reset_sums) - and word 13 holds the number of
+        selected patches; so neither a fill nor a copy kernel runs per step."""
         api = ops.api
         raw, gt = _c(raw), _c(gt)
         Cc, H, W = raw.shape
         img = raw.clamp(0, 1)
         st = _stream(raw)
-        sums = torch.zeros((16,), dtype=torch.float32, device=raw.device)
         d1, d2, d3 = torch.empty_like(raw), torch.empty_like(raw), torch.empty_like(raw)
         if params.dwt_enable:   # L1 and the eight band sums from one read of the two images
             api.call("l1_dwt2_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, sums.data_ptr(), sums[2:].data_ptr(), st)
@@ -259,7 +272,6 @@ class FusedLGDWTLoss(torch.autograd.Function):
         if params.patch_enable:
             api.call("patch_dwt_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
                      sums[10:].data_ptr(), st)
-            sums[13:14].copy_(n_sel)
         out = torch.empty((24,), dtype=torch.float32, device=raw.device)
         api.call("lgdwt_combine_p", sums.data_ptr(), partials.data_ptr(), partials.numel(), running_mean.data_ptr(),
                  C.byref(params.c), out.data_ptr(), st)
@@ -277,7 +289,10 @@ class FusedLGDWTLoss(torch.autograd.Function):
         api, params = ctx.ops.api, ctx.params
         Cc, H, W = raw.shape
         st = _stream(raw)
-        coef = (out[8:24] * g).contiguous()   # [c_l1, c_ssim, c_band x8, c_patch x3, ...] x upstream
+        # [c_l1, c_ssim, c_band x8, c_patch x3, ...] x upstream gradient; a caller that seeds the backward with
+        # LossOps.unit_grad (the train step does) gets the coefficients as they are: no multiply kernel
+        unit = ctx.ops._unit.get(g.device)
+        coef = out[8:24] if (unit is not None and g.data_ptr() == unit.data_ptr()) else (out[8:24] * g).contiguous()
         grad = torch.empty_like(raw)
         if params.dwt_enable:
             api.call("l1_dwt2_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, coef.data_ptr(), coef[2:].data_ptr(),
@@ -317,6 +332,7 @@ class _FusedParams:
         self.patch_enable = bool(crit.patch_dwt_enable and H >= crit.patch_size and W >= crit.patch_size)
         self.dwt_enable = bool(crit.dwt_enable)
         c.dwt_enable, c.patch_enable = int(self.dwt_enable), int(self.patch_enable)
+        c.reset_sums = 1
         self.c = c
         self.patch_size = crit.patch_size
         self.n_ssim_partials = int(crit.ops.api.raw("ssim_partials_count")(1, Cc, H, W))
@@ -334,6 +350,7 @@ class LGDWTCriterion:
         self.ops = ops
         self.fused = fused        # one autograd node on the UN-clamped render (see FusedLGDWTLoss)
         self._fp = {}
+        self._sums_nomask, self._no_mask = {}, {}
         self.lambda_dssim = lambda_dssim
         self.dwt_enable, self.patch_dwt_enable = dwt_enable, patch_dwt_enable
         self.dwt_weights = tuple(dwt_weights)
@@ -348,6 +365,27 @@ class LGDWTCriterion:
         mask._gs_n_sel = mask.sum().to(torch.float32).reshape(1)   # travels with the (per-camera, cached) mask
         return mask
 
+    def sums_for(self, mask, device):
+        """The persistent accumulator of FusedLGDWTLoss for this camera: kept with its (cached) patch mask, word 13 = number
+        of selected patches; one shared buffer (word 13 = 0) when the patch term is off."""
+        if mask is None:
+            s = self._sums_nomask.get(device)
+            if s is None:
+                s = self._sums_nomask[device] = torch.zeros((16,), dtype=torch.float32, device=device)
+            return s
+        s = getattr(mask, "_gs_sums", None)
+        if s is None:
+            n_sel = getattr(mask, "_gs_n_sel", None)
+            if n_sel is None:
+                n_sel = mask.sum().to(torch.float32).reshape(1)
+            s = torch.zeros((16,), dtype=torch.float32, device=device)
+            s[13:14].copy_(n_sel)
+            try:
+                mask._gs_sums = s       # cached with the per-camera mask
+            except Exception:
+                pass
+        return s
+
     def fused_call(self, raw_image, gt_image, mask=None):
         """Criterion on the rasterizer's raw output (the clamp of gaussian_renderer/__init__.py:119 is applied -
         and differentiated - inside).  Returns (loss, parts) like __call__."""
@@ -361,18 +399,15 @@ class LGDWTCriterion:
         if fp.patch_enable:
             if mask is None:
                 mask = self.elf_mask(gt_image)
-            n_sel = getattr(mask, "_gs_n_sel", None)
-            if n_sel is None:
-                n_sel = mask.sum().to(torch.float32).reshape(1)
-                try:
-                    mask._gs_n_sel = n_sel       # cached with the per-camera mask
-                except Exception:
-                    pass
+            sums = self.sums_for(mask, dev)
         else:
-            mask = torch.zeros((1,), dtype=torch.uint8, device=dev)
-            n_sel = torch.zeros((1,), dtype=torch.float32, device=dev)
-        loss, out = FusedLGDWTLoss.apply(self.ops, raw_image, gt_image, mask, n_sel, self.dwt_running_mean, fp)
-        parts = {"l1": out[5], "ssim": out[6], "dwt": out[2], "dwt_scale": out[4], "patch": out[3], "base": out[1]}
+            mask = self._no_mask.get(dev)
+            if mask is None:
+                mask = self._no_mask[dev] = torch.zeros((1,), dtype=torch.uint8, device=dev)
+            sums = self.sums_for(None, dev)
+        loss, out = FusedLGDWTLoss.apply(self.ops, raw_image, gt_image, mask, sums, self.dwt_running_mean, fp)
+        parts = {"l1": out[5], "ssim": out[6], "dwt": out[2], "dwt_scale": out[4], "patch": out[3], "base": out[1],
+                 "running_mean_before": out[7:8]}
         return loss, parts
 
     def __call__(self, image, gt_image, mask=None):

@@ -86,6 +86,7 @@ class RasterBackend:
         # count from the device header; the backward only uses the value as an upper bound) and never re-runs: the
         # caller checks `last_num_rendered()` against the capacity after the stream has drained.
         self.static_capacity = None
+        self.static_step_tag = None   # capture-safe mode: device word the captured gs_forward_status copies out with the status
         # one-shot request for the next backward: a gsplat_amd.capi.GsStepState (+ the tensors it points into, kept alive
         # by the caller) - run gs_backward_step (backward + activation backward + view statistics + Adam in the same
         # per-Gaussian kernel) instead of gs_backward; the backward then returns no gradients at all
@@ -371,6 +372,8 @@ class RasterBackend:
             s = self._scratch(geom, img, binning, capacity)
             if limit is not None:
                 s.tile_depth_limit = limit.data_ptr()
+            if static and self.static_step_tag is not None:
+                s.step_tag = self.static_step_tag.data_ptr()
             return s
 
         def render(scratch):
@@ -423,7 +426,7 @@ class RasterBackend:
         pkey = (device.index, "static" if static else cur.cuda_stream)
         status = self._pinned_by_device.get(pkey)
         if status is None:
-            status = self._pinned_by_device[pkey] = torch.zeros((4,), dtype=torch.int32).pin_memory()
+            status = self._pinned_by_device[pkey] = torch.zeros((16,), dtype=torch.int32).pin_memory()
         self._pinned = status  # (last used: read by bench.py for the instance count of the last view)
 
         def geometry(limit):
@@ -489,7 +492,7 @@ class RasterBackend:
                     # a block is re-used only after eight further deferred forwards
                     ring = self._status_ring.setdefault(device.index, [[], 0])
                     if len(ring[0]) < 8:
-                        ring[0].append(torch.zeros((4,), dtype=torch.int32).pin_memory())
+                        ring[0].append(torch.zeros((16,), dtype=torch.int32).pin_memory())
                     block = ring[0][ring[1] % len(ring[0])]
                     ring[1] += 1
                     self.api.call("forward_status", C.byref(s), block.data_ptr(), stream)
@@ -556,7 +559,7 @@ class RasterBackend:
                     self.depth_limit_stats["used"] += 1
                     ring = self._status_ring.setdefault(cur.device.index if hasattr(cur, "device") else 0, [[], 0])
                     if len(ring[0]) < 8:
-                        ring[0].append(torch.zeros((4,), dtype=torch.int32).pin_memory())
+                        ring[0].append(torch.zeros((16,), dtype=torch.int32).pin_memory())
                     block = ring[0][ring[1] % len(ring[0])]
                     ring[1] += 1
                     self.api.call("forward_status", C.byref(s), block.data_ptr(), stream)

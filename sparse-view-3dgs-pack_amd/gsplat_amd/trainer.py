@@ -103,7 +103,25 @@ class FlatAdam:
             if name not in skip:
                 self.seg_steps[name] += 1
 
-    def step_range(self, lo, hi, skip=(), grads=None):
+    def grads_out_request(self):
+        """The GsStepState of the data-parallel form of gs_backward_step: raw rows in, gradients OUT into the flat gradient
+        buffer (nothing to pack before the exchange), this view's statistic increments into `stat_delta`, the validity
+        flag into the exchange buffer's tail.  Counters are not touched (exchange_and_step advances them)."""
+        from .capi import GsStepState
+        m = self.model
+        st = GsStepState()
+        p, gv = self.field_views(m.flat), m.grad_views()
+        for k, name in enumerate(self.ROWS):
+            setattr(st, name, p[name].data_ptr())
+            st.grad_out[k] = gv[name].data_ptr()
+            st.step[k] = 1
+        st.beta1, st.beta2, st.eps = self.betas[0], self.betas[1], self.eps
+        st.max_radii2D = m.max_radii2D.data_ptr()
+        st.xyz_gradient_accum, st.denom = m.stat_delta[0].data_ptr(), m.stat_delta[1].data_ptr()
+        st.fail_flag = m.fail_flag.data_ptr()
+        return st
+
+    def step_range(self, lo, hi, skip=(), grads=None, gate=None):
         """The update of elements [lo, hi) of the flat buffers (lo a multiple of 4): the data-parallel step applies
         Adam chunk by chunk as the chunks of the gradient all-reduce arrive.  The segment table is shifted by -lo so
         that the kernel's element index i stands for element lo + i (a negative `begin` keeps the phase of the
@@ -119,6 +137,11 @@ class FlatAdam:
         stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
         # grads: a tensor holding the gradients of elements [lo, hi) (default: that slice of the flat gradient buffer)
         gptr = m.flat_grad.data_ptr() + 4 * lo if grads is None else grads.data_ptr()
+        if gate is not None:  # a device float: the update is a no-op on the device when it is non-zero (gs_adam_step_gated)
+            self.api.call("adam_step_gated", m.flat.data_ptr() + 4 * lo, gptr,
+                          self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
+                          self.betas[0], self.betas[1], self.eps, self.t, gate.data_ptr(), stream)
+            return
         self.api.call("adam_step", m.flat.data_ptr() + 4 * lo, gptr,
                       self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
                       self.betas[0], self.betas[1], self.eps, self.t, stream)
@@ -295,10 +318,14 @@ class GaussianModelLite:
         self.flat = self.flat_padded[:n]
         # gradient buffer + a [2, P] tail for this step's densification-statistic increments: the data-parallel
         # exchange is then ONE all-reduce (SUM) over gradients and increments together
-        self.exchange = torch.zeros((n_pad + 2 * P,), dtype=torch.float32, device=self.device)
+        # ... and four more floats: word 0 = "some rank's view was invalid" (GsStepState.fail_flag: lists that proved too
+        # short under depth limits, or a binning overflow), summed with everything else
+        self.exchange = torch.zeros((n_pad + 2 * P + 4,), dtype=torch.float32, device=self.device)
         self.flat_grad = self.exchange[:n]
         self.grad_padded = self.exchange[:n_pad]
-        self.stat_delta = self.exchange[n_pad:].view(2, P)
+        self.stat_delta = self.exchange[n_pad:n_pad + 2 * P].view(2, P)
+        self.stat_tail = self.exchange[n_pad:]            # statistics + flag: what travels beside the gradients
+        self.fail_flag = self.exchange[n_pad + 2 * P:n_pad + 2 * P + 1]
         self.params = {}
         off = 0
         shapes = self._shapes(P)
@@ -726,7 +753,11 @@ class Trainer:
         # sharded_optimizer (default: env GS_SHARDED_ADAM=1): reduce-scatter the gradients, Adam on this rank's 1/N of
         # the rows, all-gather the parameters - instead of all-reduce + the full Adam pass on every replica
         import os
-        self.sharded_optimizer = (os.environ.get("GS_SHARDED_ADAM", "0") == "1") if sharded_optimizer is None \
+        # Default for N > 1: sharded (GS_SHARDED_ADAM=0: all-reduce).  Byte model: both forms move 2 (N-1)/N x 244 B per
+        # Gaussian over each GPU's links (an all-reduce IS a reduce-scatter + all-gather); the sharded form does it in two
+        # large collectives instead of four chunks, runs 1/N of the 28 B/element optimizer pass, and owes an all-gather of
+        # the moments only before a densification or a checkpoint.
+        self.sharded_optimizer = (os.environ.get("GS_SHARDED_ADAM", "1") == "1") if sharded_optimizer is None \
             else bool(sharded_optimizer)
         self.model, self.cameras, self.gts, self.criterion = model, cameras, gt_images, criterion
         self.Rasterizer, self.Settings, self.bg = Rasterizer, Settings, bg
@@ -808,6 +839,16 @@ class Trainer:
                 and isinstance(m.optimizer, FlatAdam) and not m.with_nir and m.flat.is_cuda
                 and hasattr(backend.api, "_backward_step") and hasattr(backend, "fused_step"))
 
+    def _fused_dp_ok(self, backend, optimizer_step):
+        """N > 1: the data-parallel form of the fused backward (GsStepState.grad_out): raw rows in, the 59 gradient floats per
+        Gaussian written straight into the exchange buffer together with this view's statistic increments and validity
+        flag - no activation kernels, no activated copies, no packing; the optimizer then runs gated by the reduced flag."""
+        m = self.model
+        return (self.FUSED_STEP and optimizer_step and self.world_size > 1 and backend is not None
+                and isinstance(m.optimizer, FlatAdam) and not m.with_nir and m.flat.is_cuda
+                and hasattr(backend.api, "_backward_step") and hasattr(backend.api, "_adam_step_gated")
+                and hasattr(backend, "fused_step"))
+
     # Depth-limited instance lists (RasterBackend.depth_limit_request) for the fused single-GPU step: None = off,
     # "deferred" = on, with the forward's verdict ("were the cut lists long enough?") collected one step later, when it
     # costs no wait.  A step whose limits failed changed nothing on the device (gs_backward_step checks the same flag),
@@ -819,9 +860,23 @@ class Trainer:
     RAW_ACTIVATIONS = __import__("os").environ.get("GS_RAW_ACTIVATIONS", "1") != "0"
 
     def sync(self):
-        """Settle the verdict of the last depth-limited step (redoing the step if its limits failed)."""
+        """Settle the verdict of the last depth-limited step (redoing the step if its limits failed), and that of the last
+        replay of a GraphedStep bound to this trainer."""
+        g = getattr(self, "_graphed", None)
+        if g is not None:
+            g.settle()
         p, self._pending = getattr(self, "_pending", None), None
-        if p is None or p["verdict"]():
+        if p is None:
+            return
+        if "flag_host" in p:
+            # data-parallel step: the verdict is the REDUCED flag - the same number on every rank, so that all ranks repeat
+            # the step (its collectives included) or none does; this rank's own verdict only updates its hints and limits
+            p["event"].synchronize()
+            if p["verdict"] is not None:
+                p["verdict"]()
+            if float(p["flag_host"][0]) == 0.0:
+                return
+        elif p["verdict"]():
             return
         opt = self.model.optimizer
         opt.t, opt.seg_steps = p["counters"][0], dict(p["counters"][1])
@@ -846,14 +901,20 @@ class Trainer:
         backend = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
         backend = getattr(backend, "backend", None)
         fused_step = self._fused_step_ok(backend, optimizer_step)
+        fused_dp = self._fused_dp_ok(backend, optimizer_step)
         # (not with a trainable exposure: its torch optimizer has stepped on the invalid image by the time the verdict
         # arrives, and a repeat would step it twice)
-        deferred = fused_step and self.depth_limit == "deferred" and getattr(self, "_coef_dev", None) is None \
+        deferred = (fused_step or fused_dp) and self.depth_limit == "deferred" and getattr(self, "_coef_dev", None) is None \
             and m.exposure is None
         if deferred:
             counters = (m.optimizer.t, dict(m.optimizer.seg_steps))
             backend.depth_limit_request = "defer"
-        if fused_step:
+        if fused_dp:
+            backend.raw_activations = self.RAW_ACTIVATIONS
+            backend.fused_step = m.optimizer.grads_out_request()
+            if not self.RAW_ACTIVATIONS:
+                raise RuntimeError("the data-parallel fused backward takes the raw parameter rows (GS_RAW_ACTIVATIONS=1)")
+        elif fused_step:
             backend.raw_activations = self.RAW_ACTIVATIONS
             backend.fused_step = m.optimizer.fused_request(skip, coef_dev=getattr(self, "_coef_dev", None))
             rows = getattr(self, "rows_override", None)  # parity tests: blend sums to use instead of stage 1
@@ -864,22 +925,51 @@ class Trainer:
         fused = getattr(self.criterion, "fused", False)
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
                      clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci,
-                     raw_activations=fused_step and self.RAW_ACTIVATIONS,
+                     raw_activations=(fused_step or fused_dp) and self.RAW_ACTIVATIONS,
                      camera_key=getattr(self, "_camera_key_override", None) or ("trainer", id(self), ci))
         mask = None if self.masks is None else self.masks[ci]
         verdict = backend.take_deferred() if deferred else None
-        if verdict is not None:
+        rm = None
+        if verdict is not None and not fused:
             rm = getattr(self.criterion, "dwt_running_mean", None)
             rm = None if rm is None else rm.clone()
         if fused:
             loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
+            # (seeded with the criterion's cached constant 1: no fill kernel for the implicit seed, no multiply by it)
+            torch.autograd.backward(loss, self.criterion.ops.unit_grad(loss.device))
         else:
             loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
-        loss.backward()
+            loss.backward()
         radii = pkg["radii"]
-        if verdict is not None:
+        if fused_dp:
+            # gradients, statistic increments and the validity flag are in the exchange buffer: reduce, then the gated
+            # optimizer; every rank learns the reduced flag one step later (sync) and repeats the step if it is set
+            if backend.fused_step is not None:
+                backend.fused_step = None
+                raise RuntimeError("fused data-parallel step armed but the rasterizer backward did not run")
+            with torch.no_grad():
+                self.exchange_and_step(optimizer_step, skip, gate=m.fail_flag)
+            if deferred:
+                host = self._flag_blocks[self._flag_i % len(self._flag_blocks)] if getattr(self, "_flag_blocks", None) else None
+                if host is None:
+                    self._flag_blocks = [torch.zeros((1,), dtype=torch.float32).pin_memory() for _ in range(4)]
+                    self._flag_i = 0
+                    host = self._flag_blocks[0]
+                self._flag_i += 1
+                host.copy_(m.fail_flag, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(m.flat.device))
+                if fused:
+                    rm = parts.get("running_mean_before")
+                self._pending = dict(verdict=verdict, flag_host=host, event=ev, ci=ci, skip=skip, counters=counters,
+                                     running_mean=rm, loss=loss.detach())
+        elif verdict is not None:
+            if fused:  # (the criterion's combine kernel leaves the running mean it started from in its output: no clone)
+                rm = parts.get("running_mean_before")
             self._pending = dict(verdict=verdict, ci=ci, skip=skip, counters=counters, running_mean=rm, loss=loss.detach())
-        if fused_step:
+        if fused_dp:
+            pass
+        elif fused_step:
             # gs_backward_step has already applied the activation backward, the view statistics and Adam
             if backend.fused_step is not None:
                 backend.fused_step = None
@@ -903,7 +993,7 @@ class Trainer:
 
     DP_CHUNKS = 4
 
-    def exchange_and_step(self, optimizer_step, skip=()):
+    def exchange_and_step(self, optimizer_step, skip=(), gate=None):
         """The one exchange step of the data-parallel path and the optimizer step.  The exchange buffer = the 59-
         floats-per-Gaussian gradients (236 B x P) followed by this step's increments of the densification statistics
         (8 B x P) is summed over ranks in DP_CHUNKS consecutive all-reduces (RCCL over xGMI; gloo in the CPU tests)
@@ -919,24 +1009,41 @@ class Trainer:
                 opt.step(*([skip] if skip else []))
             return
         if self.sharded_optimizer and chunked:
-            return self._exchange_and_step_sharded(optimizer_step, skip)
+            return self._exchange_and_step_sharded(optimizer_step, skip, gate)
         n_grad = m.flat_grad.numel()
         nch = self.DP_CHUNKS if chunked else 1
-        bounds = [(i * n_grad // nch) // 4 * 4 for i in range(nch)] + [m.exchange.numel()]
+        n_stat_end = m.exchange.numel() - 4     # (the last four floats: validity flag + padding)
+        wflag = None
+        if gate is not None:  # the flag first, on its own: every chunk's gated update needs it
+            wflag = dist.all_reduce(m.exchange[n_stat_end:], op=dist.ReduceOp.SUM, async_op=True)
+        bounds = [(i * n_grad // nch) // 4 * 4 for i in range(nch)] + [n_stat_end]
         works = [dist.all_reduce(m.exchange[bounds[i]:bounds[i + 1]], op=dist.ReduceOp.SUM, async_op=True)
                  for i in range(nch)]
+        if wflag is not None:
+            wflag.wait()
         wmax = dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)
         if optimizer_step and chunked:
             opt.begin_step(skip)
         for i, w in enumerate(works):
             w.wait()
             if optimizer_step and chunked:
-                opt.step_range(bounds[i], min(bounds[i + 1], n_grad), skip)
+                opt.step_range(bounds[i], min(bounds[i + 1], n_grad), skip, gate=gate)
         if optimizer_step and not chunked:
             opt.step()
         wmax.wait()
-        m.xyz_gradient_accum += m.stat_delta[0].unsqueeze(1)
-        m.denom += m.stat_delta[1].unsqueeze(1)
+        self._add_statistics(gate)
+
+    def _add_statistics(self, gate):
+        """running totals += the summed increments of all ranks' views - unless some rank's view was invalid (gate != 0):
+        the step is about to be repeated, nothing of it may stay."""
+        m = self.model
+        if gate is None:
+            m.xyz_gradient_accum += m.stat_delta[0].unsqueeze(1)
+            m.denom += m.stat_delta[1].unsqueeze(1)
+        else:
+            ok = (gate == 0).to(torch.float32)
+            m.xyz_gradient_accum += (m.stat_delta[0] * ok).unsqueeze(1)
+            m.denom += (m.stat_delta[1] * ok).unsqueeze(1)
 
     def gather_optimizer_state(self):
         """Sharded optimizer only: every rank holds current Adam moments for ITS shard; before anything that needs them
@@ -948,7 +1055,7 @@ class Trainer:
         for buf in (opt.exp_avg_padded, opt.exp_avg_sq_padded):
             dist.all_gather_into_tensor(buf, buf[self.rank * S:(self.rank + 1) * S])
 
-    def _exchange_and_step_sharded(self, optimizer_step, skip=()):
+    def _exchange_and_step_sharded(self, optimizer_step, skip=(), gate=None):
         """The sharded form of exchange_and_step: rank r owns elements [r S, (r+1) S) of the padded flat
         buffers.  reduce-scatter (SUM) leaves the summed gradients of its shard on each rank, Adam runs on that shard
         only (1/N of the 28 B/element pass), all-gather returns the updated parameters to every replica; the view
@@ -964,18 +1071,19 @@ class Trainer:
         lo, hi = rank * S, min((rank + 1) * S, n)
         gshard = m.grad_padded[rank * S:(rank + 1) * S]
         wg = dist.reduce_scatter_tensor(gshard, m.grad_padded, op=dist.ReduceOp.SUM, async_op=True)
-        ws = dist.all_reduce(m.stat_delta, op=dist.ReduceOp.SUM, async_op=True)
+        ws = dist.all_reduce(m.stat_tail, op=dist.ReduceOp.SUM, async_op=True)   # statistic increments + validity flag
         wmax = dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)
         wg.wait()
+        if gate is not None:
+            ws.wait()  # the gate is the reduced flag
         if optimizer_step:
             opt.begin_step(skip)
             if hi > lo:
-                opt.step_range(lo, hi, skip, grads=gshard)
+                opt.step_range(lo, hi, skip, grads=gshard, gate=gate)
             dist.all_gather_into_tensor(m.flat_padded, m.flat_padded[rank * S:(rank + 1) * S])
         ws.wait()
         wmax.wait()
-        m.xyz_gradient_accum += m.stat_delta[0].unsqueeze(1)
-        m.denom += m.stat_delta[1].unsqueeze(1)
+        self._add_statistics(gate)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -1095,6 +1203,7 @@ class GraphedStep:
         """capacity: binning capacity (instances) to capture with; default = capacity_margin x the largest view the
         backend has seen recently."""
         self.tr = trainer
+        trainer._graphed = self   # Trainer.sync() settles the last replay too
         self.fixed_capacity = capacity
         self.capacity_margin = capacity_margin
         self.warmup = warmup
@@ -1103,6 +1212,8 @@ class GraphedStep:
         self.cam_orders = {}
         self.cam_limits = {}
         self.replays = self.eager_steps = self.captures = 0
+        self._replay_pending = None
+        self.s_rm_before = None
 
     # -- what the capture froze
     def _key(self, cam):
@@ -1128,6 +1239,7 @@ class GraphedStep:
             mk = tr.masks[ci]
             self.s_mask.copy_(mk, non_blocking=True)
             self.s_mask._gs_n_sel.copy_(mk._gs_n_sel, non_blocking=True)
+            self.s_mask._gs_sums[13:14].copy_(mk._gs_n_sel, non_blocking=True)  # (words 0..12 stay zero between steps)
         # the forward's per-camera hints (RasterBackend._camera_cache keys them by the view matrix's address, which is the
         # static tensor's here): bring in what this camera's last visit measured - tile order and per-tile depth limits
         cc = self._cam_cache()
@@ -1178,6 +1290,8 @@ class GraphedStep:
         if tr.masks is not None and tr.masks[ci] is not None:
             self.s_mask = tr.masks[ci].clone()
             self.s_mask._gs_n_sel = tr.masks[ci]._gs_n_sel.clone()
+            self.s_mask._gs_sums = torch.zeros((16,), dtype=torch.float32, device=dev)
+            self.s_mask._gs_sums[13:14].copy_(self.s_mask._gs_n_sel)
         self.s_cam = cam._replace(world_view_transform=self.s_view, full_proj_transform=self.s_proj,
                                   camera_center=self.s_center)
         self.coef = torch.zeros((11,), dtype=torch.float32, device=dev)
@@ -1185,11 +1299,18 @@ class GraphedStep:
         # binning capacity: the largest view seen so far with head-room
         self.capacity = int(self.fixed_capacity) if self.fixed_capacity is not None else \
             int(max(be._capacity_hint, 4096) * self.capacity_margin)
-        be._pinned_by_device.setdefault((dev.index, "static"), torch.zeros((4,), dtype=torch.int32).pin_memory())
+        be._pinned_by_device.setdefault((dev.index, "static"), torch.zeros((16,), dtype=torch.int32).pin_memory())
+        # the replay's identity: uploaded before every replay, copied out with the status words by the captured
+        # gs_forward_status (GsScratch.step_tag) - the host polls the pinned block for it instead of draining the stream
+        self.s_tag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.tag_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self._tag = 0
+        self._tag_event = None
         saved = (tr.cameras, tr.gts, tr.masks)
 
         def one_step():
             be.static_capacity = self.capacity
+            be.static_step_tag = self.s_tag
             be.depth_limit_request = "graph" if tr.depth_limit else None
             tr.cameras, tr.gts, tr.masks = [self.s_cam], [self.s_gt], (None if self.s_mask is None else [self.s_mask])
             tr._coef_dev = self.coef
@@ -1198,6 +1319,7 @@ class GraphedStep:
                 return tr._step_camera(0, True, ())
             finally:
                 be.static_capacity = None
+                be.static_step_tag = None
                 tr.cameras, tr.gts, tr.masks = saved
                 tr._coef_dev = None
                 tr._camera_key_override = None
@@ -1228,7 +1350,9 @@ class GraphedStep:
             self._coef_for_next()
             with torch.cuda.graph(self.graph):
                 self.s_loss = one_step()
+            self.s_rm_before = (tr.last.get("parts") or {}).get("running_mean_before")  # (a view of the captured output)
             # the capture itself launched nothing: replay once so that this call ends with a step
+            self._upload_tag()
             self.graph.replay()
             torch.cuda.synchronize(dev)
             fits = self._view_ok(be)
@@ -1266,9 +1390,53 @@ class GraphedStep:
         self._coef_event = torch.cuda.Event()
         self._coef_event.record(torch.cuda.current_stream(self.coef.device))
 
+    def _upload_tag(self):
+        self._tag = (self._tag + 1) & 0x7FFFFFFF
+        if self._tag_event is not None:
+            self._tag_event.synchronize()  # the previous upload has read the pinned word
+        self.tag_host[0] = self._tag
+        self.s_tag.copy_(self.tag_host, non_blocking=True)
+        self._tag_event = torch.cuda.Event()
+        self._tag_event.record(torch.cuda.current_stream(self.s_tag.device))
+
+    def settle(self):
+        """The verdict of the last replay (did the view fit the captured capacity, did its depth limits hold?), read from
+        the status words the replay's forward copied out.  The host does not drain the stream for it: it polls the pinned
+        block for the replay's tag, which arrives when the FORWARD of that replay has finished - the rest of the step is
+        still queued behind it, so the GPU never waits for the host.  A failed replay changed nothing on the device
+        (gs_backward_step is a no-op on either flag): counters and the criterion's running mean are put back, the step is
+        taken eagerly and the graph is captured again next time."""
+        p, self._replay_pending = getattr(self, "_replay_pending", None), None
+        if p is None:
+            return
+        tr, be = self.tr, self._backend()
+        st = be._pinned_by_device[(self.s_tag.device.index, "static")]
+        spins = 0
+        while int(st[8]) != p["tag"]:
+            spins += 1
+            if spins > 2000:  # (not there after ~2 ms of polling: wait for the stream the ordinary way)
+                torch.cuda.current_stream(self.s_tag.device).synchronize()
+                break
+        num_rendered, overflow, trunc_failed = int(st[0]), int(st[1]), int(st[2])
+        if num_rendered <= self.capacity and not overflow and not trunc_failed:
+            return
+        ci = p["ci"]
+        self.cam_limits.pop(ci, None)
+        opt = tr.model.optimizer
+        opt.t -= 1
+        for name in opt.seg_steps:
+            opt.seg_steps[name] -= 1
+        crit = tr.criterion
+        if self.s_rm_before is not None:  # the criterion's running mean saw the loss of an un-rendered image
+            crit.dwt_running_mean.copy_(self.s_rm_before)
+        self.graph, self.key = None, None
+        self.eager_steps += 1
+        self.s_loss = tr._step_camera(ci, True, ()).clone()
+
     def step(self, k):
         tr = self.tr
         tr.sync()
+        self.settle()
         ci = tr.camera_index(k)
         cam = tr.cameras[ci]
         be = self._backend()
@@ -1281,27 +1449,15 @@ class GraphedStep:
             return self._capture(ci)
         self._load(ci)
         self._coef_for_next()
-        crit = tr.criterion
-        if self.s_rm_backup is not None:
-            self.s_rm_backup.copy_(crit.dwt_running_mean)
+        self._upload_tag()
         self.graph.replay()
         self._save_order(ci)
         tr.model.optimizer.begin_step(())
         self.replays += 1
-        # one host wait per step (the eager path has one too, inside the forward): did the view fit the capacity?
-        torch.cuda.current_stream(tr.model.flat.device).synchronize()
-        if not self._view_ok(be):
-            # the captured step was a no-op on the device (gs_backward_step skips on overflow and on depth limits that
-            # proved too tight): undo the counter, run the step eagerly (which also raises the capacity hint), forget this
-            # camera's limits and capture again next time
-            self.cam_limits.pop(ci, None)
-            opt = tr.model.optimizer
-            opt.t -= 1
-            for name in opt.seg_steps:
-                opt.seg_steps[name] -= 1
-            if self.s_rm_backup is not None:  # the criterion's running mean saw a loss of an un-rendered image
-                crit.dwt_running_mean.copy_(self.s_rm_backup)
-            self.graph, self.key = None, None
-            self.eager_steps += 1
-            return tr._step_camera(ci, True, ())
+        self._replay_pending = dict(tag=self._tag, ci=ci)
         return self.s_loss
+
+    def sync(self):
+        """Settle everything that is pending (an eager deferred verdict, the last replay's): call before reading the model."""
+        self.tr.sync()
+        self.settle()

@@ -324,9 +324,12 @@ def test_graphed_step_with_stale_limits_falls_back(hip):
     lb = [float(gs.step(k)) for k in range(9)]          # capture on camera 0, then cameras 1 2 3 0 1 2 3 0
     assert gs.eager_steps == 0 and sorted(gs.cam_limits) == [0, 1, 2, 3]
     gs.cam_limits[1].fill_(1e-3)                         # camera 1's limits now cut everything
-    lb.append(float(gs.step(9)))                         # -> flagged, undone, stepped eagerly
+    gs.step(9)                                           # -> flagged; the host learns it when it settles the replay
+    gs.sync()                                            #    (before the next step, or here): undone, stepped eagerly
+    lb.append(float(gs.s_loss))
     assert gs.eager_steps == 1 and 1 not in gs.cam_limits
     lb += [float(gs.step(k)) for k in range(10, 14)]     # re-captured; camera 1 re-learns its limits
+    gs.sync()
     assert 1 in gs.cam_limits
     cams = [0, 0, 0, 0] + [k % 4 for k in range(1, 10)] + [2, 2, 2, 2] + [3, 0, 1]
     hip.depth_limit_on = False

@@ -1,0 +1,134 @@
+"""The data-parallel form of the fused step on the GPU (two ranks sharing the one device of the test box, gloo for the
+exchange: the control flow and every kernel are those of the RCCL run, only the transport differs):
+
+  forward on RAW rows with depth-limited, region-binned lists (deferred verdict) -> fused criterion ->
+  gs_backward_step with GsStepState.grad_out: the 59 gradient floats per Gaussian, this view's statistic increments and
+  the validity flag written straight into the exchange buffer -> all-reduce (or reduce-scatter / all-gather with the
+  sharded optimizer) -> gs_adam_step_gated.
+
+Checked: (1) it is the un-fused data-parallel step (separate activation / statistics kernels, plain Adam, full lists):
+parameters, statistics and replicas; (2) a rank whose camera's depth limits are sabotaged makes EVERY rank repeat the step
+(the flag travels with the gradients) and the run is still the un-limited run, replicas bit-identical.
+"""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make(rank, world, fused):
+    import diff_gaussian_rasterization as dgr
+    import lgdwt_loss
+    from gsplat_amd import hip_backend, synthetic
+    from gsplat_amd.trainer import GaussianModelLite, Trainer, camera_to, render
+    from simple_knn._C import distCUDA2
+    dev = torch.device("cuda", 0)
+    hip = hip_backend()
+    P, W, H = 30000, 480, 320
+    sc = synthetic.trained_like(P, seed=3, sh_degree=3, knn=lambda x: distCUDA2(x.to(dev)).cpu())
+    cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(W, H)[:4]]
+    g = torch.Generator().manual_seed(5)
+    target = dict(sc, shs=sc["shs"] + 0.02 * torch.randn(sc["shs"].shape, generator=g))
+    bg = torch.zeros(3, device=dev)
+    tm = GaussianModelLite(target, dev, api=hip.api)
+    with torch.no_grad():
+        gts = [render(c, tm, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg)["render"].clone() for c in cams]
+    model = GaussianModelLite(sc, dev, api=hip.api)
+    crit = lgdwt_loss.criterion(dwt_enable=True, patch_dwt_enable=True)
+    tr = Trainer(model, cams, gts, crit, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg, rank, world,
+                 optimizer_step=True)
+    tr.FUSED_STEP = fused
+    return tr, hip
+
+
+def _worker(rank, world, port, outdir, mode, sharded):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr, hip = _make(rank, world, fused=(mode != "plain"))
+    tr.sharded_optimizer = sharded
+    hip.tile_cull = True
+    info = {}
+    if mode == "plain":
+        for k in range(8):
+            tr.step(k)
+    else:
+        tr.depth_limit = "deferred"
+        assert tr._fused_dp_ok(hip, True)
+        used0, failed0 = hip.depth_limit_stats["used"], hip.depth_limit_stats["failed"]
+        for k in range(4):                      # every rank has seen its two cameras twice
+            tr.step(k)
+        tr.sync()
+        if mode == "sabotage" and rank == 1:
+            # rank 1's next camera (index 1): its limits now cut everything
+            hip.camera_entry(480, 320, camera_key=("trainer", id(tr), tr.camera_index(4)))["limit"].fill_(1e-3)
+        before = tr.model.flat.detach().clone()
+        t_before = tr.model.optimizer.t
+        tr.step(4)
+        torch.cuda.synchronize()
+        if mode == "sabotage":
+            # nobody stepped: the gate was set on every rank although only rank 1's view was invalid
+            info["unchanged_after_bad_step"] = bool(torch.equal(before, tr.model.flat.detach()))
+            info["t_after_bad_step"] = tr.model.optimizer.t - t_before
+        for k in range(5, 8):
+            tr.step(k)
+        tr.sync()
+        info["used"] = hip.depth_limit_stats["used"] - used0
+        info["failed"] = hip.depth_limit_stats["failed"] - failed0
+    m = tr.model
+    tr.gather_optimizer_state()
+    torch.cuda.synchronize()
+    torch.save(dict(flat=m.flat.detach().cpu(), accum=m.xyz_gradient_accum.cpu(), denom=m.denom.cpu(),
+                    maxr=m.max_radii2D.cpu(), m1=m.optimizer.exp_avg.cpu(), t=m.optimizer.t, info=info),
+               os.path.join(outdir, "%s_rank%d.pt" % (mode, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(mode, sharded):
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), d, mode, sharded), nprocs=world, join=True)
+        return [torch.load(os.path.join(d, "%s_rank%d.pt" % (mode, r))) for r in range(world)]
+
+
+def _same_run(a, b):
+    d = (a["flat"] - b["flat"]).double()
+    assert float(d.pow(2).mean().sqrt()) <= 1e-4 * float(a["flat"].double().pow(2).mean().sqrt())
+    assert torch.equal(a["denom"], b["denom"]) and torch.equal(a["maxr"], b["maxr"])
+    assert torch.allclose(a["accum"], b["accum"], rtol=2e-3, atol=1e-7)
+    assert a["t"] == b["t"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("sharded", [False, True], ids=["allreduce", "sharded"])
+def test_fused_data_parallel_step_is_the_plain_one_and_a_bad_view_repeats_on_every_rank(sharded):
+    plain = _run("plain", sharded)
+    fused = _run("fused", sharded)
+    bad = _run("sabotage", sharded)
+    for run in (plain, fused, bad):
+        for k in ("flat", "accum", "denom", "maxr", "m1"):
+            assert torch.equal(run[0][k], run[1][k]), "replicas differ in " + k
+        assert run[0]["t"] == run[1]["t"] == 8
+    _same_run(plain[0], fused[0])
+    _same_run(plain[0], bad[0])
+    # limits were used from each camera's second visit on; nothing failed in the clean run
+    assert fused[0]["info"]["used"] >= 4 and fused[0]["info"]["failed"] == 0 and fused[1]["info"]["failed"] == 0
+    # the sabotaged view: flagged on rank 1, and NEITHER rank stepped before the host saw the flag
+    assert bad[1]["info"]["failed"] >= 1
+    for r in (0, 1):
+        assert bad[r]["info"]["unchanged_after_bad_step"], "rank %d stepped on an invalid view" % r
+        assert bad[r]["info"]["t_after_bad_step"] == 1   # (counter advanced optimistically; put back and redone by sync)

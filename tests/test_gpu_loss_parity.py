@@ -182,9 +182,13 @@ def test_ssim_partials_equal_the_atomic_sum_and_the_oracle(hip, oracle, H, W):
         s_part[1] = 0.0
         rm1, rm2 = torch.ones(1, device=dev), torch.ones(1, device=dev)
         o1, o2 = torch.empty(24, device=dev), torch.empty(24, device=dev)
+        atomic_sum = float(s_atomic[1])
+        assert fp.c.reset_sums == 1   # the fused criterion's form: the call re-zeroes the accumulators it has read
         api.call("lgdwt_combine", s_atomic.data_ptr(), rm1.data_ptr(), C.byref(fp.c), o1.data_ptr(), st)
         api.call("lgdwt_combine_p", s_part.data_ptr(), part.data_ptr(), n, rm2.data_ptr(), C.byref(fp.c), o2.data_ptr(), st)
-        res[name] = (float(part.double().sum()), float(s_atomic[1]), o1.cpu(), o2.cpu())
+        assert float(s_atomic[:13].abs().max()) == 0.0 and float(s_part[:13].abs().max()) == 0.0
+        assert float(o1[7]) == 1.0 and float(o2[7]) == 1.0   # the running mean the call started from
+        res[name] = (float(part.double().sum()), atomic_sum, o1.cpu(), o2.cpu())
     for name in res:
         ps, at, o1, o2 = res[name]
         assert abs(ps - at) <= 1e-5 * abs(at), (name, ps, at)
