@@ -8,8 +8,10 @@
 A step = one camera per GPU: activations -> GaussianRasterizer forward -> clamp -> LGDWT loss
 (0.8 L1 + 0.2 (1-SSIM) + running-mean-scaled global 2-level DWT + 0.1 patch DWT) -> backward to the
 six parameter tensors -> densification statistics -> Adam (N = 1: all of the last three inside the
-backward's per-Gaussian kernel, gs_backward_step; N > 1: one RCCL all-reduce of the 59-float/Gaussian
-gradient buffer + the statistics, then the fused Adam kernel).  The timed step therefore INCLUDES the
+backward's per-Gaussian kernel, gs_backward_step; N > 1: the same kernel writes the 59 gradient floats per
+Gaussian, the statistic increments and a validity flag into ONE exchange buffer -> RCCL reduce-scatter ->
+gated Adam on this rank's 1/N of the rows -> all-gather of the parameters; GS_SHARDED_ADAM=0: chunked
+all-reduce with the optimizer behind the chunks).  The timed step therefore INCLUDES the
 optimizer; the metric's "(fwd+bwd)" is BASELINE.json's wording.  Synthetic "trained-like" Gaussians, NeRF-synthetic-
 like orbit cameras, inputs resident in HBM before the timed region.  Cameras are sharded over ranks
 and per-GPU work is fixed, so scaling is "weak".
@@ -310,7 +312,7 @@ def main():
     # depth-limited instance lists (csrc/gs_tilecull.h; exact, verified by the forward, verdict collected one step later -
     # gsplat_amd.trainer.Trainer.depth_limit): GS_BENCH_DEPTH_LIMIT=0 switches them off
     # (default: on from 100 k Gaussians - on the 10 k scene of c1 there is nothing to cut and the two extra launches cost 3 %)
-    depth_limit = world == 1 and args.config not in NIR_CONFIGS and \
+    depth_limit = args.config not in NIR_CONFIGS and \
         os.environ.get("GS_BENCH_DEPTH_LIMIT", "1" if P >= 100_000 else "0") != "0"
     if depth_limit:
         tr.depth_limit = "deferred"
@@ -400,6 +402,8 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    if world > 1:
+        tr.exchange_events = []   # (Trainer.exchange_and_step brackets the exchange + optimizer with HIP events)
     barrier()
     t0 = time.perf_counter()
     sampled = graphed is None and not args.no_stage_timers
@@ -511,8 +515,26 @@ def main():
             be2._capacity_hint, be2._capacity_hint_limited = saved_hints
             torch.cuda.empty_cache()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dp_info = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # per rank: the step's wall time, of which exchange (collectives + optimizer, as the compute stream sees them)
+        ev = getattr(tr, "exchange_events", None) or []
+        tr.exchange_events = None
+        ex_ms = sum(a.elapsed_time(b) for a, b in ev[-args.steps:]) / max(1, len(ev[-args.steps:]))
+        mine = torch.tensor([dt / args.steps * 1e3, ex_ms], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        nbytes = tr.model.exchange.numel() * 4
+        worst = max(float(x[1]) for x in allr)
+        dp_info = {"per_rank_step_ms": [float(x[0]) for x in allr],
+                   "per_rank_exchange_ms": [float(x[1]) for x in allr],
+                   "per_rank_compute_ms": [float(x[0]) - float(x[1]) for x in allr],
+                   "exchange_bytes_per_gpu": nbytes,
+                   # ring / RS+AG traffic per GPU = 2 (N-1)/N x bytes, over the time the slowest rank spent in the exchange
+                   "bus_GBps": (2.0 * (world - 1) / world * nbytes / 1e9) / (worst * 1e-3) if worst > 0 else None,
+                   "what": "exchange = reduce-scatter + Adam on 1/N + all-gather (sharded) or chunked all-reduce with Adam "
+                           "behind the chunks, bracketed by HIP events on the compute stream; compute = step - exchange"}
     dt = float(tmax[0])
 
     if rank == 0:
@@ -581,8 +603,12 @@ def main():
                        "reference_lists_ms_per_step": None if ref_lists is None else ref_lists["ms_per_step"],
                        "num_rendered_reference_lists": None if ref_lists is None else ref_lists["num_rendered_last_view"],
                        "num_rendered_last_view": R_last, "loss": "L1+SSIM" + ("+DWT2" if dwt else "") +
-                       ("+patchDWT" if patch else ""), "optimizer": "Adam eps 1e-15, " + ("inside the backward's per-Gaussian kernel (gs_backward_step)"
-                                                       if "preprocess_bwd_step" in stages else "fused HIP kernel over the flat buffer"),
+                       ("+patchDWT" if patch else ""),
+                       "optimizer": "Adam eps 1e-15, " + (
+                           "fused HIP kernel over this rank's shard of the flat buffer, gated by the reduced validity flag "
+                           "(the backward kernel writes gradients, statistic increments and flag into the exchange buffer)"
+                           if world > 1 else ("inside the backward's per-Gaussian kernel (gs_backward_step)"
+                                              if "preprocess_bwd_step" in stages else "fused HIP kernel over the flat buffer")),
                        "parallelism": ("camera-sharded dp%d, reduce-scatter of 59 f32/Gaussian + Adam on 1/N of the rows + "
                                        "all-gather of the parameters (GS_SHARDED_ADAM=1)" % world)
                        if getattr(tr, "sharded_optimizer", False) and world > 1 else
@@ -590,6 +616,7 @@ def main():
             "roofline": roofline,
             "reference_lists": ref_lists,
             "other_scenes": other or None,
+            "data_parallel": dp_info,
             "step_times_ms": {"timed (config.lists)": dt / args.steps * 1e3,
                               "reference lists": None if ref_lists is None else ref_lists["ms_per_step"],
                               "init-like, sh_degree 0": other.get("init_like", {}).get("ms_per_step"),

@@ -1008,6 +1008,22 @@ class Trainer:
             if optimizer_step:
                 opt.step(*([skip] if skip else []))
             return
+        timed = getattr(self, "exchange_events", None) is not None and m.flat.is_cuda
+        if timed:  # bench.py: how long the compute stream sees the exchange + optimizer take
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(m.flat.device))
+        try:
+            return self._exchange_and_step(optimizer_step, skip, gate)
+        finally:
+            if timed:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(torch.cuda.current_stream(m.flat.device))
+                self.exchange_events.append((e0, e1))
+
+    def _exchange_and_step(self, optimizer_step, skip=(), gate=None):
+        m = self.model
+        opt = m.optimizer
+        chunked = isinstance(opt, FlatAdam)
         if self.sharded_optimizer and chunked:
             return self._exchange_and_step_sharded(optimizer_step, skip, gate)
         n_grad = m.flat_grad.numel()
