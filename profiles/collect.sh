@@ -3,9 +3,9 @@
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC has 4 slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 # usage: bash profiles/collect.sh <tag>      -> gpurun_out/prof_<tag>/{trace,fetch,write}
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 # kernel-level numbers: eager launches (a hipGraph replay shows the same kernels), no reference-lists leg
-export GS_BENCH_GRAPH=0 GS_BENCH_REFERENCE_LISTS=0
+export GS_BENCH_GRAPH=0 GS_BENCH_REFERENCE_LISTS=0 GS_BENCH_OTHER_SCENES=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

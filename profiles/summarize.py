@@ -20,7 +20,8 @@ OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs
         "bin_prepare_kernel", "render_fwd_wave_kernel", "render_bwd_wave_kernel", "render_fwd_kernel", "render_bwd_kernel", "adam_kernel", "scan_small_kernel", "preprocess_bwd_kernel", "l1_fwd_kernel",
         "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
         "patch_dwt_kernel", "lgdwt_combine_kernel", "act_fwd_kernel", "act_bwd_kernel", "densify_stats_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel", "preprocess_bwd_step_kernel",
-        "tile_order_kernel", "zero_rows_kernel", "stop_depth_bounds_kernel")
+        "tile_order_kernel", "zero_rows_kernel", "stop_depth_bounds_kernel", "region_bin_kernel", "region_prepare_kernel",
+        "status_tag_kernel", "rs_small_sort_kernel")
 
 
 def short(name):
@@ -83,10 +84,13 @@ with open(os.path.join(here, "%s_pmc_traffic.csv" % tag), "w") as f:
         traffic[k] = rd + wr
 stage_of = {"render_bwd": "render_bwd_wave_kernel", "render_fwd": "render_fwd_wave_kernel", "preprocess_fwd": "preprocess_fwd_kernel",
             "preprocess_bwd": "preprocess_bwd_kernel", "preprocess_bwd_step": "preprocess_bwd_step_kernel",
-            "duplicate": "duplicate_kernel", "tile_ranges": "tile_ranges_kernel"}
+            "duplicate": "duplicate_kernel", "tile_ranges": "tile_ranges_kernel", "region_bin": "region_bin_kernel",
+            "ssim_fwd": "ssim_fwd_kernel", "ssim_bwd": "ssim_bwd_kernel"}
 out = {st: traffic[k] for st, k in stage_of.items() if k in traffic}
 out["tag"] = tag
-if "rs_scatter_kernel" in traffic:  # the sort stage = all passes of hist + scatter (launch counts per step: 6 each)
+if "region_bin_kernel" in traffic:   # region binning: the whole binning stage is this one kernel (bench.py stage "sort")
+    out["sort"] = traffic["region_bin_kernel"]
+elif "rs_scatter_kernel" in traffic:  # LSD path: all passes of hist + scatter (launch counts per step: 6 each)
     out["sort"] = 6 * (traffic.get("rs_scatter_kernel", 0) + traffic.get("rs_hist_kernel", 0))
 json.dump(out, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(here, "%s_step_timeline.txt" % tag)).read())

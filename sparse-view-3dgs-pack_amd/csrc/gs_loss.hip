@@ -516,7 +516,41 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
   float (*hor)[SH][HS] = reinterpret_cast<float (*)[SH][HS]>(lds_buf);
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
-  {  // all global loads of the halo tile are in flight before the first LDS store (a rolled loop waits per round)
+  // Halo tile loads.  Rows are 42 floats starting at column bx - 5: with W a multiple of 4 (and so every plane and row
+  // 16-byte aligned) the aligned span [bx - 8, bx + 40) is fetched as 12 float4 per row - 2 vector loads per thread and
+  // plane instead of 7 scalar ones (a float4 lies entirely inside or entirely outside the image); else element-wise.
+  const bool vec = (W & 3) == 0 && ((((uintptr_t)img1) | ((uintptr_t)img2)) & 15) == 0;
+  if (vec) {
+    constexpr int VPR = 12, NV = SH * VPR, NVI = (NV + GS_BLOCK - 1) / GS_BLOCK;
+    float4 a[NVI], b[NVI];
+#pragma unroll
+    for (int it = 0; it < NVI; it++) {
+      const int v = threadIdx.x + it * GS_BLOCK;
+      const int r = v / VPR, q = v % VPR;
+      const int y = by + r - 5, x4 = bx - 8 + 4 * q;
+      a[it] = b[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < NV && y >= 0 && y < H && x4 >= 0 && x4 + 3 < W) {
+        a[it] = *reinterpret_cast<const float4*>(img1 + plane + (size_t)y * W + x4);
+        b[it] = *reinterpret_cast<const float4*>(img2 + plane + (size_t)y * W + x4);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NVI; it++) {
+      const int v = threadIdx.x + it * GS_BLOCK;
+      if (v < NV) {
+        const int r = v / VPR, c0 = 4 * (v % VPR) - 3;  // tile column of the vector's first element
+        const float av[4] = {a[it].x, a[it].y, a[it].z, a[it].w}, bv[4] = {b[it].x, b[it].y, b[it].z, b[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int c = c0 + e;
+          if (c >= 0 && c < SH) {
+            tile[0][r][c] = av[e];
+            tile[1][r][c] = bv[e];
+          }
+        }
+      }
+    }
+  } else {  // all global loads of the halo tile are in flight before the first LDS store (a rolled loop waits per round)
     constexpr int NIT = (SH * SH + GS_BLOCK - 1) / GS_BLOCK;
     float a[NIT], b[NIT];
 #pragma unroll
@@ -606,7 +640,43 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
   const float gu = coef_dev ? coef_dev[0] : 0.f;  // uniform dL/dssim_map (mean reduction upstream)
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
-  {
+  const bool vec = (W & 3) == 0 && !dL_dmap &&
+                   ((((uintptr_t)dm_dmu1) | ((uintptr_t)dm_dsigma1_sq) | ((uintptr_t)dm_dsigma12)) & 15) == 0;
+  if (vec) {  // (see ssim_fwd_kernel; uniform upstream gradient only - the train step's case)
+    constexpr int VPR = 12, NV = SH * VPR, NVI = (NV + GS_BLOCK - 1) / GS_BLOCK;
+    float4 a[NVI], b[NVI], d[NVI];
+#pragma unroll
+    for (int it = 0; it < NVI; it++) {
+      const int v = threadIdx.x + it * GS_BLOCK;
+      const int r = v / VPR, q = v % VPR;
+      const int y = by + r - 5, x4 = bx - 8 + 4 * q;
+      a[it] = b[it] = d[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < NV && y >= 0 && y < H && x4 >= 0 && x4 + 3 < W) {
+        const size_t o = plane + (size_t)y * W + x4;
+        a[it] = *reinterpret_cast<const float4*>(dm_dmu1 + o);
+        b[it] = *reinterpret_cast<const float4*>(dm_dsigma1_sq + o);
+        d[it] = *reinterpret_cast<const float4*>(dm_dsigma12 + o);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NVI; it++) {
+      const int v = threadIdx.x + it * GS_BLOCK;
+      if (v < NV) {
+        const int r = v / VPR, c0 = 4 * (v % VPR) - 3;
+        const float av[4] = {a[it].x, a[it].y, a[it].z, a[it].w}, bv[4] = {b[it].x, b[it].y, b[it].z, b[it].w};
+        const float dv[4] = {d[it].x, d[it].y, d[it].z, d[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int c = c0 + e;
+          if (c >= 0 && c < SH) {
+            tile[0][r][c] = av[e] * gu;
+            tile[1][r][c] = bv[e] * gu;
+            tile[2][r][c] = dv[e] * gu;
+          }
+        }
+      }
+    }
+  } else {
     constexpr int NIT = (SH * SH + GS_BLOCK - 1) / GS_BLOCK;
     float g[NIT], a[NIT], b[NIT], d[NIT];
 #pragma unroll
