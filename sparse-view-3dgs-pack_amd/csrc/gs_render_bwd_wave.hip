@@ -45,6 +45,14 @@ __device__ __forceinline__ float row_total_in_lane15(float v) {
   v += dppw<0x118, 0xf, true>(v);  // row_shr:8
   return v;
 }
+// the same scan in the other direction: lane 0 of every row ends with the row total
+__device__ __forceinline__ float row_total_in_lane0(float v) {
+  v += dppw<0x101, 0xf, true>(v);  // row_shl:1
+  v += dppw<0x102, 0xf, true>(v);  // row_shl:2
+  v += dppw<0x104, 0xf, true>(v);  // row_shl:4
+  v += dppw<0x108, 0xf, true>(v);  // row_shl:8
+  return v;
+}
 
 #define WB 64  // batch = one list entry per lane
 
@@ -113,10 +121,18 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
     Tbg[s] = T[s] * b;
     A[s] = kd_prev[s] = last_alpha[s] = 0.f;
   }
-  // per-row factors applied after the reduction (lane 15 of row q carries value q of t0 / 4+q of t1)
-  const int rq = lane >> 4;
+  // After the reduction the twelve totals of an entry sit in THREE lanes of every 16-lane row - lane 15: value q of t0,
+  // lane 0: value 4 + q of t1, lane 7: t2's value of row q - so that ONE atomic instruction (12 lanes, one 64-byte gradient
+  // row) carries them all; per-lane slot and factor are fixed for the whole kernel.  (Three instructions with four lanes each
+  // were three requests to the memory-side atomic units per entry: 2.9 M per view at the bench workload, against the ~20 G
+  // requests/s those units retire - MI355X_MICROARCH.md "Global float atomics".)
+  const int rq = lane >> 4, lr = lane & 15;
   const float rowscale0 = rq == 0 ? (0.5f * W) / GS_LOG2E : (rq == 1 ? (0.5f * H) / GS_LOG2E : -0.5f);
   const float rowscale1 = rq == 0 ? -0.5f : 1.0f;
+  const bool live2 = rq == 0 || (HAS_EXTRA && !FSGS && rq == 1) || (HAS_INVDEPTH && rq == 2);
+  const int lane_slot = lr == 15 ? rq : (lr == 0 ? 4 + rq : (rq == 0 ? GR_CB : (rq == 1 ? GR_EXTRA : (rq == 2 ? GR_ID : GR_N))));
+  const float lane_scale = lr == 15 ? rowscale0 : (lr == 0 ? rowscale1 : 1.0f);
+  const bool lane_adds = lr == 15 || lr == 0 || (lr == 7 && live2);
   const int q0 = n - (int)lmax;  // entries q < q0 (counted from the back) are behind every pixel's last contributor
   const int rounds = (n + WB - 1) / WB;
 
@@ -181,7 +197,8 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
       const float q2a = co.x + co.x, q2c = co.z + co.z;
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        if (vmask[s] == 0ull) continue;  // wave-uniform: quadrant not touched by this Gaussian
+        // (no separate wave-uniform "quadrant untouched" test: the exec-mask region's own s_cbranch_execz is that test, and a
+        // scalar instruction costs 2.7 vector issue slots - tests/tools/valu_peak_probe.hip)
         if (valid[s]) {
           const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
           const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));
@@ -224,22 +241,14 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
       const float s0 = swap32_add(v_mx, v_cxx), s1 = swap32_add(v_my, v_cxy);   // (0|2) (1|3)
       const float s2 = swap32_add(v_cyy, v_c0), s3 = swap32_add(v_op, v_c1);    // (4|6) (5|7)
       const float s4 = swap32_add(v_c2, v_id);                                  // (8|9)
-      const float t0 = row_total_in_lane15(swap16_add(s0, s1));                 // rows: 0 1 2 3
-      const float t1 = row_total_in_lane15(swap16_add(s2, s3));                 // rows: 4 5 6 7
+      const float t0 = row_total_in_lane15(swap16_add(s0, s1));                 // rows: 0 1 2 3   (total in lane 15)
+      const float t1 = row_total_in_lane0(swap16_add(s2, s3));                  // rows: 4 5 6 7   (total in lane 0)
       const float s5 = HAS_EXTRA ? swap32_add(v_x, 0.f) : 0.f;                  // (10|-)
-      const float t2 = row_total_in_lane15(swap16_add(s4, s5));                 // rows: 8 10 9 -
-      if ((lane & 15) == 15) {
-        // (no "!= 0" tests: an entry that reaches this point has a touched pixel, its sums are non-zero in practice
-        // and three exec-mask regions cost more than the rare zero add)
-        float* row = grad_rows + (size_t)s_id[j] * GR_STRIDE;
-        const int q = lane >> 4;
-        atomicAdd(row + q, t0 * rowscale0);      // mean2D.x, mean2D.y, conic.xx, conic.xy
-        atomicAdd(row + 4 + q, t1 * rowscale1);  // conic.yy, opacity, colour r, g
-        // colour b (row 0 -> slot 8), 4th channel (row 1 -> slot 10), inverse depth (row 2 -> slot 9); rows without a
-        // value add their 0 to the padding slot 11 so that the instruction keeps one lane-dependent address form
-        const bool live2 = q == 0 || (HAS_EXTRA && !FSGS && q == 1) || (HAS_INVDEPTH && q == 2);
-        atomicAdd(row + (q == 0 ? GR_CB : (q == 1 ? GR_EXTRA : (q == 2 ? GR_ID : GR_N))), live2 ? t2 : 0.0f);
-      }
+      const float t2 = row_total_in_lane15(swap16_add(s4, s5));                 // rows: 8 10 9 -  (total in lane 15 ...
+      const float t2m = dppw<0x128, 0xf, true>(t2);                             //  ... row_ror:8: lane 15 -> lane 7)
+      // (no "!= 0" test: an entry that reaches this point has a touched pixel, its sums are non-zero in practice)
+      const float tot = (lr == 15 ? t0 : (lr == 0 ? t1 : t2m)) * lane_scale;
+      if (lane_adds) atomicAdd(grad_rows + (size_t)s_id[j] * GR_STRIDE + lane_slot, tot);
     }
   }
 }

@@ -58,15 +58,20 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
   const int n = (int)(range.y - range.x);
   const int rounds = (n + WB - 1) / WB;
 
+  // T[s] > 0: the pixel's transmittance, pixel alive.  T[s] < 0: the pixel is done - it saturated at an earlier entry (or
+  // lies outside the image) - and |T[s]| is its final transmittance (forward.cu:360-364 leaves T untouched when
+  // T (1 - alpha) < 1e-4 and stops).  "Done" in the sign bit instead of a flag: a flag assigned under a divergent branch
+  // and carried around the loop is kept by the compiler as a 0/1 byte per lane and converted to a lane mask and back
+  // several times per entry - a third of the loop's 60-90 scalar instructions (a SIMD issues one scalar instruction per
+  // four cycles: tests/tools/valu_peak_probe.hip), with nested exec-mask regions on top.
   float T[4], C0[4], C1[4], C2[4], D[4], X[4];
   uint32_t last_contributor[4];
-  bool done[4], inside[4];
+  bool inside[4];
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const int px = px0 + (s & 1) * 8, py = py0 + (s >> 1) * 8;
     inside[s] = px < W && py < H;
-    done[s] = !inside[s];
-    T[s] = 1.0f;
+    T[s] = inside[s] ? 1.0f : -1.0f;
     C0[s] = C1[s] = C2[s] = D[s] = X[s] = 0.f;
     last_contributor[s] = 0;
   }
@@ -80,7 +85,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
   }
   for (int i = 0; i < rounds; i++) {
     // the whole tile is done (forward.cu:326-328)
-    if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
+    if (!__any(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f)) break;
     __syncthreads();  // single wave: previous batch fully consumed
     s_a[lane] = make_float4(ra.x, ra.y, FSGS ? ra.z : ra.w, ra.z);
     s_c[lane] = blend_stage_conic(rc);  // (qa, qb, qc, opacity), see gs_blend.h
@@ -110,7 +115,8 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       }
     }
     const int cnt = min(WB, n - i * WB);
-    for (int j = 0; j < cnt; j++) {
+    bool running = true;  // (wave-uniform; the outer loop's own check ends the tile when the batch loop has been left)
+    for (int j = 0; j < cnt && running; j++) {
       const uint32_t contributor = (uint32_t)(i * WB + j + 1);
       const float4 a = s_a[j];
       const float4 k = s_k[j];
@@ -130,35 +136,31 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
         const float p2 = blend_power2(co, dx, dy);
         alpha[s] = fminf(0.99f, co.w * blend_exp2(p2));
         const bool c1 = p2 <= 0.0f, c2 = alpha[s] >= 1.0f / 255.0f;
-        hit[s] = !done[s] && c1 && c2;
-        hmask |= __ballot(c1) & __ballot(c2) & ~__ballot(done[s]);
+        const bool alive = T[s] > 0.f;
+        hit[s] = alive && c1 && c2;
+        hmask |= __ballot(c1) & __ballot(c2) & __ballot(alive);
       }
       if (hmask == 0ull) continue;
-      // (a branch-free, select-masked update of all four pixels - 14 VALU ops each, no exec-mask bookkeeping - was
-      // measured 5 % slower: 0.215 vs 0.204 ms; the exec-masked form skips untouched quadrants)
+      // one exec-mask region per touched quadrant, no branch inside it (a fully branch-free, select-masked update of all
+      // four pixels was measured 5 % slower in round 2: 0.215 vs 0.204 ms)
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         if (hit[s]) {
           const float test_T = T[s] * (1 - alpha[s]);
-          if (test_T < 0.0001f) {
-            done[s] = true;
-          } else {
-            const float w = alpha[s] * T[s];
-            C0[s] += k.x * w;
-            C1[s] += k.y * w;
-            C2[s] += k.z * w;
-            D[s] += a.z * w;
-            if (HAS_EXTRA) X[s] += s_e[j] * w;
-            if (FSGS) X[s] += w;
-            T[s] = test_T;
-            last_contributor[s] = contributor;
-          }
+          const bool sat = test_T < 0.0001f;          // saturates here: this entry is NOT blended, the pixel is done
+          const float w = sat ? 0.f : alpha[s] * T[s];
+          C0[s] += k.x * w;
+          C1[s] += k.y * w;
+          C2[s] += k.z * w;
+          D[s] += a.z * w;
+          if (HAS_EXTRA) X[s] += s_e[j] * w;
+          if (FSGS) X[s] += w;
+          T[s] = sat ? -T[s] : test_T;
+          last_contributor[s] = sat ? last_contributor[s] : contributor;
         }
       }
-      if (!__any(!(done[0] && done[1] && done[2] && done[3]))) {
-        if (!CULL) stop_z = a.w;
-        break;
-      }
+      running = __any(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f);
+      if (!running && !CULL) stop_z = a.w;
     }
   }
   if (lane == 0) {
@@ -185,13 +187,14 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
     if (inside[s]) {
       const int px = px0 + (s & 1) * 8, py = py0 + (s >> 1) * 8;
       const int pix_id = W * py + px;
-      final_T[pix_id] = T[s];
+      const float Tf = fabsf(T[s]);
+      final_T[pix_id] = Tf;
       n_contrib[pix_id] = last_contributor[s];
-      out_color[pix_id] = C0[s] + T[s] * bg0;
-      out_color[HW + pix_id] = C1[s] + T[s] * bg1;
-      out_color[2 * HW + pix_id] = C2[s] + T[s] * bg2;
+      out_color[pix_id] = C0[s] + Tf * bg0;
+      out_color[HW + pix_id] = C1[s] + Tf * bg1;
+      out_color[2 * HW + pix_id] = C2[s] + Tf * bg2;
       if (out_invdepth) out_invdepth[pix_id] = D[s];
-      if (HAS_EXTRA) out_extra[pix_id] = X[s] + T[s] * bg0;  // the reference's NIR pass keeps channel 0 (bg[0])
+      if (HAS_EXTRA) out_extra[pix_id] = X[s] + Tf * bg0;  // the reference's NIR pass keeps channel 0 (bg[0])
       if (FSGS) out_extra[pix_id] = X[s];
     }
   }

@@ -1361,11 +1361,24 @@ class GraphedStep:
         torch.cuda.synchronize(dev)
         fits = self._view_ok(be)
         if fits:
+            # A cyclic-garbage sweep INSIDE the capture may free tensors of an earlier capture's private pool (autograd
+            # contexts are cycles) - a device free while the stream is capturing aborts the process.  So: the old graph goes
+            # first, garbage is collected now, and the collector stays off until the capture has ended.
+            import gc
+            self.graph = None
+            gc.collect()
+            torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             self._load(ci)
             self._coef_for_next()
-            with torch.cuda.graph(self.graph):
-                self.s_loss = one_step()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.s_loss = one_step()
+            finally:
+                if gc_was_on:
+                    gc.enable()
             self.s_rm_before = (tr.last.get("parts") or {}).get("running_mean_before")  # (a view of the captured output)
             # the capture itself launched nothing: replay once so that this call ends with a step
             self._upload_tag()

@@ -86,5 +86,6 @@ def test_schedule_with_densification_runs_on_the_gpu(hip):
         losses.append(float(out["loss"]))
     assert len(set(sizes)) > 1 and all(torch.isfinite(torch.tensor(losses)))
     assert model.flat.numel() == model.P * 59 and model.optimizer.exp_avg.numel() == model.flat.numel()
-    assert model.exchange.numel() == model.flat_padded.numel() + 2 * model.P and model.denom.shape == (model.P, 1)
+    # (exchange buffer = padded gradients + this step's [2, P] statistic increments + 4 floats for the validity flag)
+    assert model.exchange.numel() == model.flat_padded.numel() + 2 * model.P + 4 and model.denom.shape == (model.P, 1)
     assert 0 <= model.flat_padded.numel() - model.P * 59 < 3360  # padded to whole optimizer shards

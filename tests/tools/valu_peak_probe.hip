@@ -10,6 +10,9 @@
 //   pk_mul    48 x v_pk_mul_f32
 //   mix5_1    40 x v_fma_f32 + 8 x v_exp_f32 (the blend kernels' ratio: 5 VALU per transcendental)
 //   blendmix  a stream shaped like the blend kernels' alpha test: v_sub, v_mul, v_fma x3, v_exp, v_mul, v_min, v_cmp x2
+//   salu      48 x s_and_b64 on 8 independent SGPR pairs: the SCALAR issue rate (the blend loops keep their lane masks in
+//             scalars: ballots, mask algebra, exec-mask regions - 60-90 scalar instructions per list entry)
+//   valu_salu_1to1  48 x (v_fma_f32 ; s_and_b64) interleaved, 96 instructions: do the two pipes issue side by side?
 // Waves per SIMD are forced by the LDS a workgroup asks for: a workgroup = 4 waves (one per SIMD of its CU) and
 // w workgroups fit a CU, so every SIMD holds w waves.  The grid is 256 CUs x w x ROUNDS workgroups.
 // Reported: G wave-instructions/s of the whole chip (events around the launch) and shader cycles per instruction per SIMD
@@ -32,10 +35,10 @@ typedef float float2v __attribute__((ext_vector_type(2)));
     }                                                                                 \
   } while (0)
 
-enum Kind { FMA = 0, FMA_DEP = 1, PK_FMA = 2, PK_MUL = 3, MIX5_1 = 4, BLENDMIX = 5, NKIND = 6 };
-static const char* kind_name[NKIND] = {"fma", "fma_dep", "pk_fma", "pk_mul", "mix5_1", "blendmix"};
+enum Kind { FMA = 0, FMA_DEP = 1, PK_FMA = 2, PK_MUL = 3, MIX5_1 = 4, BLENDMIX = 5, SALU = 6, VS_MIX = 7, NKIND = 8 };
+static const char* kind_name[NKIND] = {"fma", "fma_dep", "pk_fma", "pk_mul", "mix5_1", "blendmix", "salu", "valu_salu_1to1"};
 // VALU instructions per block of each kind (all 48), and how many f32 lane-operations one instruction performs
-static const int kind_insts[NKIND] = {48, 48, 48, 48, 48, 48};
+static const int kind_insts[NKIND] = {48, 48, 48, 48, 48, 48, 48, 96};
 
 // one asm statement per 48-instruction block: between separate asm statements the compiler inserts s_nop hazard padding
 #define R8(op) op(0) op(1) op(2) op(3) op(4) op(5) op(6) op(7)
@@ -68,6 +71,20 @@ __global__ void __launch_bounds__(256) probe_kernel(float* __restrict__ out, uns
       asm volatile(X6(R8(OP_PKFMA)) : PACC8 : "v"(x2), "v"(y2));
     } else if (KIND == PK_MUL) {
       asm volatile(X6(R8(OP_PKMUL)) : PACC8 : "v"(x2), "v"(y2));
+    } else if (KIND == SALU) {
+      unsigned long long m0 = i, m1 = i + 1, m2 = i + 2, m3 = i + 3, m4 = i + 4, m5 = i + 5, m6 = i + 6, m7 = i + 7, mm = ~0ull;
+#define OP_SAND(i) "s_and_b64 %" #i ", %" #i ", %8\n"
+      asm volatile(X6(R8(OP_SAND)) : "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3), "+s"(m4), "+s"(m5), "+s"(m6), "+s"(m7) : "s"(mm));
+      a4 += (float)(m0 & 1);
+    } else if (KIND == VS_MIX) {
+      unsigned long long m0 = i, m1 = i + 1, m2 = i + 2, m3 = i + 3, mm = ~0ull;
+#define OP_VS(i) "v_fma_f32 %" #i ", %12, %13, %" #i "\n s_and_b64 %8, %8, %14\n"
+#define OP_VS2(i) "v_fma_f32 %" #i ", %12, %13, %" #i "\n s_and_b64 %9, %9, %14\n"
+      asm volatile(X6(OP_VS(0) OP_VS2(1) OP_VS(2) OP_VS2(3) OP_VS(4) OP_VS2(5) OP_VS(6) OP_VS2(7))
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(m0), "+s"(m1), "+s"(m2),
+                     "+s"(m3)
+                   : "v"(x), "v"(y), "s"(mm));
+      a4 += (float)((m0 ^ m1) & 1);
     } else if (KIND == MIX5_1) {
       asm volatile(MIX8 MIX8 MIX8 MIX8 MIX8 MIX8 MIX8 MIX8 : ACC8 : "v"(x), "v"(y));
     } else {
@@ -159,6 +176,8 @@ int main(int argc, char** argv) {
         case PK_FMA: r = run<PK_FMA>(w, iters, rounds, d_out, d_ticks, n_cu, clock_hz); break;
         case PK_MUL: r = run<PK_MUL>(w, iters, rounds, d_out, d_ticks, n_cu, clock_hz); break;
         case MIX5_1: r = run<MIX5_1>(w, iters, rounds, d_out, d_ticks, n_cu, clock_hz); break;
+        case SALU: r = run<SALU>(w, iters, rounds, d_out, d_ticks, n_cu, clock_hz); break;
+        case VS_MIX: r = run<VS_MIX>(w, iters, rounds, d_out, d_ticks, n_cu, clock_hz); break;
         default: r = run<BLENDMIX>(w, iters, rounds, d_out, d_ticks, n_cu, clock_hz); break;
       }
       printf("%-9s %5d %10.3f %12.1f %14.2f\n", kind_name[k], w, r.ms, r.ginst, r.cyc_per_inst);
