@@ -392,19 +392,25 @@ def main():
                     tr.step(k)
                     k += 1
                 barrier()
-    if graphed is None and not args.no_stage_timers:  # an eager timed region carries the event pair of the dominant kernel
-        api.call("profile_reset")
-        api.call("profile_only", names.index(dom_stage))
-        api.call("profile_enable", 1)
     from gsplat_amd import hip_backend as _hb0
-    dl0 = dict(_hb0().depth_limit_stats)
     # (no cyclic-garbage collection inside the 30 ms timed window: a generation-2 sweep of the interpreter is milliseconds)
     import gc
     gc.collect()
     gc.disable()
+    # the sweep above (and the set-up before it) left the GPU idle for tens of milliseconds: a few more untimed steps so that
+    # the timed region starts on a busy device, as every step of a training run does
+    for _ in range(3):
+        run_step(k)
+        k += 1
+    settle()
+    if graphed is None and not args.no_stage_timers:  # an eager timed region carries the event pair of the dominant kernel
+        api.call("profile_reset")
+        api.call("profile_only", names.index(dom_stage))
+        api.call("profile_enable", 1)
     if world > 1:
         tr.exchange_events = []   # (Trainer.exchange_and_step brackets the exchange + optimizer with HIP events)
     barrier()
+    dl0 = dict(_hb0().depth_limit_stats)
     t0 = time.perf_counter()
     sampled = graphed is None and not args.no_stage_timers
     for i in range(args.steps):

@@ -70,6 +70,25 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
   const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
   uint32_t tiles = 0;
   const int T = a.grid_x * a.grid_y;
+  // region binning: up to four bucket counters waiting to be bumped (selects, not an indexed array: that would live in
+  // scratch memory), the slots they returned, and this Gaussian's bucket entry
+  int p0 = 0, p1 = 0, p2 = 0, p3 = 0, n_pend = 0;
+  uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu, dbits = 0;
+  auto bump = [&]() {
+    if (n_pend > 0) s0 = atomicAdd(&a.region_count[(size_t)p0 * RG_COUNT_STRIDE], 1u);
+    if (n_pend > 1) s1 = atomicAdd(&a.region_count[(size_t)p1 * RG_COUNT_STRIDE], 1u);
+    if (n_pend > 2) s2 = atomicAdd(&a.region_count[(size_t)p2 * RG_COUNT_STRIDE], 1u);
+    if (n_pend > 3) s3 = atomicAdd(&a.region_count[(size_t)p3 * RG_COUNT_STRIDE], 1u);
+    n_pend = 0;
+  };
+  auto collect = [&]() {
+    const uint2 entry = make_uint2(dbits, (uint32_t)idx);
+    if (s0 < a.region_cap) a.region_bucket[(size_t)p0 * a.region_cap + s0] = entry;
+    if (s1 < a.region_cap) a.region_bucket[(size_t)p1 * a.region_cap + s1] = entry;
+    if (s2 < a.region_cap) a.region_bucket[(size_t)p2 * a.region_cap + s2] = entry;
+    if (s3 < a.region_cap) a.region_bucket[(size_t)p3 * a.region_cap + s3] = entry;
+    s0 = s1 = s2 = s3 = 0xFFFFFFFFu;
+  };
   if (lds_floats) {  // the tail of the limit buffer (segments), or all of it
     const float* src = a.tile_depth_limit + (GS_LIMIT_TILES_IN_LDS ? 0 : T);
     for (int i = threadIdx.x; i < lds_floats; i += GS_BLOCK) s_limit[i] = src[i];
@@ -171,13 +190,14 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
             ty1 = min(ty1, (int)floorf(yh * 0.0625f) + 1);
           }
           if (tx1 > tx0 && ty1 > ty0) {
-            const uint32_t dbits = __float_as_uint(sp.depth);
             const int segs_x = (int)depth_limit_segs_x((uint32_t)a.grid_x);
-            // A returning atomic takes a microsecond or two to come back: the (up to four: a footprint within 2 x 2 regions,
-            // nearly all of them) atomics of a Gaussian are issued back to back, their bucket writes follow; larger
-            // footprints take the rest one by one.
-            int p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // (selects, not an indexed array: that would live in scratch memory)
-            int n_pend = 0;
+            // A returning device-scope atomic is the slowest thing this kernel does (about 5 us under load at C3; measured: a
+            // second set of them costs 16 us of the kernel's 120).  So: never one after the other - the bucket counters of a
+            // Gaussian are bumped four at a time, back to back (a footprint within 2 x 2 regions, nearly all of them, has one
+            // such batch; taking the regions beyond the fourth one by one cost 29 us, the wave waiting for its largest
+            // Gaussian) - and the last batch is issued behind the loads of the SH row and collected after the colour is
+            // computed, so that its round trip hides under that of the coefficients (`bump` / `collect` below).
+            dbits = __float_as_uint(sp.depth);
             for (int ry = ty0 >> 2; ry <= (ty1 - 1) >> 2; ry++) {
               for (int rx = tx0 >> 2; rx <= (tx1 - 1) >> 2; rx++) {
                 if (a.tile_depth_limit) {
@@ -194,28 +214,14 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
                 }
                 const int r = ry * a.rg_x + rx;
                 tiles++;
-                if (n_pend < 4) {
-                  p0 = n_pend == 0 ? r : p0;
-                  p1 = n_pend == 1 ? r : p1;
-                  p2 = n_pend == 2 ? r : p2;
-                  p3 = n_pend == 3 ? r : p3;
-                  n_pend++;
-                } else {
-                  const uint32_t slot = atomicAdd(&a.region_count[(size_t)r * RG_COUNT_STRIDE], 1u);
-                  if (slot < a.region_cap) a.region_bucket[(size_t)r * a.region_cap + slot] = make_uint2(dbits, (uint32_t)idx);
-                }
+                if (n_pend == 4) { bump(); collect(); }
+                p0 = n_pend == 0 ? r : p0;
+                p1 = n_pend == 1 ? r : p1;
+                p2 = n_pend == 2 ? r : p2;
+                p3 = n_pend == 3 ? r : p3;
+                n_pend++;
               }
             }
-            uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
-            if (n_pend > 0) s0 = atomicAdd(&a.region_count[(size_t)p0 * RG_COUNT_STRIDE], 1u);
-            if (n_pend > 1) s1 = atomicAdd(&a.region_count[(size_t)p1 * RG_COUNT_STRIDE], 1u);
-            if (n_pend > 2) s2 = atomicAdd(&a.region_count[(size_t)p2 * RG_COUNT_STRIDE], 1u);
-            if (n_pend > 3) s3 = atomicAdd(&a.region_count[(size_t)p3 * RG_COUNT_STRIDE], 1u);
-            const uint2 entry = make_uint2(dbits, (uint32_t)idx);
-            if (s0 < a.region_cap) a.region_bucket[(size_t)p0 * a.region_cap + s0] = entry;
-            if (s1 < a.region_cap) a.region_bucket[(size_t)p1 * a.region_cap + s1] = entry;
-            if (s2 < a.region_cap) a.region_bucket[(size_t)p2 * a.region_cap + s2] = entry;
-            if (s3 < a.region_cap) a.region_bucket[(size_t)p3 * a.region_cap + s3] = entry;
           }
         }
       } else if (a.tile_cull) {
@@ -290,14 +296,17 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
                 sh.f[4 * k] = sh.f[4 * k + 1] = sh.f[4 * k + 2] = sh.f[4 * k + 3] = 0.f;
               }
             }
+            bump();
             rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
           } else {
+            bump();
             ShMem sh{a.shs + (size_t)idx * a.M * 3};
             rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
           }
           sp.r = rgb.x; sp.g = rgb.y; sp.b = rgb.z;
           sp.clamped |= cl;  // (bits 8-9 already hold the depth-limit verdict)
         } else {
+          bump();
           sp.r = a.colors_precomp[3 * idx];
           sp.g = a.colors_precomp[3 * idx + 1];
           sp.b = a.colors_precomp[3 * idx + 2];
@@ -322,6 +331,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       cd[2] = make_float2(cov3D[4], cov3D[5]);
     }
     g.tiles_touched[idx] = tiles;
+    collect();  // (the last batch of bucket slots: nothing pending outside region mode)
     // key of the per-Gaussian depth sort (gs_binning.hip): culled Gaussians sort behind everything
     if (a.tile_cull != 2) g.depth_keys[idx] = tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
     a.radii[idx] = radius_out;

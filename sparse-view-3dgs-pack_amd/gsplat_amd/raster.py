@@ -52,7 +52,12 @@ class RasterBackend:
         self.tile_cull = os.environ.get("GS_TILE_CULL", "1") != "0"
         # how the culled lists are built: "region" = region binning (csrc/gs_regionbin.hip, GsView.tile_cull = 2: two launches),
         # "lsd" = depth sort + emission + partition by tile (csrc/gs_binning.hip, 23 launches).  Same lists tile by tile.
-        self.binning = os.environ.get("GS_BINNING", "region")
+        # "auto" (default): region binning, except for forwards WITHOUT depth limits whose lists are known to be long (more
+        # than REGION_AUTO_MAX instances per region at the capacity the previous views needed: ~5 000 Gaussians per region) -
+        # a region's bitonic sort grows as n log^2 n and its bucket atomics as n, so beyond that the LSD path is as fast or
+        # faster (C3 full culled lists, 9.55 M instances: preprocess + binning 0.44 ms with regions, 0.42 ms LSD; depth-limited,
+        # 1.86 M: 0.20 vs 0.30)
+        self.binning = os.environ.get("GS_BINNING", "auto")
         self.last_deferred_num_rendered = None  # instance count of the last deferred forward whose verdict was collected
         self._region_off = set()   # (P, W, H) whose regions hold more Gaussians than one workgroup sorts: LSD path
         self._cap_memo = {}
@@ -121,7 +126,7 @@ class RasterBackend:
         v.sh_degree = int(degree)
         v.prefiltered, v.antialiasing, v.debug = int(bool(prefiltered)), int(bool(antialiasing)), int(bool(debug))
         v.tile_cull = int(self.tile_cull)
-        if self.tile_cull and self.binning == "region" and device.type == "cuda" and \
+        if self.tile_cull and self.binning in ("region", "auto") and device.type == "cuda" and \
                 (self._region_key is None or self._region_key not in self._region_off):
             v.tile_cull = 2
         bg, viewmatrix, projmatrix, campos = (_prep(x, device) for x in (bg, viewmatrix, projmatrix, campos))
@@ -433,6 +438,10 @@ class RasterBackend:
             self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(scratch_of(empty, 0, limit)),
                           radii.data_ptr(), status.data_ptr(), stream)
 
+        if view.tile_cull == 2 and self.binning == "auto" and limit is None and not static:
+            regions = ((((W + 15) // 16) + 3) // 4) * ((((H + 15) // 16) + 3) // 4)
+            if self._capacity_hint > self.REGION_AUTO_MAX * regions:
+                view.tile_cull = 1   # long un-limited lists: the LSD path (same lists)
         if view.tile_cull == 2:
             out = self._forward_region(P, W, H, cache, limit, defer, static, status, cur, geom, img, view, g, radii, stream,
                                        new_binning, scratch_of, render, remember)
@@ -512,6 +521,7 @@ class RasterBackend:
             return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
 
     REGION_MAX_ENTRIES = 16384  # csrc/gs_common.h RG_MAX_ENTRIES
+    REGION_AUTO_MAX = 13000     # binning = "auto": instances of capacity per region above which un-limited forwards take the LSD path
 
     def _forward_region(self, P, W, H, cache, limit, defer, static, status, cur, geom, img, view, g, radii, stream,
                         new_binning, scratch_of, render, remember):
