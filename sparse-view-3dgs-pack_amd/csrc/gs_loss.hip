@@ -426,6 +426,29 @@ __constant__ float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.03
 #define HS 33  // row stride of the horizontal-pass buffer (odd): the 32 lanes of a store group (8 column groups x 4 rows)
                // and of a vertical-pass load group (one row) each fall on 32 different banks
 
+// Workgroup -> tile mapping of the SSIM kernels.  The hardware deals consecutive workgroups out to the 8 XCDs in turn, each
+// with its own L2; with the natural (x, y, plane) order horizontally adjacent tiles - which share 16 of a halo row's 48
+// floats - land on different XCDs and every XCD fetches its own copy of the shared lines (PMC: 2x the bytes the tiles
+// span).  Here launch slot b belongs to XCD b % 8 and XCD k works through the k-th contiguous eighth of the tiles in raster
+// order: neighbours run on the same XCD at about the same time and meet in its L2.
+struct SsimTile { int bx, by, z, linear; bool live; };
+__device__ __forceinline__ SsimTile ssim_tile_of_block(int gx, int gy, int gz) {
+  const int n = gx * gy * gz, per = (n + 7) / 8;
+  const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  SsimTile r;
+  r.live = (int)(blockIdx.x >> 3) < per && t < n;
+  r.linear = t;
+  r.z = t / (gx * gy);
+  const int rem = t - r.z * gx * gy;
+  r.by = (rem / gx) * ST;
+  r.bx = (rem % gx) * ST;
+  return r;
+}
+static inline unsigned ssim_launch_blocks(int W, int H, int planes) {
+  const int n = ((W + ST - 1) / ST) * ((H + ST - 1) / ST) * planes;
+  return (unsigned)(((n + 7) / 8) * 8);
+}
+
 // Separable 11-tap convolution of NQ quantities over the 42x42 halo tile.  Register-blocked: a thread produces 4
 // adjacent outputs along the pass direction from 14 inputs (sliding window), i.e. 3.5 LDS reads per output and
 // quantity instead of 11; in the forward the five quantities (a, a^2, b, b^2, ab) are formed from the two image
@@ -509,13 +532,16 @@ __device__ __forceinline__ void ssim_conv_tile(const float (*tile)[SH][SH + 1], 
 __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                             int H, int W, float C1, float C2, float* __restrict__ ssim_map,
                                                             float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
-                                                            float* __restrict__ dm_dsigma12, float* sum_out, float* __restrict__ partials) {
+                                                            float* __restrict__ dm_dsigma12, float* sum_out, float* __restrict__ partials,
+                                                            int planes) {
   constexpr int LDS_WORDS = (2 * SH * (SH + 1) > 5 * SH * HS) ? 2 * SH * (SH + 1) : 5 * SH * HS;
   __shared__ float lds_buf[LDS_WORDS];
   float (*tile)[SH][SH + 1] = reinterpret_cast<float (*)[SH][SH + 1]>(lds_buf);
   float (*hor)[SH][HS] = reinterpret_cast<float (*)[SH][HS]>(lds_buf);
-  const size_t plane = (size_t)blockIdx.z * H * W;
-  const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
+  const SsimTile tl = ssim_tile_of_block((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  if (!tl.live) return;
+  const size_t plane = (size_t)tl.z * H * W;
+  const int bx = tl.bx, by = tl.by;
   // Halo tile loads.  Rows are 42 floats starting at column bx - 5: with W a multiple of 4 (and so every plane and row
   // 16-byte aligned) the aligned span [bx - 8, bx + 40) is fetched as 12 float4 per row - 2 vector loads per thread and
   // plane instead of 7 scalar ones (a float4 lies entirely inside or entirely outside the image); else element-wise.
@@ -618,7 +644,7 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_fwd_kernel(const float* __restr
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
     __syncthreads();
     if (threadIdx.x == 0)
-      partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      partials[tl.linear] = (red[0] + red[1]) + (red[2] + red[3]);
   } else if (sum_out) {  // uniform branch: mean SSIM without a second pass over the map
     float acc[1] = {msum};
     __syncthreads();
@@ -632,14 +658,16 @@ __global__ void __launch_bounds__(GS_BLOCK) ssim_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dm_dsigma1_sq,
                                                             const float* __restrict__ dm_dsigma12,
                                                             float* __restrict__ dL_dimg1, const float* __restrict__ coef_dev,
-                                                            int accumulate, const float* __restrict__ clamp_src) {
+                                                            int accumulate, const float* __restrict__ clamp_src, int planes) {
   constexpr int LDS_WORDS = (3 * SH * (SH + 1) > 3 * SH * HS) ? 3 * SH * (SH + 1) : 3 * SH * HS;
   __shared__ float lds_buf[LDS_WORDS];
   float (*tile)[SH][SH + 1] = reinterpret_cast<float (*)[SH][SH + 1]>(lds_buf);
   float (*hor)[SH][HS] = reinterpret_cast<float (*)[SH][HS]>(lds_buf);
   const float gu = coef_dev ? coef_dev[0] : 0.f;  // uniform dL/dssim_map (mean reduction upstream)
-  const size_t plane = (size_t)blockIdx.z * H * W;
-  const int bx = blockIdx.x * ST, by = blockIdx.y * ST;
+  const SsimTile tl = ssim_tile_of_block((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  if (!tl.live) return;
+  const size_t plane = (size_t)tl.z * H * W;
+  const int bx = tl.bx, by = tl.by;
   const bool vec = (W & 3) == 0 && !dL_dmap &&
                    ((((uintptr_t)dm_dmu1) | ((uintptr_t)dm_dsigma1_sq) | ((uintptr_t)dm_dsigma12)) & 15) == 0;
   if (vec) {  // (see ssim_fwd_kernel; uniform upstream gradient only - the train step's case)
@@ -889,8 +917,8 @@ int gs_ssim_fwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_FWD, s);
-  hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_launch_blocks(W, H, B * C)), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, (float*)nullptr, B * C);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -901,8 +929,8 @@ int gs_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int3
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_BWD, s);
-  hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, (const float*)nullptr, 0, (const float*)nullptr);
+  hipLaunchKernelGGL(ssim_bwd_kernel, dim3(ssim_launch_blocks(W, H, B * C)), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, (const float*)nullptr, 0, (const float*)nullptr, B * C);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -931,8 +959,8 @@ int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, 
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_FWD, s);
-  hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, sum_out, (float*)nullptr);
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_launch_blocks(W, H, B * C)), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, sum_out, (float*)nullptr, B * C);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -949,8 +977,8 @@ int gs_ssim_fwd_partials(const float* img1, const float* img2, int32_t B, int32_
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_FWD, s);
-  hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, partials);
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_launch_blocks(W, H, B * C)), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     C1, C2, (float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, partials, B * C);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -962,8 +990,8 @@ int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_SSIM_BWD, s);
-  hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + ST - 1) / ST, (H + ST - 1) / ST, B * C), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
-                     (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, coef_dev, accumulate, clamp_src);
+  hipLaunchKernelGGL(ssim_bwd_kernel, dim3(ssim_launch_blocks(W, H, B * C)), dim3(GS_BLOCK), 0, s, img1, img2, H, W,
+                     (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, coef_dev, accumulate, clamp_src, B * C);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
