@@ -417,6 +417,11 @@ int gs_l1_bwd_dev(const float* a, const float* b, int64_t n, const float* coef_d
  * grad_pred (+= if accumulate) = l1_coef_dev[0] * sign(pred - gt) + the gs_dwt2_l1_bwd term. */
 int gs_l1_dwt2_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* l1_sum,
                    float* band_sums, void* stream);
+/* gs_l1_dwt2_fwd on clamp(raw, 0, 1), which is also written to clamped_out [C,H,W] (the clamp of
+ * gaussian_renderer/__init__.py:119 without a pass of its own).  H and W multiples of 4 and 16-byte aligned planes, else
+ * GS_E_UNSUPPORTED (clamp first and call gs_l1_dwt2_fwd). */
+int gs_l1_dwt2_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, float* l1_sum,
+                         float* band_sums, float* clamped_out, void* stream);
 int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
                    const float* l1_coef_dev /*[1]*/, const float* coef_dev /*[8]*/, float* grad_pred,
                    int32_t accumulate, void* stream);

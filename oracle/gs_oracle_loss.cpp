@@ -488,6 +488,15 @@ int gso_l1_dwt2_fwd(const float* pred, const float* gt, int32_t C, int32_t H, in
   int rc = gso_l1_fwd(pred, gt, (int64_t)C * H * W, l1_sum, nullptr);
   return rc ? rc : gso_dwt2_l1_fwd(pred, gt, C, H, W, band_sums, nullptr);
 }
+int gso_l1_dwt2_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, float* l1_sum, float* band_sums,
+                          float* clamped_out, void*) {
+  if (!raw || !clamped_out) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  if ((H % 4) != 0 || (W % 4) != 0) return GS_E_UNSUPPORTED;
+  const int64_t n = (int64_t)C * H * W;
+  for (int64_t i = 0; i < n; i++) clamped_out[i] = fminf(fmaxf(raw[i], 0.f), 1.f);  // gaussian_renderer/__init__.py:119
+  return gso_l1_dwt2_fwd(clamped_out, gt, C, H, W, l1_sum, band_sums, nullptr);
+}
 int gso_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* l1_coef,
                     const float* coef, float* grad, int32_t accumulate, void*) {
   if (!l1_coef) return GS_E_NULL;

@@ -178,9 +178,12 @@ __device__ __forceinline__ void bands_of(const Px44& x, Blk44& o) {
 }
 
 // sums[0..7] += band L1 sums; sums[8] (only when l1_sum != nullptr, added there) += sum |pred - gt|
+// clamped_out (FAST only): `pred` is the un-clamped render - the 4x4 block is clamped to [0, 1] as it is loaded and written
+// there, which is the torch.clamp pass of gaussian_renderer/__init__.py:119 without its own read of the image
 template <bool FAST>
 __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                               int C, int H, int W, float* band_sums, float* l1_sum) {
+                                                               int C, int H, int W, float* band_sums, float* l1_sum,
+                                                               float* __restrict__ clamped_out) {
   const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
   const int64_t total = (int64_t)C * h2 * w2;
   float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -189,6 +192,15 @@ __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __re
     Px44 pa, pb;
     load_px44<FAST>(pred + (size_t)c * H * W, H, W, i2, j2, h1, w1, pa);
     load_px44<FAST>(gt + (size_t)c * H * W, H, W, i2, j2, h1, w1, pb);
+    if (FAST && clamped_out) {
+#pragma unroll
+      for (int y = 0; y < 4; y++) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) pa.v[y][x] = fminf(fmaxf(pa.v[y][x], 0.f), 1.f);  // (torch.clamp: NaN stays NaN - v_max/v_min drop it; renders are finite)
+        reinterpret_cast<float4*>(clamped_out + (size_t)c * H * W + (size_t)(4 * i2 + y) * W)[j2] =
+            make_float4(pa.v[y][0], pa.v[y][1], pa.v[y][2], pa.v[y][3]);
+      }
+    }
     Blk44 a, b;
     bands_of(pa, a);
     bands_of(pb, b);
@@ -807,15 +819,18 @@ static inline bool dwt2_fast(const void* a, const void* b, const void* g, int H,
   return (H % 4) == 0 && (W % 4) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)g) & 15) == 0);
 }
 static int dwt2_l1_fwd_launch(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* band_sums,
-                              float* l1_sum, hipStream_t s) {
+                              float* l1_sum, hipStream_t s, float* clamped_out = nullptr) {
   const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
   // few, long-running workgroups: every workgroup ends in nine atomics on one cache line, and at 1500 workgroups
   // (1080p) their serialisation was 40 % of the kernel (25.9 us at a 4096 cap, 15.1 us at 512)
   const dim3 grid(nblocks((int64_t)C * h2 * w2, GS_BLOCK, 512));
-  if (dwt2_fast(pred, gt, nullptr, H, W))
-    hipLaunchKernelGGL(dwt2_l1_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum);
+  if (dwt2_fast(pred, gt, clamped_out, H, W))
+    hipLaunchKernelGGL(dwt2_l1_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum, clamped_out);
+  else if (clamped_out)
+    return GS_E_UNSUPPORTED;  // (H, W multiples of 4 and 16-byte aligned planes only: clamp with torch otherwise)
   else
-    hipLaunchKernelGGL(dwt2_l1_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum);
+    hipLaunchKernelGGL(dwt2_l1_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum,
+                       (float*)nullptr);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -854,6 +869,14 @@ int gs_l1_dwt2_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_DWT2_FWD, s);
   return dwt2_l1_fwd_launch(pred, gt, C, H, W, band_sums, l1_sum, s);
+}
+int gs_l1_dwt2_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, float* l1_sum, float* band_sums,
+                         float* clamped_out, void* stream) {
+  if (!raw || !gt || !band_sums || !l1_sum || !clamped_out) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT2_FWD, s);
+  return dwt2_l1_fwd_launch(raw, gt, C, H, W, band_sums, l1_sum, s, clamped_out);
 }
 int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* l1_coef_dev,
                    const float* coef_dev, float* grad_pred, int32_t accumulate, void* stream) {
