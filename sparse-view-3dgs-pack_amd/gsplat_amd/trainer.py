@@ -1206,115 +1206,71 @@ class TrainerNIR(Trainer):
 # hipGraph replay of the steady-state single-GPU step
 # ----------------------------------------------------------------------------------------------------------------
 class GraphedStep:
-    """Captures ONE train step of a Trainer (forward, fused criterion, gs_backward_step) into a hipGraph and replays it:
-    ~45 kernel launches, their Python glue and the forward's host wait become one graph launch.  What changes from step
-    to step travels through device buffers the captured kernels read: the camera (matrices, centre), its ground truth
-    and patch mask are copied into static tensors, Adam's step-dependent constants into `coef` (GsStepState.coef_dev).
-    Everything frozen at capture is checked before a replay (image size, field of view, active SH degree, number of
-    Gaussians, skipped rows); when it no longer holds - or when a view needs more binning capacity than was captured
-    (the step kernel then does nothing, see gs_backward_step) - the step runs eagerly and the graph is re-captured.
-    Results are those of the eager fused step: same kernels, same arguments."""
+    """Captures the train step of a Trainer (forward, fused criterion, gs_backward_step) into hipGraphs - ONE PER CAMERA -
+    and replays them: the kernel launches of a step, their Python glue and the forward's host wait become one graph launch.
+    Everything that belongs to a camera is baked into its own graph - matrices, ground truth, patch mask, the criterion's
+    per-camera accumulator and the backend's per-camera tile order and depth limits (the same entry the eager step of that
+    camera uses, RasterBackend.camera_entry, read and rewritten in place by the captured kernels) - so a replay copies
+    nothing: only Adam's step-dependent constants (`coef`, GsStepState.coef_dev) and the replay's tag are uploaded.  (One
+    graph fed through static buffers copied the 25 MB ground truth and a dozen small tensors per replay: 35 us of a 1.1 ms
+    step at 1080p, most of a C1 step.)  The graphs share one memory pool: replays run one at a time on one stream and no
+    intermediate outlives its replay.
+    Everything frozen at capture is checked before a replay (model buffers, image size, field of view, active SH degree,
+    the camera's tensors, the binning capacity); when it no longer holds the camera is captured again.  A view that needs
+    more binning capacity than was captured, or whose depth limits failed, did nothing on the device (gs_backward_step
+    skips on either flag): the step is then taken eagerly (settle).  Results are those of the eager fused step: same
+    kernels, same arguments."""
 
     def __init__(self, trainer, capacity_margin=1.5, warmup=3, capacity=None):
         """capacity: binning capacity (instances) to capture with; default = capacity_margin x the largest view the
-        backend has seen recently."""
+        backend has seen recently.  warmup: un-captured steps before the FIRST capture (allocator and library state
+        settle); every later camera takes one."""
         self.tr = trainer
         trainer._graphed = self   # Trainer.sync() settles the last replay too
         self.fixed_capacity = capacity
         self.capacity_margin = capacity_margin
         self.warmup = warmup
-        self.graph = None
-        self.key = None
-        self.cam_orders = {}
-        self.cam_limits = {}
+        self.graphs = {}          # camera index -> dict(graph, key, loss, rm_before)
+        self.pool = None
+        self.capacity = None
+        self.coef = None
         self.replays = self.eager_steps = self.captures = 0
         self._replay_pending = None
-        self.s_rm_before = None
+        self.s_loss = None
 
-    # -- what the capture froze
-    def _key(self, cam):
-        m = self.tr.model
+    # (compatibility: "is anything captured", the key of the last camera stepped)
+    @property
+    def graph(self):
+        return next(iter(self.graphs.values()))["graph"] if self.graphs else None
+
+    # -- what a capture froze
+    def _key(self, ci):
+        tr = self.tr
+        m, cam = tr.model, tr.cameras[ci]
+        mask = None if tr.masks is None else tr.masks[ci]
         # m.generation: a re-layout / restore / load_ply with the SAME number of Gaussians still replaces every buffer the
         # captured kernels point into; the statistic tensors are re-created by densify_and_prune on their own
         return (m.P, m.generation, m.denom.data_ptr(), m.max_radii2D.data_ptr(), m.xyz_gradient_accum.data_ptr(),
-                m.active_sh_degree, int(cam.image_height), int(cam.image_width), float(cam.FoVx), float(cam.FoVy))
+                m.active_sh_degree, int(cam.image_height), int(cam.image_width), float(cam.FoVx), float(cam.FoVy),
+                cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr(), cam.camera_center.data_ptr(),
+                tr.gts[ci].data_ptr(), None if mask is None else mask.data_ptr(), self.capacity, bool(tr.depth_limit))
 
     def _backend(self):
         tr = self.tr
         be = getattr(getattr(getattr(tr.Rasterizer, "_fn", None), "_impl", None), "backend", None)
         return be
 
-    def _load(self, ci):
+    def camera_entry(self, ci):
+        """The backend's per-camera state (tile order, depth limits) of camera `ci` - shared with the eager step."""
         tr = self.tr
         cam = tr.cameras[ci]
-        self.s_view.copy_(cam.world_view_transform, non_blocking=True)
-        self.s_proj.copy_(cam.full_proj_transform, non_blocking=True)
-        self.s_center.copy_(cam.camera_center, non_blocking=True)
-        self.s_gt.copy_(tr.gts[ci], non_blocking=True)
-        if self.s_mask is not None:
-            mk = tr.masks[ci]
-            self.s_mask.copy_(mk, non_blocking=True)
-            self.s_mask._gs_n_sel.copy_(mk._gs_n_sel, non_blocking=True)
-            self.s_mask._gs_sums[13:14].copy_(mk._gs_n_sel, non_blocking=True)  # (words 0..12 stay zero between steps)
-        # the forward's per-camera hints (RasterBackend._camera_cache keys them by the view matrix's address, which is the
-        # static tensor's here): bring in what this camera's last visit measured - tile order and per-tile depth limits
-        cc = self._cam_cache()
-        if cc is not None:
-            if ci in self.cam_orders:
-                cc["order"].copy_(self.cam_orders[ci], non_blocking=True)
-            if ci in self.cam_limits:
-                cc["limit"].copy_(self.cam_limits[ci], non_blocking=True)
-            else:
-                cc["limit"].fill_(float("inf"))
+        return self._backend().camera_entry(int(cam.image_width), int(cam.image_height), camera_key=("trainer", id(tr), ci),
+                                            device_index=tr.model.flat.device.index)
 
-    def _cam_cache(self):
-        """The backend's per-camera entry of the STATIC camera (the captured kernels read and write its buffers): found under
-        this object's own key and pinned against eviction for as long as the graph lives."""
+    def _shared_init(self, dev):
         be = self._backend()
-        cam = self.s_cam
-        cc = be._cam_cache.get((self.s_view.device.index, int(cam.image_width), int(cam.image_height),
-                                ("key", ("graph", id(self)))))
-        if cc is not None:
-            cc["pinned"] = True
-        return cc
-
-    def _save_order(self, ci):
-        cc = self._cam_cache()
-        if cc is None:
-            return
-        if cc["order_ok"]:
-            if ci not in self.cam_orders:
-                self.cam_orders[ci] = torch.empty_like(cc["order"])
-            self.cam_orders[ci].copy_(cc["order"], non_blocking=True)
-        if cc["limit_ok"]:
-            if ci not in self.cam_limits:
-                self.cam_limits[ci] = torch.empty_like(cc["limit"])
-            self.cam_limits[ci].copy_(cc["limit"], non_blocking=True)
-
-    def _capture(self, ci):
-        import numpy as np
-        tr, be = self.tr, self._backend()
-        m = tr.model
-        cam = tr.cameras[ci]
-        dev = m.flat.device
-        # static inputs
-        self.s_view = cam.world_view_transform.clone()
-        self.s_proj = cam.full_proj_transform.clone()
-        self.s_center = cam.camera_center.clone()
-        self.s_gt = tr.gts[ci].clone()
-        self.s_mask = None
-        if tr.masks is not None and tr.masks[ci] is not None:
-            self.s_mask = tr.masks[ci].clone()
-            self.s_mask._gs_n_sel = tr.masks[ci]._gs_n_sel.clone()
-            self.s_mask._gs_sums = torch.zeros((16,), dtype=torch.float32, device=dev)
-            self.s_mask._gs_sums[13:14].copy_(self.s_mask._gs_n_sel)
-        self.s_cam = cam._replace(world_view_transform=self.s_view, full_proj_transform=self.s_proj,
-                                  camera_center=self.s_center)
         self.coef = torch.zeros((11,), dtype=torch.float32, device=dev)
         self.coef_host = torch.zeros((11,), dtype=torch.float32).pin_memory()
-        # binning capacity: the largest view seen so far with head-room
-        self.capacity = int(self.fixed_capacity) if self.fixed_capacity is not None else \
-            int(max(be._capacity_hint, 4096) * self.capacity_margin)
         be._pinned_by_device.setdefault((dev.index, "static"), torch.zeros((16,), dtype=torch.int32).pin_memory())
         # the replay's identity: uploaded before every replay, copied out with the status words by the captured
         # gs_forward_status (GsScratch.step_tag) - the host polls the pinned block for it instead of draining the stream
@@ -1322,91 +1278,122 @@ class GraphedStep:
         self.tag_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self._tag = 0
         self._tag_event = None
-        saved = (tr.cameras, tr.gts, tr.masks)
-
-        def one_step():
-            be.static_capacity = self.capacity
-            be.static_step_tag = self.s_tag
-            be.depth_limit_request = "graph" if tr.depth_limit else None
-            tr.cameras, tr.gts, tr.masks = [self.s_cam], [self.s_gt], (None if self.s_mask is None else [self.s_mask])
-            tr._coef_dev = self.coef
-            tr._camera_key_override = ("graph", id(self))
-            try:
-                return tr._step_camera(0, True, ())
-            finally:
-                be.static_capacity = None
-                be.static_step_tag = None
-                tr.cameras, tr.gts, tr.masks = saved
-                tr._coef_dev = None
-                tr._camera_key_override = None
-
         self._coef_event = None
-        crit = tr.criterion
+        crit = self.tr.criterion
         if getattr(crit, "dwt_running_mean", None) is None and hasattr(crit, "dwt_running_mean"):
             crit.dwt_running_mean = torch.ones((1,), dtype=torch.float32, device=dev)
-        self.s_rm_backup = None if getattr(crit, "dwt_running_mean", None) is None else crit.dwt_running_mean.clone()
-        # warm-up on a side stream (allocator and library state settle), then capture; every one of these runs is a
-        # real train step of camera `ci`: counters and parameters advance as in eager mode
+
+    def _one_step(self, ci):
+        """One step of camera `ci` in the capture-safe form (fixed capacity, no host wait, constants from `coef`)."""
+        tr, be = self.tr, self._backend()
+        be.static_capacity = self.capacity
+        be.static_step_tag = self.s_tag
+        be.depth_limit_request = "graph" if tr.depth_limit else None
+        tr._coef_dev = self.coef
+        try:
+            return tr._step_camera(ci, True, ())
+        finally:
+            be.static_capacity = None
+            be.static_step_tag = None
+            be.depth_limit_request = None
+            tr._coef_dev = None
+
+    def _capture(self, ci):
+        import gc
+        tr, be = self.tr, self._backend()
+        m = tr.model
+        dev = m.flat.device
+        if self.coef is None:
+            self._shared_init(dev)
+        first = not self.graphs
+        if first or self.capacity is None:
+            # binning capacity: the largest view seen so far with head-room (one number for every camera's graph)
+            self.capacity = int(self.fixed_capacity) if self.fixed_capacity is not None else \
+                int(max(be._capacity_hint, 4096) * self.capacity_margin)
+        crit = tr.criterion
         opt = m.optimizer
         counters = (opt.t, dict(opt.seg_steps))
-        rm0 = None if self.s_rm_backup is None else crit.dwt_running_mean.clone()
+        rm0 = None if getattr(crit, "dwt_running_mean", None) is None else crit.dwt_running_mean.clone()
+        # warm-up on a side stream, then capture; every one of these runs is a real train step of camera `ci`: counters
+        # and parameters advance as in eager mode.  The first capture settles allocator and library state; a later camera
+        # takes one un-captured step, which creates what a step creates lazily per camera (the backend's entry, the
+        # criterion's accumulator - nothing may come from host memory inside a capture) and gives the capture a tile-order
+        # hint to bake in.
+        n_warm = max(1, self.warmup) if first else 1
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(self.warmup):
-                self._load(ci)
+            for _ in range(n_warm):
                 self._coef_for_next()  # (_step_camera's fused_request advances the counters itself)
-                one_step()
+                self._one_step(ci)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         fits = self._view_ok(be)
+        if fits:   # the warm-up steps happened: what a failed first replay has to put back is the state after them
+            counters = (opt.t, dict(opt.seg_steps))
+            rm0 = None if rm0 is None else crit.dwt_running_mean.clone()
         if fits:
-            # A cyclic-garbage sweep INSIDE the capture may free tensors of an earlier capture's private pool (autograd
-            # contexts are cycles) - a device free while the stream is capturing aborts the process.  So: the old graph goes
+            # A cyclic-garbage sweep INSIDE the capture may free tensors of an earlier capture's pool (autograd contexts are
+            # cycles) - a device free while the stream is capturing aborts the process.  So: this camera's old graph goes
             # first, garbage is collected now, and the collector stays off until the capture has ended.
-            import gc
-            self.graph = None
+            self.graphs.pop(ci, None)
             gc.collect()
             torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            self._load(ci)
+            graph = torch.cuda.CUDAGraph()
             self._coef_for_next()
             gc_was_on = gc.isenabled()
             gc.disable()
             try:
-                with torch.cuda.graph(self.graph):
-                    self.s_loss = one_step()
+                with torch.cuda.graph(graph, pool=self.pool):
+                    loss = self._one_step(ci)
             finally:
                 if gc_was_on:
                     gc.enable()
-            self.s_rm_before = (tr.last.get("parts") or {}).get("running_mean_before")  # (a view of the captured output)
+            if self.pool is None:
+                self.pool = graph.pool()
+            rm_before = (tr.last.get("parts") or {}).get("running_mean_before")  # (a view of the captured output)
             # the capture itself launched nothing: replay once so that this call ends with a step
             self._upload_tag()
-            self.graph.replay()
+            graph.replay()
             torch.cuda.synchronize(dev)
             fits = self._view_ok(be)
         if not fits:
             # this view needs more instances than the capacity (or its depth limits were stale): none of the steps above
             # changed anything on the device (gs_backward_step skips on either flag).  Put the counters back and take ONE
             # eager step instead.
-            self.cam_limits.pop(ci, None)
+            self._invalidate(ci, be.last_status())
             opt.t, opt.seg_steps = counters[0], dict(counters[1])
             if rm0 is not None:
                 crit.dwt_running_mean.copy_(rm0)
-            self.graph, self.key = None, None
             self.eager_steps += 1
-            return tr._step_camera(ci, True, ())
-        self.key = self._key(cam)
+            self.s_loss = tr._step_camera(ci, True, ())
+            return self.s_loss
+        self.graphs[ci] = dict(graph=graph, key=self._key(ci), loss=loss, rm_before=rm_before)
         self.captures += 1
-        self._save_order(ci)
-        return self.s_loss
+        self.s_loss = loss
+        return loss
+
+    def _invalidate(self, ci, status):
+        """After a step that did nothing on the device.  Limits that failed: the camera forgets them (its graph stays - the
+        eager step that follows measures new ones into the same buffers).  A view that did not fit the capacity: every
+        graph was captured with that capacity - all go, the next capture sizes it from the backend's grown hint."""
+        num_rendered, overflow, trunc_failed = status
+        be = self._backend()
+        ent = self.camera_entry(ci)
+        if trunc_failed and ent is not None:
+            ent["limit_ok"] = False
+            ent["limit"].fill_(float("inf"))
+            be.depth_limit_stats["failed"] += 1
+        if overflow or num_rendered > self.capacity:
+            self.graphs.clear()
+            self.capacity = None   # (the eager step that follows grows the backend's hint; the next capture reads it)
 
     def _view_ok(self, be):
         num_rendered, overflow, trunc_failed = be.last_status()
         return num_rendered <= self.capacity and not overflow and not trunc_failed
 
     def _coef_for_next(self):
-        """Constants of the step the NEXT launch performs: the launch (eager inside one_step, or a replay) is step t + 1."""
+        """Constants of the step the NEXT launch performs: the launch (eager inside _one_step, or a replay) is step t + 1."""
         opt = self.tr.model.optimizer
         saved_t, saved_seg = opt.t, dict(opt.seg_steps)
         opt.begin_step(())
@@ -1433,8 +1420,8 @@ class GraphedStep:
         the status words the replay's forward copied out.  The host does not drain the stream for it: it polls the pinned
         block for the replay's tag, which arrives when the FORWARD of that replay has finished - the rest of the step is
         still queued behind it, so the GPU never waits for the host.  A failed replay changed nothing on the device
-        (gs_backward_step is a no-op on either flag): counters and the criterion's running mean are put back, the step is
-        taken eagerly and the graph is captured again next time."""
+        (gs_backward_step is a no-op on either flag): counters and the criterion's running mean are put back and the step
+        is taken eagerly."""
         p, self._replay_pending = getattr(self, "_replay_pending", None), None
         if p is None:
             return
@@ -1447,18 +1434,17 @@ class GraphedStep:
                 torch.cuda.current_stream(self.s_tag.device).synchronize()
                 break
         num_rendered, overflow, trunc_failed = int(st[0]), int(st[1]), int(st[2])
-        if num_rendered <= self.capacity and not overflow and not trunc_failed:
+        if num_rendered <= p["capacity"] and not overflow and not trunc_failed:
             return
         ci = p["ci"]
-        self.cam_limits.pop(ci, None)
+        self._invalidate(ci, (num_rendered, overflow, trunc_failed))
         opt = tr.model.optimizer
         opt.t -= 1
         for name in opt.seg_steps:
             opt.seg_steps[name] -= 1
         crit = tr.criterion
-        if self.s_rm_before is not None:  # the criterion's running mean saw the loss of an un-rendered image
-            crit.dwt_running_mean.copy_(self.s_rm_before)
-        self.graph, self.key = None, None
+        if p["rm_before"] is not None:  # the criterion's running mean saw the loss of an un-rendered image
+            crit.dwt_running_mean.copy_(p["rm_before"])
         self.eager_steps += 1
         self.s_loss = tr._step_camera(ci, True, ()).clone()
 
@@ -1467,23 +1453,27 @@ class GraphedStep:
         tr.sync()
         self.settle()
         ci = tr.camera_index(k)
-        cam = tr.cameras[ci]
         be = self._backend()
         if tr.model.exposure is not None or not tr._fused_step_ok(be, True) or be._capacity_hint <= 0:
             # what the capture cannot hold (a torch optimizer for the exposure, N > 1, ...), or no view has been
             # rendered yet to size the binning capacity from
             self.eager_steps += 1
-            return tr._step_camera(ci, True, ())
-        if self.graph is None or self.key != self._key(cam):
+            self.s_loss = tr._step_camera(ci, True, ())
+            return self.s_loss
+        g = self.graphs.get(ci)
+        if g is None or g["key"] != self._key(ci):
             return self._capture(ci)
-        self._load(ci)
         self._coef_for_next()
         self._upload_tag()
-        self.graph.replay()
-        self._save_order(ci)
+        g["graph"].replay()
+        if tr.depth_limit:
+            ent = self.camera_entry(ci)
+            if ent is not None and ent["limit_ok"]:
+                be.depth_limit_stats["used"] += 1
         tr.model.optimizer.begin_step(())
         self.replays += 1
-        self._replay_pending = dict(tag=self._tag, ci=ci)
+        self._replay_pending = dict(tag=self._tag, ci=ci, capacity=self.capacity, rm_before=g["rm_before"])
+        self.s_loss = g["loss"]
         return self.s_loss
 
     def sync(self):

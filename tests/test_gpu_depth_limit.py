@@ -321,17 +321,18 @@ def test_graphed_step_with_stale_limits_falls_back(hip):
     a, b = make(hip), make(hip)
     b.depth_limit = "deferred"
     gs = GraphedStep(b)
-    lb = [float(gs.step(k)) for k in range(9)]          # capture on camera 0, then cameras 1 2 3 0 1 2 3 0
-    assert gs.eager_steps == 0 and sorted(gs.cam_limits) == [0, 1, 2, 3]
-    gs.cam_limits[1].fill_(1e-3)                         # camera 1's limits now cut everything
+    lb = [float(gs.step(k)) for k in range(9)]          # every camera's capture (0: 4 steps; 1 2 3: 2 each), then 0 1 2 3 0
+    assert gs.eager_steps == 0 and gs.captures == 4
+    assert all(gs.camera_entry(c)["limit_ok"] for c in range(4))
+    gs.camera_entry(1)["limit"].fill_(1e-3)              # camera 1's limits now cut everything
     gs.step(9)                                           # -> flagged; the host learns it when it settles the replay
     gs.sync()                                            #    (before the next step, or here): undone, stepped eagerly
     lb.append(float(gs.s_loss))
-    assert gs.eager_steps == 1 and 1 not in gs.cam_limits
-    lb += [float(gs.step(k)) for k in range(10, 14)]     # re-captured; camera 1 re-learns its limits
+    assert gs.eager_steps == 1 and gs.captures == 4      # (camera 1's graph stays: the eager step measured new limits)
+    lb += [float(gs.step(k)) for k in range(10, 14)]     # replays; camera 1 (step 13) on its re-learnt limits
     gs.sync()
-    assert 1 in gs.cam_limits
-    cams = [0, 0, 0, 0] + [k % 4 for k in range(1, 10)] + [2, 2, 2, 2] + [3, 0, 1]
+    assert gs.eager_steps == 1 and gs.captures == 4 and gs.camera_entry(1)["limit_ok"]
+    cams = [0, 0, 0, 0, 1, 1, 2, 2, 3, 3] + [k % 4 for k in range(4, 14)]
     hip.depth_limit_on = False
     la = [float(a._step_camera(c, True, ())) for c in cams]
     hip.depth_limit_on = True
