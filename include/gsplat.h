@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 
 /* error codes (negative = caller error) */
 #define GS_OK 0
@@ -291,11 +291,34 @@ typedef struct GsStepState {
    * (gs_adam_step_gated takes it as its gate). */
   float* grad_out[5];
   float* fail_flag;
+  /* ---- two-phase step (single GPU, GsView.tile_cull != 0) ----
+   * 0: gs_backward_step handles every Gaussian.  2: only the Gaussians that emitted instances in this view - the caller has
+   * already run gs_step_uninstanced on the same state for the others. */
+  int32_t phase;
+  int32_t _pad_phase;
+  void* phase1_done; /* with phase = 2: a hipEvent_t recorded behind gs_step_uninstanced on its stream, or NULL.  gs_backward_step
+                        makes its stream wait for it AFTER the backward blend has been launched - the two then run side by
+                        side - and before the per-Gaussian kernel.  NULL: the caller has ordered the two calls itself. */
 } GsStepState;
 int gs_backward_step(const GsView* view, const GsGaussians* g, const int32_t* radii,
                      const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
                      const float* dL_dinvdepth, const GsStepState* st, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* The part of gs_backward_step that does not wait for the loss: a Gaussian that emitted no instance in this view
+ * (tiles_touched == 0: off screen, culled, or cut by the depth limits - four fifths of them on depth-limited lists) has
+ * zero gradients whatever the image looks like, so its view statistics and its Adam step (zero gradient: the moments decay,
+ * the parameter moves by the old momentum - torch.optim.Adam does the same) need nothing but the forward's geometry stage.
+ * Call it on a second stream, ordered after gs_forward_render, right before gs_backward_step with st->phase = 2 on the
+ * first: it then runs CONCURRENTLY with stage 1 of the backward, the blend - a pure HBM stream next to a kernel that is
+ * bound by vector issue and leaves HBM idle (next to the criterion's kernels it gains nothing: they slow down by what it
+ * takes, measured).  gs_backward_step steps the Gaussians with instances; its per-Gaussian kernel must be ordered after
+ * this call (st->phase1_done; the two split the float4s of the parameter rows between them).  Like gs_backward_step a no-op on the device when the forward had flagged
+ * overflow or trunc_failed - so it must not start before the forward BLEND has finished.  Same element arithmetic: the
+ * two calls together leave the bits gs_backward_step (phase 0) leaves.  GS_E_UNSUPPORTED with tile_cull = 0 (every visible
+ * Gaussian has instances there) and in the data-parallel form. */
+int gs_step_uninstanced(const GsView* view, const GsGaussians* g, const int32_t* radii,
+                        const GsScratch* scratch, const GsStepState* st, void* stream);
 
 /* Stage 2 of gs_backward on its own (parity export): the per-Gaussian chain rule from given sums of the blend
  * backward.  rows [P,16] (device): mean2D.x, mean2D.y, conic.xx, conic.xy, conic.yy, opacity, r, g, b, depth slot,

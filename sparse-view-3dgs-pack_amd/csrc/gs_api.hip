@@ -374,6 +374,8 @@ static int step_args(const GsGaussians* g, const GsStepState* st, StepArgs& sa) 
   if (g->M != 16 || g->colors_precomp || g->cov3D_precomp || !g->scales || !g->rotations || g->extra_channel)
     return GS_E_UNSUPPORTED;
   sa.st = *st;
+  sa.phase = 0;
+  sa.phase1_workgroups = 0;
   static const int row_of_lr[6] = {0, 1, 1, 2, 3, 4};
   for (int k = 0; k < 5; k++) {
     if (st->step[k] < 0) return GS_E_SHAPE;
@@ -434,6 +436,16 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   if (step) {
     GS_PROF(ST_BWD_STEP, s);
     sa.hdr = gv.hdr;
+    if (step->phase == 2) {  // the Gaussians without instances are stepped by gs_step_uninstanced (maybe still running)
+      if (!v->tile_cull || step->grad_out[0]) return GS_E_UNSUPPORTED;
+      sa.phase = 2;
+      if (step->phase1_done) {
+        const hipError_t e = hipStreamWaitEvent(s, (hipEvent_t)step->phase1_done, 0);
+        if (e != hipSuccess) return (int)e;  // (positive: a HIP error code, as after a failed launch)
+      }
+    } else if (step->phase != 0) {
+      return GS_E_SHAPE;
+    }
     launch_preprocess_bwd_step(a, sa, s);
   } else {
     GS_PROF(ST_PREPROCESS_BWD, s);
@@ -450,6 +462,38 @@ int gs_backward_step(const GsView* v, const GsGaussians* g, const int32_t* radii
   const GsGrads none = {};
   return backward_impl(v, g, radii, sc, num_rendered, dL_dcolor, dL_dinvdepth, nullptr, 0, &none, workspace, workspace_bytes,
                        stream, st);
+}
+
+int gs_step_uninstanced(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, const GsStepState* st,
+                        void* stream) {
+  int rc = check_args(v, g);
+  if (rc) return rc;
+  if (!sc || !st) return GS_E_NULL;
+  if (!v->tile_cull || st->grad_out[0]) return GS_E_UNSUPPORTED;
+  const int P = g->P;
+  if (P == 0) return GS_OK;
+  StepArgs sa;
+  rc = step_args(g, st, sa);
+  if (rc) return rc;
+  if (!radii || !sc->geom) return GS_E_NULL;
+  if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
+  hipStream_t s = (hipStream_t)stream;
+  GeomView gv = geom_view(sc->geom, (size_t)P);
+  const GsGrads none = {};
+  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, 0, nullptr, &none);
+  a.skip_uninstanced = 1;
+  sa.hdr = gv.hdr;
+  sa.phase = 1;
+  {
+    static const int wgs_env = [] { const char* e = getenv("GS_PHASE1_WORKGROUPS"); return e ? atoi(e) : 0; }();
+    sa.phase1_workgroups = wgs_env;
+  }
+  {
+    GS_PROF(ST_STEP_UNINST, s);
+    launch_preprocess_bwd_step(a, sa, s);
+  }
+  GS_LAUNCH_CHECK(s, v->debug);
+  return GS_OK;
 }
 
 int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, const float* rows,

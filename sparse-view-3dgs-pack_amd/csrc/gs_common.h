@@ -299,5 +299,7 @@ struct StepArgs {
   float lr_bc1[6];        // lr / (1 - beta1^t) per learning-rate class   (st.coef_dev, when given, replaces both arrays)
   float inv_sqrt_bc2[5];  // 1 / sqrt(1 - beta2^t) per row
   const GeomHeader* hdr;  // overflow (binning capacity exceeded, nothing blended) or trunc_failed set -> the step is a no-op
+  int phase;              // 0 every Gaussian | 1 only those without instances | 2 only those with (gs_step_uninstanced)
+  int phase1_workgroups;  // grid of the throttled phase-1 kernel (0 = default)
 };
 int launch_preprocess_bwd_step(const PreprocessBwdArgs& a, const StepArgs& sa, hipStream_t s);

@@ -117,10 +117,31 @@ GS_DEV void adam_update(float& p, float g, float& m, float& v, float lr_bc1, flo
 // iteration when the piece starts on 16 bytes (always when P is a multiple of 4; after a densification a row's segment
 // of the flat buffer may start anywhere), else element-wise.  LR_SPLIT > 0: elements with (index % 48) < LR_SPLIT take
 // lr_a, the others lr_b (the SH block: 3 DC floats at feature_lr, 45 at feature_lr / 20).
-template <int N, int LR_SPLIT, typename G>
+#ifndef GS_PHASE1_UNROLL
+#define GS_PHASE1_UNROLL 3
+#endif
+#ifndef GS_PHASE1_NT
+#define GS_PHASE1_NT 1
+#endif
+typedef float gs_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const gs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const gs_f4v*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float* p, float4 v) {
+  gs_f4v w;
+  w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<gs_f4v*>(p));
+}
+// MODE (the two-phase step, StepArgs.phase; sel[r] = "Gaussian r of the workgroup's piece has NO instances"): the two
+// phases split the float4s of a piece between them - 1: only float4s ALL of whose elements belong to Gaussians without
+// instances (zero gradient); 2: the float4s with at least one element of a Gaussian WITH instances, every element of
+// them (the gradient image holds zeros for the others) - so every float4 is read and written once per step, as in
+// MODE 0.  (Unaligned pieces go element by element: 1 takes the flagged elements, 2 the others.)
+template <int N, int LR_SPLIT, int MODE, typename G>
 __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int first,
                                            int cnt, const G& grad, float lr_a, float lr_b, float isb, float b1, float b2,
-                                           float eps) {
+                                           float eps, const unsigned char* sel = nullptr) {
   float* pf = p + (size_t)first * N;
   float* mf = m + (size_t)first * N;
   float* vf = v + (size_t)first * N;
@@ -129,22 +150,35 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
   if (vec) {
     // U float4 triples in flight per thread: the loads of a group are all issued before the first is consumed (a plain
     // loop waits out the HBM latency once per float4: 12 round trips per thread for the SH block)
-    constexpr int U = 3;
+    constexpr int U = MODE == 1 ? GS_PHASE1_UNROLL : 3;  // (phase 1 shares the SIMDs with the backward blend: few registers)
     for (int j0 = 4 * threadIdx.x; j0 < nfl; j0 += 4 * GS_BLOCK * U) {
       float4 p4[U], m4[U], v4[U];
+      unsigned char es[U][4] = {};
+      bool any[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int j = j0 + u * 4 * GS_BLOCK;
-        if (j < nfl) {
-          p4[u] = *reinterpret_cast<const float4*>(pf + j);
-          m4[u] = *reinterpret_cast<const float4*>(mf + j);
-          v4[u] = *reinterpret_cast<const float4*>(vf + j);
+        any[u] = j < nfl;
+        if (MODE != 0 && j < nfl) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) es[u][e] = sel[(j + e) / N];
+          const bool all_flagged = (es[u][0] & es[u][1] & es[u][2] & es[u][3]) != 0;
+          any[u] = MODE == 1 ? all_flagged : !all_flagged;
+        }
+        if (any[u]) {
+          if (MODE == 1 && GS_PHASE1_NT) {  // phase 1 streams next to the backward blend: keep its lines out of that kernel's L2
+            p4[u] = nt_load4(pf + j); m4[u] = nt_load4(mf + j); v4[u] = nt_load4(vf + j);
+          } else {
+            p4[u] = *reinterpret_cast<const float4*>(pf + j);
+            m4[u] = *reinterpret_cast<const float4*>(mf + j);
+            v4[u] = *reinterpret_cast<const float4*>(vf + j);
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int j = j0 + u * 4 * GS_BLOCK;
-        if (j < nfl) {
+        if (any[u]) {
           float* pe = reinterpret_cast<float*>(&p4[u]);
           float* me = reinterpret_cast<float*>(&m4[u]);
           float* ve = reinterpret_cast<float*>(&v4[u]);
@@ -152,15 +186,23 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
           for (int e = 0; e < 4; e++) {
             const float lr = (LR_SPLIT > 0 && ((j + e) % 48) >= LR_SPLIT) ? lr_b : lr_a;
             adam_update(pe[e], grad(j + e), me[e], ve[e], lr, isb, b1, b2, eps);
+            // phase 1 runs next to the backward blend, which needs the registers: one element's IEEE sqrt / division
+            // temporaries at a time instead of four interleaved (the kernel waits on HBM, not on issue)
+            if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
           }
-          *reinterpret_cast<float4*>(pf + j) = p4[u];
-          *reinterpret_cast<float4*>(mf + j) = m4[u];
-          *reinterpret_cast<float4*>(vf + j) = v4[u];
+          if (MODE == 1 && GS_PHASE1_NT) {
+            nt_store4(pf + j, p4[u]); nt_store4(mf + j, m4[u]); nt_store4(vf + j, v4[u]);
+          } else {
+            *reinterpret_cast<float4*>(pf + j) = p4[u];
+            *reinterpret_cast<float4*>(mf + j) = m4[u];
+            *reinterpret_cast<float4*>(vf + j) = v4[u];
+          }
         }
       }
     }
   } else {
     for (int j = threadIdx.x; j < nfl; j += GS_BLOCK) {
+      if (MODE != 0 && (sel[j / N] != 0) != (MODE == 1)) continue;
       float pe = pf[j], me = mf[j], ve = vf[j];
       const float lr = (LR_SPLIT > 0 && (j % 48) >= LR_SPLIT) ? lr_b : lr_a;
       adam_update(pe, grad(j), me, ve, lr, isb, b1, b2, eps);
@@ -191,9 +233,16 @@ __device__ __forceinline__ void grad_block(float* __restrict__ out, int first, i
 #define SG_ROT (7 * GS_BLOCK)
 #define SG_TOTAL (11 * GS_BLOCK)
 
+// PHASE (StepArgs.phase; the two-phase step, gs_step_uninstanced): 0 = every Gaussian.  2 = the Gaussians WITH instances
+// (statistics; Adam on every float4 that holds one of their elements) - the others are stepped by step_uninstanced_kernel
+// below (phase 1), which needs nothing but the forward's geometry stage and runs on a side stream next to the backward
+// blend: a pure HBM stream (parameters and moments of four fifths of the Gaussians with depth-limited lists) beside a
+// kernel that is bound by vector issue.  Same arithmetic per element in every phase.
+template <int PHASE>
 __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(PreprocessBwdArgs a, StepArgs sa) {
   __shared__ float s_sh[GS_BLOCK * SH_LDS_ROW];
   __shared__ float s_g[SG_TOTAL];
+  __shared__ unsigned char s_sel[PHASE == 0 ? 1 : GS_BLOCK];
   const GsStepState& st = sa.st;
   const bool grads_out = st.grad_out[0] != nullptr;  // data-parallel form: gradients out, no Adam (gsplat.h)
   // the forward ran out of binning capacity (possible only when the caller did not re-run it: a replayed graph): the
@@ -224,18 +273,21 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   const int radius = a.radii[idx];
   const bool visible = radius > 0;
   const float b1 = st.beta1, b2 = st.beta2, eps = st.eps;
+  // a Gaussian that emitted no instance (culled spans, depth limits) has all-zero blend sums, hence zero gradients: it
+  // still counts as seen (statistics) and still takes its Adam step, but its records, sums and SH row are not read
+  const bool instanced = !(a.skip_uninstanced && a.tiles_touched[idx] == 0);
+  const bool mine = PHASE == 0 || (in_range && instanced);  // this launch does this Gaussian's statistics
+  if (PHASE != 0) s_sel[tid] = (in_range && !instanced) ? 1 : 0;  // (adam_block's flag: a Gaussian WITHOUT instances)
+  const bool active = visible && instanced;
 
   GeomBack gb = {};
   ShSink dsh{s_sh + tid * SH_LDS_ROW, true};
 #pragma unroll
   for (int k = 0; k < SH_LDS_ROW; k++) dsh.p[k] = 0.f;
-  // a Gaussian that emitted no instance (culled spans, depth limits) has all-zero blend sums, hence zero gradients: it
-  // still counts as seen (statistics) and still takes its Adam step, but its records, sums and SH row are not read
-  const bool active = visible && !(a.skip_uninstanced && a.tiles_touched[idx] == 0);
   if (active) geometry_backward(a, idx, gb);
 
   // ---- view statistics (train.py:266-268, gaussian_model.py:471-473)
-  if (in_range && st.max_radii2D) {
+  if (in_range && st.max_radii2D && mine) {
     const float gnorm = sqrtf(gb.dmean2D_x * gb.dmean2D_x + gb.dmean2D_y * gb.dmean2D_y);
     if (grads_out) {  // this view's increments, assigned (the caller sums them over ranks)
       if (visible) st.max_radii2D[idx] = fmaxf(st.max_radii2D[idx], (float)radius);
@@ -249,37 +301,45 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   }
   // ---- activation backward of this Gaussian's rows into the LDS gradient image
   {
-    // opacity = sigmoid(raw): grad * s * (1 - s)
-    const float sg = 1.0f / (1.0f + expf(-st.opacity[idx]));
-    s_g[SG_OPAC + tid] = gb.dop * (1.0f - sg) * sg;
-    // scaling = exp(raw): grad * result
-    s_g[SG_SCALE + 3 * tid] = gb.dscale.x * expf(st.scaling[3 * (size_t)idx]);
-    s_g[SG_SCALE + 3 * tid + 1] = gb.dscale.y * expf(st.scaling[3 * (size_t)idx + 1]);
-    s_g[SG_SCALE + 3 * tid + 2] = gb.dscale.z * expf(st.scaling[3 * (size_t)idx + 2]);
-    // rotation = q / max(|q|, 1e-12): dq = (g - v (v . g)) / |q|
-    const float* qr = st.rotation + 4 * (size_t)idx;
-    const float4 q = make_float4(qr[0], qr[1], qr[2], qr[3]);
-    const float norm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    float g[4];
-    if (norm > 1e-12f) {
-      const float inv = 1.0f / norm;
-      const float vx = q.x * inv, vy = q.y * inv, vz = q.z * inv, vw = q.w * inv;
-      const float dot = vx * gb.dq[0] + vy * gb.dq[1] + vz * gb.dq[2] + vw * gb.dq[3];
-      g[0] = (gb.dq[0] - vx * dot) * inv;
-      g[1] = (gb.dq[1] - vy * dot) * inv;
-      g[2] = (gb.dq[2] - vz * dot) * inv;
-      g[3] = (gb.dq[3] - vw * dot) * inv;
-    } else {
-      g[0] = gb.dq[0] / 1e-12f; g[1] = gb.dq[1] / 1e-12f; g[2] = gb.dq[2] / 1e-12f; g[3] = gb.dq[3] / 1e-12f;
-    }
+    if (PHASE == 2 && !mine) {  // (stepped by phase 1: zero gradient, no parameter read)
 #pragma unroll
-    for (int k = 0; k < 4; k++) s_g[SG_ROT + 4 * tid + k] = g[k];
+      for (int k = 0; k < 3; k++) s_g[SG_XYZ + 3 * tid + k] = s_g[SG_SCALE + 3 * tid + k] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) s_g[SG_ROT + 4 * tid + k] = 0.f;
+      s_g[SG_OPAC + tid] = 0.f;
+    } else {
+      // opacity = sigmoid(raw): grad * s * (1 - s)
+      const float sg = 1.0f / (1.0f + expf(-st.opacity[idx]));
+      s_g[SG_OPAC + tid] = gb.dop * (1.0f - sg) * sg;
+      // scaling = exp(raw): grad * result
+      s_g[SG_SCALE + 3 * tid] = gb.dscale.x * expf(st.scaling[3 * (size_t)idx]);
+      s_g[SG_SCALE + 3 * tid + 1] = gb.dscale.y * expf(st.scaling[3 * (size_t)idx + 1]);
+      s_g[SG_SCALE + 3 * tid + 2] = gb.dscale.z * expf(st.scaling[3 * (size_t)idx + 2]);
+      // rotation = q / max(|q|, 1e-12): dq = (g - v (v . g)) / |q|
+      const float* qr = st.rotation + 4 * (size_t)idx;
+      const float4 q = make_float4(qr[0], qr[1], qr[2], qr[3]);
+      const float norm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+      float g[4];
+      if (norm > 1e-12f) {
+        const float inv = 1.0f / norm;
+        const float vx = q.x * inv, vy = q.y * inv, vz = q.z * inv, vw = q.w * inv;
+        const float dot = vx * gb.dq[0] + vy * gb.dq[1] + vz * gb.dq[2] + vw * gb.dq[3];
+        g[0] = (gb.dq[0] - vx * dot) * inv;
+        g[1] = (gb.dq[1] - vy * dot) * inv;
+        g[2] = (gb.dq[2] - vz * dot) * inv;
+        g[3] = (gb.dq[3] - vw * dot) * inv;
+      } else {
+        g[0] = gb.dq[0] / 1e-12f; g[1] = gb.dq[1] / 1e-12f; g[2] = gb.dq[2] / 1e-12f; g[3] = gb.dq[3] / 1e-12f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) s_g[SG_ROT + 4 * tid + k] = g[k];
+      // ---- SH half: basis values and colour gradient to the LDS row; the view-direction part completes dL_dmean
+      if (active) gb.dmean = gb.dmean + sh_backward_row(a, idx, gb.dcolor, dsh);
+      s_g[SG_XYZ + 3 * tid] = gb.dmean.x;
+      s_g[SG_XYZ + 3 * tid + 1] = gb.dmean.y;
+      s_g[SG_XYZ + 3 * tid + 2] = gb.dmean.z;
+    }
   }
-  // ---- SH half: basis values and colour gradient to the LDS row; the view-direction part completes dL_dmean
-  if (active) gb.dmean = gb.dmean + sh_backward_row(a, idx, gb.dcolor, dsh);
-  s_g[SG_XYZ + 3 * tid] = gb.dmean.x;
-  s_g[SG_XYZ + 3 * tid + 1] = gb.dmean.y;
-  s_g[SG_XYZ + 3 * tid + 2] = gb.dmean.z;
   __syncthreads();  // every thread of the workgroup has read its parameters: the rows may now change
 
   // ---- Adam over the workgroup's contiguous pieces of the five row arrays: coalesced float4 streams of p, m, v
@@ -299,27 +359,87 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   };
   if (grads_out) {
     // the workgroup's contiguous piece of each gradient row array, straight from the LDS image
-    grad_block<3>(st.grad_out[0], first, cnt, Lds{s_g + SG_XYZ});
-    grad_block<1>(st.grad_out[2], first, cnt, Lds{s_g + SG_OPAC});
-    grad_block<3>(st.grad_out[3], first, cnt, Lds{s_g + SG_SCALE});
-    grad_block<4>(st.grad_out[4], first, cnt, Lds{s_g + SG_ROT});
-    grad_block<48>(st.grad_out[1], first, cnt, ShGrad{s_sh});
+    if (PHASE == 0) {
+      grad_block<3>(st.grad_out[0], first, cnt, Lds{s_g + SG_XYZ});
+      grad_block<1>(st.grad_out[2], first, cnt, Lds{s_g + SG_OPAC});
+      grad_block<3>(st.grad_out[3], first, cnt, Lds{s_g + SG_SCALE});
+      grad_block<4>(st.grad_out[4], first, cnt, Lds{s_g + SG_ROT});
+      grad_block<48>(st.grad_out[1], first, cnt, ShGrad{s_sh});
+    }
     return;
   }
+  constexpr int SEL = PHASE;
   if (st.step[0] > 0)
-    adam_block<3, 0>(st.xyz, st.m[0], st.v[0], first, cnt, Lds{s_g + SG_XYZ}, sa.lr_bc1[0], 0.f, sa.inv_sqrt_bc2[0], b1, b2, eps);
+    adam_block<3, 0, SEL>(st.xyz, st.m[0], st.v[0], first, cnt, Lds{s_g + SG_XYZ}, sa.lr_bc1[0], 0.f, sa.inv_sqrt_bc2[0], b1, b2, eps, s_sel);
   if (st.step[2] > 0)
-    adam_block<1, 0>(st.opacity, st.m[2], st.v[2], first, cnt, Lds{s_g + SG_OPAC}, sa.lr_bc1[3], 0.f, sa.inv_sqrt_bc2[2], b1, b2, eps);
+    adam_block<1, 0, SEL>(st.opacity, st.m[2], st.v[2], first, cnt, Lds{s_g + SG_OPAC}, sa.lr_bc1[3], 0.f, sa.inv_sqrt_bc2[2], b1, b2, eps, s_sel);
   if (st.step[3] > 0)
-    adam_block<3, 0>(st.scaling, st.m[3], st.v[3], first, cnt, Lds{s_g + SG_SCALE}, sa.lr_bc1[4], 0.f, sa.inv_sqrt_bc2[3], b1, b2, eps);
+    adam_block<3, 0, SEL>(st.scaling, st.m[3], st.v[3], first, cnt, Lds{s_g + SG_SCALE}, sa.lr_bc1[4], 0.f, sa.inv_sqrt_bc2[3], b1, b2, eps, s_sel);
   if (st.step[4] > 0)
-    adam_block<4, 0>(st.rotation, st.m[4], st.v[4], first, cnt, Lds{s_g + SG_ROT}, sa.lr_bc1[5], 0.f, sa.inv_sqrt_bc2[4], b1, b2, eps);
+    adam_block<4, 0, SEL>(st.rotation, st.m[4], st.v[4], first, cnt, Lds{s_g + SG_ROT}, sa.lr_bc1[5], 0.f, sa.inv_sqrt_bc2[4], b1, b2, eps, s_sel);
   if (st.step[1] > 0)
-    adam_block<48, 3>(st.features, st.m[1], st.v[1], first, cnt, ShGrad{s_sh}, sa.lr_bc1[1], sa.lr_bc1[2], sa.inv_sqrt_bc2[1], b1,
-                      b2, eps);
+    adam_block<48, 3, SEL>(st.features, st.m[1], st.v[1], first, cnt, ShGrad{s_sh}, sa.lr_bc1[1], sa.lr_bc1[2], sa.inv_sqrt_bc2[1], b1,
+                           b2, eps, s_sel);
+}
+
+// Phase 1 as its own, THROTTLED kernel: it runs on a side stream next to the criterion and the backward blend, which need the
+// wave slots - launched as one workgroup per Gaussian block it would take every slot first and the other stream's kernels
+// would queue behind it (measured: no overlap at all, the step got slower).  A few workgroups per CU walking the blocks keep
+// enough loads in flight for the HBM stream (3 float4 triples per thread) and leave the machine to the others.
+__global__ void __launch_bounds__(GS_BLOCK, 4) step_uninstanced_kernel(PreprocessBwdArgs a, StepArgs sa, int nblocks) {
+  __shared__ unsigned char s_sel[GS_BLOCK];
+  const GsStepState& st = sa.st;
+  if ((sa.hdr->overflow | sa.hdr->trunc_failed) != 0u) return;  // (as preprocess_bwd_step_kernel)
+  if (st.coef_dev) {  // (wave-uniform values: kept in scalar registers - this kernel shares its SIMDs with the backward blend)
+#pragma unroll
+    for (int k = 0; k < 6; k++) sa.lr_bc1[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st.coef_dev[k])));
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+      sa.inv_sqrt_bc2[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st.coef_dev[6 + k])));
+  }
+  const float b1 = st.beta1, b2 = st.beta2, eps = st.eps;
+  const int tid = threadIdx.x;
+  struct Zero {
+    __device__ __forceinline__ float operator()(int) const { return 0.f; }
+  };
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int idx = blk * GS_BLOCK + tid;
+    const bool in_range = idx < a.P;
+    const bool mine = in_range && a.tiles_touched[idx] == 0;
+    s_sel[tid] = mine ? 1 : 0;
+    if (mine && st.max_radii2D) {  // seen, with a zero gradient (train.py:266-268)
+      const int radius = a.radii[idx];
+      if (radius > 0) {
+        st.max_radii2D[idx] = fmaxf(st.max_radii2D[idx], (float)radius);
+        st.denom[idx] += 1.0f;   // (xyz_gradient_accum += 0)
+      }
+    }
+    __syncthreads();
+    const int first = blk * GS_BLOCK;
+    const int cnt = min(GS_BLOCK, a.P - first);
+    if (st.step[0] > 0)
+      adam_block<3, 0, 1>(st.xyz, st.m[0], st.v[0], first, cnt, Zero{}, sa.lr_bc1[0], 0.f, sa.inv_sqrt_bc2[0], b1, b2, eps, s_sel);
+    if (st.step[2] > 0)
+      adam_block<1, 0, 1>(st.opacity, st.m[2], st.v[2], first, cnt, Zero{}, sa.lr_bc1[3], 0.f, sa.inv_sqrt_bc2[2], b1, b2, eps, s_sel);
+    if (st.step[3] > 0)
+      adam_block<3, 0, 1>(st.scaling, st.m[3], st.v[3], first, cnt, Zero{}, sa.lr_bc1[4], 0.f, sa.inv_sqrt_bc2[3], b1, b2, eps, s_sel);
+    if (st.step[4] > 0)
+      adam_block<4, 0, 1>(st.rotation, st.m[4], st.v[4], first, cnt, Zero{}, sa.lr_bc1[5], 0.f, sa.inv_sqrt_bc2[4], b1, b2, eps, s_sel);
+    if (st.step[1] > 0)
+      adam_block<48, 3, 1>(st.features, st.m[1], st.v[1], first, cnt, Zero{}, sa.lr_bc1[1], sa.lr_bc1[2], sa.inv_sqrt_bc2[1], b1,
+                           b2, eps, s_sel);
+    __syncthreads();  // (s_sel is rewritten by the next block)
+  }
 }
 
 int launch_preprocess_bwd_step(const PreprocessBwdArgs& a, const StepArgs& sa, hipStream_t s) {
-  hipLaunchKernelGGL(preprocess_bwd_step_kernel, dim3((a.P + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, a, sa);
+  const dim3 grid((a.P + GS_BLOCK - 1) / GS_BLOCK), block(GS_BLOCK);
+  if (sa.phase == 1) {
+    const int nblocks = (int)grid.x;
+    int wgs = sa.phase1_workgroups > 0 ? sa.phase1_workgroups : 512;
+    if (wgs > nblocks) wgs = nblocks;
+    hipLaunchKernelGGL(step_uninstanced_kernel, dim3(wgs), block, 0, s, a, sa, nblocks);
+  } else if (sa.phase == 2) hipLaunchKernelGGL(preprocess_bwd_step_kernel<2>, grid, block, 0, s, a, sa);
+  else hipLaunchKernelGGL(preprocess_bwd_step_kernel<0>, grid, block, 0, s, a, sa);
   return 0;
 }

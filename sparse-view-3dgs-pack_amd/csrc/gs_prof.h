@@ -28,6 +28,7 @@ enum GsStage {
   ST_MODEL,
   ST_BWD_STEP,
   ST_TILE_ORDER,
+  ST_STEP_UNINST,
   ST_COUNT
 };
 

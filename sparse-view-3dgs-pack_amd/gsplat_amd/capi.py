@@ -97,7 +97,8 @@ class GsStepState(C.Structure):
                 ("step", C.c_int32 * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_radii2D", C.c_void_p), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
                 ("coef_dev", C.c_void_p), ("rows_override", C.c_void_p), ("grad_out", C.c_void_p * 5),
-                ("fail_flag", C.c_void_p)]
+                ("fail_flag", C.c_void_p), ("phase", C.c_int32), ("_pad_phase", C.c_int32),
+                ("phase1_done", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -122,6 +123,8 @@ PROTOTYPES = {
     "forward_render_fsgs": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P, _P]),
     "backward_fsgs": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P, _P,
                                 C.POINTER(GsGrads), _P, _SZ, _P]),
+    "step_uninstanced": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch),
+                                   C.POINTER(GsStepState), _P]),
     "backward_step": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P,
                                 C.POINTER(GsStepState), _P, _SZ, _P]),
     "backward_from_rows": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _P, _I32,
@@ -178,7 +181,7 @@ PROTOTYPES = {
 # entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
 # (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
 # reference's two 3-channel passes, so the checker does not need it)
-DEVICE_ONLY = ("backward_step", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "adam_step_gated", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
+DEVICE_ONLY = ("backward_step", "step_uninstanced", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "adam_step_gated", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
                "forward_render_x", "backward_x")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}

@@ -96,6 +96,10 @@ class RasterBackend:
         # by the caller) - run gs_backward_step (backward + activation backward + view statistics + Adam in the same
         # per-Gaussian kernel) instead of gs_backward; the backward then returns no gradients at all
         self.fused_step = None
+        self._side_streams = {}
+        self.two_phase_launches = 0
+        self._uninst_done = None
+        self._uninst_keep = None
         # one-shot, set together with fused_step by the train step: the opacities / scales / rotations of the next forward
         # (and of its gs_backward_step) are the model's RAW rows, activated inside the kernels
         # (GsGaussians.raw_activations): no activation kernel, no activated copies
@@ -326,9 +330,16 @@ class RasterBackend:
         return s
 
     # ------------------------------------------------------------------ forward
+    # The two-phase train step (gs_step_uninstanced): the Adam update of the Gaussians that emitted no instance in this view
+    # is launched on a side stream right before the fused backward and runs NEXT TO the backward blend; the per-Gaussian
+    # kernel of gs_backward_step (phase 2) waits for it.  From TWO_PHASE_MIN_P Gaussians on (below, the extra launch and
+    # the stream hand-offs cost more than the hidden stream saves); GS_TWO_PHASE_STEP=0 switches it off.
+    TWO_PHASE = os.environ.get("GS_TWO_PHASE_STEP", "1") != "0"
+    TWO_PHASE_MIN_P = 100_000
+
     def rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
-                            cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
-                            sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False):
+                             cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
+                             sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False):
         """= RasterizeGaussiansCUDA (rasterize_points.cu:35-124).
 
         Returns (num_rendered, color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
@@ -661,6 +672,21 @@ class RasterBackend:
             if self.keep_workspace:
                 self.last_workspace = ws
             s = self._scratch(geomBuffer, imgBuffer, binningBuffer, self._capacity_for(binningBuffer, P, W, H, R))
+            if self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and view.tile_cull != 0 and not step.grad_out[0]:
+                main = torch.cuda.current_stream(device)
+                side = self._side_streams.get(device.index)
+                if side is None:
+                    side = self._side_streams[device.index] = torch.cuda.Stream(device=device)
+                side.wait_stream(main)   # (the forward has decided overflow / trunc_failed; the criterion is through)
+                with torch.cuda.stream(side):
+                    self.api.call("step_uninstanced", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),
+                                  C.byref(step), C.c_void_p(side.cuda_stream))
+                    done = torch.cuda.Event()
+                    done.record(side)
+                self.two_phase_launches += 1
+                self._uninst_done = done          # (kept alive until the next step replaces it)
+                step.phase = 2                    # gs_backward_step: the Gaussians with instances only ...
+                step.phase1_done = done.cuda_event  # ... its per-Gaussian kernel behind the side launch
             self.api.call("backward_step", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
                           dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(step), _ptr(ws), ws.numel(),
                           self._stream(device))

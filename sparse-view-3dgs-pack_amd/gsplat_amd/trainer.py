@@ -765,6 +765,10 @@ class Trainer:
         self.optimizer_step = optimizer_step
         self.masks = masks  # per-camera ELF patch masks (depend on the ground truth only): cached
         self.last = None
+        # who this trainer is in the backend's per-camera state (keys ("trainer", uid, camera index)): a counter, not id() -
+        # the address of a dead trainer is handed to the next one, which would then inherit its cameras' hints and limits
+        Trainer._uids = getattr(Trainer, "_uids", 0) + 1
+        self.uid = Trainer._uids
         self._stack = []    # train.py:106-111: cameras are drawn without replacement
         self._rng = None
 
@@ -926,7 +930,7 @@ class Trainer:
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
                      clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci,
                      raw_activations=(fused_step or fused_dp) and self.RAW_ACTIVATIONS,
-                     camera_key=getattr(self, "_camera_key_override", None) or ("trainer", id(self), ci))
+                     camera_key=getattr(self, "_camera_key_override", None) or ("trainer", self.uid, ci))
         mask = None if self.masks is None else self.masks[ci]
         verdict = backend.take_deferred() if deferred else None
         rm = None
@@ -1264,7 +1268,7 @@ class GraphedStep:
         """The backend's per-camera state (tile order, depth limits) of camera `ci` - shared with the eager step."""
         tr = self.tr
         cam = tr.cameras[ci]
-        return self._backend().camera_entry(int(cam.image_width), int(cam.image_height), camera_key=("trainer", id(tr), ci),
+        return self._backend().camera_entry(int(cam.image_width), int(cam.image_height), camera_key=("trainer", tr.uid, ci),
                                             device_index=tr.model.flat.device.index)
 
     def _shared_init(self, dev):

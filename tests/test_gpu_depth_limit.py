@@ -296,7 +296,7 @@ def test_deferred_verdict_redoes_a_step_whose_limits_failed(hip):
     la = [float(a.step(k)) for k in range(12)]
     lb = [b.step(k) for k in range(5)]                    # cameras 0 1 2 3 0
     b.sync()
-    hip.camera_entry(480, 320, camera_key=("trainer", id(b), 1))["limit"].fill_(1e-3)  # everything of camera 1 is cut on its next visit
+    hip.camera_entry(480, 320, camera_key=("trainer", b.uid, 1))["limit"].fill_(1e-3)  # everything of camera 1 is cut on its next visit
     failed0 = hip.depth_limit_stats["failed"]
     before = b.model.flat.detach().clone()
     lb.append(b.step(5))                                  # camera 1 with useless limits: nothing may change

@@ -74,7 +74,7 @@ def _worker(rank, world, port, outdir, mode, sharded):
         tr.sync()
         if mode == "sabotage" and rank == 1:
             # rank 1's next camera (index 1): its limits now cut everything
-            hip.camera_entry(480, 320, camera_key=("trainer", id(tr), tr.camera_index(4)))["limit"].fill_(1e-3)
+            hip.camera_entry(480, 320, camera_key=("trainer", tr.uid, tr.camera_index(4)))["limit"].fill_(1e-3)
         before = tr.model.flat.detach().clone()
         t_before = tr.model.optimizer.t
         tr.step(4)

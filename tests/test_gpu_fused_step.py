@@ -12,6 +12,21 @@ from gsplat_amd.trainer import GaussianModelLite, Trainer, camera_to
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def one_binning_path(hip):
+    """The probe tests pin the blend sums to RANDOM rows, and which Gaussians read their row at all (tiles_touched != 0)
+    is a property of the binning path: the region path counts a Gaussian whose bounding box reaches a region, the LSD path
+    one whose ellipse reaches a tile - the same thing on real sums (a Gaussian without instances has zero sums), not on
+    random ones.  `binning = "auto"` picks the path from the sizes of the views rendered before (other tests'), so the
+    two runs of a comparison could end up on different paths: pin it."""
+    old = (hip.binning, hip._capacity_hint, hip._capacity_hint_limited)
+    hip.binning = "region"
+    hip._cam_cache.clear()
+    yield
+    hip.binning, hip._capacity_hint, hip._capacity_hint_limited = old
+    hip._cam_cache.clear()
+
+
 def make(hip, fused, P=30000, W=480, H=320, seed=3, sh_degree=3, skip_rows=None):
     from simple_knn._C import distCUDA2
     dev = torch.device("cuda")
@@ -55,6 +70,38 @@ def test_fused_tail_equals_the_three_kernels_bit_for_bit(hip, skip, deg):
             assert torch.equal(sa[k], sb[k]), (it, k, float((sa[k] - sb[k]).abs().max()))
         assert a.model.optimizer.t == b.model.optimizer.t and a.model.optimizer.seg_steps == b.model.optimizer.seg_steps
     assert float(a.model.denom.max()) == 3.0 and float((sa["flat"] - make(hip, False, sh_degree=deg).model.flat).abs().max()) > 0
+
+
+def test_two_phase_step_leaves_the_bits_of_the_one_launch_step(hip):
+    """gs_step_uninstanced (the Adam step and statistics of the Gaussians WITHOUT instances, on a side stream under the
+    criterion and the backward blend) + gs_backward_step phase 2 (the others) against the one-launch step, on depth-limited
+    lists (most Gaussians are then without instances) and with the blend sums pinned: the very same bits, step after step."""
+    a, b = make(hip, True), make(hip, True)
+    P = a.model.P
+    g = torch.Generator().manual_seed(13)
+    rows = torch.zeros((P, 16))
+    rows[:, :9] = torch.randn((P, 9), generator=g) * 1e-3
+    rows = rows.cuda()
+    a.rows_override = b.rows_override = rows
+    a.depth_limit = b.depth_limit = "deferred"
+    n0 = hip.two_phase_launches
+    try:
+        for k in range(10):
+            hip.TWO_PHASE = False
+            a.step(k)
+            hip.TWO_PHASE, hip.TWO_PHASE_MIN_P = True, 0
+            b.step(k)
+        a.sync()
+        b.sync()
+    finally:
+        del hip.TWO_PHASE, hip.TWO_PHASE_MIN_P     # (back to the class defaults)
+    assert hip.two_phase_launches - n0 >= 10
+    sa, sb = state(a), state(b)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), (k, float((sa[k] - sb[k]).abs().max()))
+    assert a.model.optimizer.t == b.model.optimizer.t == 10
+    # the statistics say that most Gaussians were visible in every view (so: stepped by one phase or the other each time)
+    assert float(sb["denom"].mean()) > 5.0
 
 
 def test_fused_train_step_tracks_the_unfused_one(hip):
