@@ -335,6 +335,7 @@ def main():
     # them around ONE kernel only - the dominant one, found by an untimed pass with every stage instrumented first.
     names = [api.raw("profile_stage_name")(i).decode() for i in range(api.raw("profile_stage_count")())]
     prof, prof_timed, dom_stage = {}, {}, os.environ.get("GS_BENCH_DOMINANT", "")
+    prof_alone = None
 
     def profile_all_stages(nsteps):
         nonlocal k
@@ -435,6 +436,17 @@ def main():
         prof = profile_all_stages(min(args.steps, 10))
         if dom_stage in prof_timed:
             prof[dom_stage] = prof_timed[dom_stage]  # the timed region's own measurement of the dominant kernel
+        # the two-phase step runs the Adam stream of the Gaussians without instances BESIDE the backward blend: both
+        # kernels' durations above are those of the pair.  The same step with every kernel on its own (one launch for the
+        # whole per-Gaussian stage), untimed, for the per-kernel rooflines
+        from gsplat_amd import hip_backend as _hb1
+        if world == 1 and _hb1().two_phase_launches > 0:
+            _hb1().TWO_PHASE = False
+            try:
+                p1 = profile_all_stages(min(args.steps, 6))
+            finally:
+                del _hb1().TWO_PHASE
+            prof_alone = {k_: ms_ / cnt_ for k_, (ms_, cnt_) in p1.items()}
     # the same step on the reference's bounding-square instance lists (GsView.tile_cull = 0: point_list / ranges /
     # num_rendered bit-identical to the reference's), outside the timed region
     ref_lists = None
@@ -553,6 +565,10 @@ def main():
         views = args.steps * world
         value = views / dt
         sb = stage_bytes(P, R_last, N)
+        if prof_alone is not None:
+            # two-phase step: the per-Gaussian stage's bytes are split between two launches (how, depends on the view): no
+            # per-launch byte figure for either; the one-launch form is priced in stages_one_launch_step
+            sb.pop("preprocess_bwd_step", None)
         stages = {}
         if "sort_depth" in prof and "sort" in prof:  # the two halves of the (tile|depth) sort: one SURVEY stage
             prof["sort"] = (prof["sort"][0] + prof.pop("sort_depth")[0], prof["sort"][1])
@@ -588,10 +604,31 @@ def main():
                 if kname in stages and args.config == "c3":  # (the instruction counts are those of the C3 workload)
                     v = valu_roofline(kname, stages[kname]["ms_per_launch"])
                     if v:
+                        if prof_alone and kname in prof_alone:
+                            va = valu_roofline(kname, prof_alone[kname])
+                            v["alone"] = {"ms_per_launch": prof_alone[kname], "achieved": va["achieved"], "frac": va["frac"],
+                                          "what": "the kernel without the Adam stream of the two-phase step beside it "
+                                                  "(GS_TWO_PHASE_STEP=0, untimed pass of this run)"}
                         blend[kname] = v
             if dom in blend:
                 roofline.update(blend[dom])
                 roofline["hbm_view"] = hbm
+            if prof_alone is not None and "step_uninstanced" in stages:
+                # the kernel that runs BESIDE render_bwd in the two-phase step, priced by the bytes the counters saw
+                co = {"kernel": "step_uninstanced", "ms_per_launch": stages["step_uninstanced"]["ms_per_launch"], "bound": "hbm",
+                      "what": "Adam update (zero gradient) + view statistics of the Gaussians without instances: streams "
+                              "their parameters and both moments on a side stream while render_bwd issues vector "
+                              "instructions; gs_backward_step's per-Gaussian kernel waits for both"}
+                try:
+                    t = json.load(open(tf))
+                    if t.get("step_uninstanced"):
+                        co["traffic"] = t["step_uninstanced"]
+                        co["achieved"] = t["step_uninstanced"] / 1e9 / (co["ms_per_launch"] / 1e3)
+                        co["peak"], co["unit"] = HBM_PEAK_GBS, "GB/s"
+                        co["frac"] = co["achieved"] / HBM_PEAK_GBS
+                except Exception:
+                    pass
+                roofline["co_running"] = co
             roofline["blend_kernels_valu"] = blend or None
         out = {
             "metric": "train-step views/s (fwd+bwd) @1M Gaussians 1080p" if args.config == "c3"
@@ -628,6 +665,16 @@ def main():
                               "init-like, sh_degree 0": other.get("init_like", {}).get("ms_per_step"),
                               "unsaturated background": other.get("ball_in_shell", {}).get("ms_per_step")},
             "stages": stages,
+            "stages_one_launch_step": None if prof_alone is None else {
+                "ms_per_launch": prof_alone,
+                "preprocess_bwd_step_GBps": (None if "preprocess_bwd_step" not in prof_alone else
+                                             stage_bytes(P, R_last, N)["preprocess_bwd_step"] / 1e9 /
+                                             (prof_alone["preprocess_bwd_step"] / 1e3)),
+                "what": "the same step with the per-Gaussian stage as ONE launch after the blend (GS_TWO_PHASE_STEP=0): in the "
+                        "timed step `step_uninstanced` (the Adam update of the Gaussians without instances, an HBM stream) "
+                        "runs on a side stream beside `render_bwd` (bound by vector issue) - both are slower than alone, "
+                        "the pair is faster than one after the other - and `preprocess_bwd_step` only steps the Gaussians "
+                        "with instances"},
             "stages_note": ("HIP events around every kernel group in an untimed EAGER pass of the same step right after the timed "
                             "region (each event pair drains the pipeline for ~10 us); the timed region replays the step "
                             "from a hipGraph (%d replays, %d eager fall-backs, %d captures), so no event sits inside it; "

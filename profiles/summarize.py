@@ -21,7 +21,7 @@ OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs
         "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
         "patch_dwt_kernel", "lgdwt_combine_kernel", "act_fwd_kernel", "act_bwd_kernel", "densify_stats_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel", "preprocess_bwd_step_kernel",
         "tile_order_kernel", "zero_rows_kernel", "stop_depth_bounds_kernel", "region_bin_kernel", "region_prepare_kernel",
-        "status_tag_kernel", "rs_small_sort_kernel")
+        "status_tag_kernel", "rs_small_sort_kernel", "step_uninstanced_kernel")
 
 
 def short(name):
@@ -45,9 +45,26 @@ trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
 tr = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(tr) if "render_bwd_wave_kernel" in r["Kernel_Name"] or "render_bwd_kernel" in r["Kernel_Name"]]
 a, b = idx[-3], idx[-2]
+# the bench ends with a few steps in its one-launch form (GS_TWO_PHASE_STEP=0, for the per-kernel rooflines): take the last
+# step that ran the two-phase form when there is one
+for j in range(len(idx) - 2, 0, -1):
+    if any("step_uninstanced_kernel" in r["Kernel_Name"] for r in tr[idx[j - 1]:idx[j]]):
+        a, b = idx[j - 1], idx[j]
+        break
 seg = tr[a:b]
 wall = (int(tr[b]["Start_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6
-busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e6
+# kernels of the two streams overlap: GPU-busy = length of the union of the intervals
+t_end = int(tr[b]["Start_Timestamp"])   # (the side stream's kernel of the NEXT step starts just before that step's render_bwd)
+iv = sorted((int(r["Start_Timestamp"]), min(int(r["End_Timestamp"]), t_end)) for r in seg)
+busy, cur_s, cur_e = 0.0, None, None
+for s0, e0 in iv:
+    if cur_e is None or s0 > cur_e:
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        cur_s, cur_e = s0, e0
+    else:
+        cur_e = max(cur_e, e0)
+busy = (busy + (cur_e - cur_s if cur_e is not None else 0)) / 1e6
 agg = collections.OrderedDict()
 for r in seg:
     n = short(r["Kernel_Name"])
@@ -85,7 +102,8 @@ with open(os.path.join(here, "%s_pmc_traffic.csv" % tag), "w") as f:
 stage_of = {"render_bwd": "render_bwd_wave_kernel", "render_fwd": "render_fwd_wave_kernel", "preprocess_fwd": "preprocess_fwd_kernel",
             "preprocess_bwd": "preprocess_bwd_kernel", "preprocess_bwd_step": "preprocess_bwd_step_kernel",
             "duplicate": "duplicate_kernel", "tile_ranges": "tile_ranges_kernel", "region_bin": "region_bin_kernel",
-            "ssim_fwd": "ssim_fwd_kernel", "ssim_bwd": "ssim_bwd_kernel"}
+            "ssim_fwd": "ssim_fwd_kernel", "ssim_bwd": "ssim_bwd_kernel",
+            "step_uninstanced": "step_uninstanced_kernel"}
 out = {st: traffic[k] for st, k in stage_of.items() if k in traffic}
 out["tag"] = tag
 if "region_bin_kernel" in traffic:   # region binning: the whole binning stage is this one kernel (bench.py stage "sort")
