@@ -620,7 +620,7 @@ def main():
                               "their parameters and both moments on a side stream while render_bwd issues vector "
                               "instructions; gs_backward_step's per-Gaussian kernel waits for both"}
                 try:
-                    t = json.load(open(tf))
+                    t = json.load(open(tf)) if args.config == "c3" else {}  # (the counters were collected on the C3 workload)
                     if t.get("step_uninstanced"):
                         co["traffic"] = t["step_uninstanced"]
                         co["achieved"] = t["step_uninstanced"] / 1e9 / (co["ms_per_launch"] / 1e3)
