@@ -32,6 +32,22 @@ def limits_on(hip):
     hip._cam_cache.clear()
 
 
+@pytest.fixture(params=[False, True], ids=["one_launch_step", "two_phase_step"])
+def step_form(request, hip):
+    """The fused step as one launch after the blend, or in its two-phase form (gs_step_uninstanced beside the blend + phase 2:
+    what runs from 100 k Gaussians on - forced here at test size)."""
+    if request.param:
+        hip.TWO_PHASE, hip.TWO_PHASE_MIN_P = True, 0
+    else:
+        hip.TWO_PHASE = False
+    n0 = hip.two_phase_launches
+    yield request.param
+    assert (hip.two_phase_launches > n0) == request.param
+    for k in ("TWO_PHASE", "TWO_PHASE_MIN_P"):
+        if k in hip.__dict__:
+            delattr(hip, k)
+
+
 def device_camera(cam):
     """(one device tensor per camera, like a trainer; the per-camera state is found by key or by the matrix's contents)"""
     return cam._replace(world_view_transform=cam.world_view_transform.to(DEV),
@@ -264,7 +280,7 @@ def test_per_camera_state_survives_recreated_camera_tensors(hip):
 
 
 @pytest.mark.parametrize("mode", ["checked_in_the_forward", "deferred"])
-def test_training_with_limits_is_the_same_run(hip, mode):
+def test_training_with_limits_is_the_same_run(hip, mode, step_form):
     a, b = make(hip), make(hip)
     hip.depth_limit_on = False
     la = [float(a.step(k)) for k in range(16)]
@@ -286,7 +302,7 @@ def test_training_with_limits_is_the_same_run(hip, mode):
     assert torch.equal(a.model.denom, b.model.denom)
 
 
-def test_deferred_verdict_redoes_a_step_whose_limits_failed(hip):
+def test_deferred_verdict_redoes_a_step_whose_limits_failed(hip, step_form):
     """Deferred mode: camera 1's limits are sabotaged between two visits.  The step that used them is a no-op on the
     device; one step later the trainer learns it, puts counters and running mean back, repeats the step with full
     lists and overwrites the loss it had handed out.  The run is the un-limited run."""
@@ -314,7 +330,7 @@ def test_deferred_verdict_redoes_a_step_whose_limits_failed(hip):
     assert torch.equal(a.model.denom, b.model.denom)
 
 
-def test_graphed_step_with_stale_limits_falls_back(hip):
+def test_graphed_step_with_stale_limits_falls_back(hip, step_form):
     from gsplat_amd.trainer import GraphedStep
     make(hip).step(0)  # (a first eager view sizes the capacity hint GraphedStep captures with)
     torch.cuda.synchronize()
