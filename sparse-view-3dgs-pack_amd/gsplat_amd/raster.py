@@ -99,7 +99,6 @@ class RasterBackend:
         self._side_streams = {}
         self.two_phase_launches = 0
         self._uninst_done = None
-        self._uninst_keep = None
         # one-shot, set together with fused_step by the train step: the opacities / scales / rotations of the next forward
         # (and of its gs_backward_step) are the model's RAW rows, activated inside the kernels
         # (GsGaussians.raw_activations): no activation kernel, no activated copies

@@ -930,7 +930,7 @@ class Trainer:
         pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
                      clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci,
                      raw_activations=(fused_step or fused_dp) and self.RAW_ACTIVATIONS,
-                     camera_key=getattr(self, "_camera_key_override", None) or ("trainer", self.uid, ci))
+                     camera_key=("trainer", self.uid, ci))
         mask = None if self.masks is None else self.masks[ci]
         verdict = backend.take_deferred() if deferred else None
         rm = None

@@ -123,6 +123,48 @@ def test_fused_pass_at_c5_size_against_the_oracle_two_pass(hip, oracle):
     check_grads({k: v.cpu() for k, v in f_g.items()}, o_g, "nir_c5_size_vs_oracle_two_pass", chain_tol=1e-2)
 
 
+def test_four_channel_pass_on_depth_limited_lists(hip):
+    """The per-camera depth limits (csrc/gs_tilecull.h) under the fused RGB + NIR pass: the second and third visit of a
+    camera render from cut, region-binned lists - all four channels, radii and every gradient the bits of the un-limited
+    pass (the 4th channel's blend stops where the colour's does: same T test, forward.cu:326-328) - and stale limits are
+    detected and the view rendered again."""
+    P, W, H = 40000, 640, 480
+    sc = synthetic.trained_like(P, seed=5, sh_degree=2)
+    cam = synthetic.orbit_cameras(W, H)[7]
+    cam = cam._replace(world_view_transform=cam.world_view_transform.cuda(), full_proj_transform=cam.full_proj_transform.cuda(),
+                       camera_center=cam.camera_center.cuda())
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    g = torch.Generator().manual_seed(3)
+    nir = torch.rand((P,), generator=g)
+    dL_rgb, dL_nir = torch.randn((3, H, W), generator=g), torch.randn((1, H, W), generator=g)
+    old = (hip.tile_cull, hip.depth_limit_on)
+    hip._cam_cache.clear()
+    try:
+        hip.tile_cull, hip.depth_limit_on = True, False
+        ref = fused(sc, cam, bg, nir, dL_rgb, dL_nir, False)
+        hip.depth_limit_on = True
+        used0, failed0 = hip.depth_limit_stats["used"], hip.depth_limit_stats["failed"]
+        first = fused(sc, cam, bg, nir, dL_rgb, dL_nir, False)     # measures the stop depths
+        second = fused(sc, cam, bg, nir, dL_rgb, dL_nir, False)    # limited
+        third = fused(sc, cam, bg, nir, dL_rgb, dL_nir, False)
+        assert hip.depth_limit_stats["used"] - used0 == 2 and hip.depth_limit_stats["failed"] == failed0
+        for run in (first, second, third):
+            assert torch.equal(run[0], ref[0]) and torch.equal(run[1], ref[1]) and torch.equal(run[2], ref[2])
+            for k in ref[3]:
+                x, y = ref[3][k].double(), run[3][k].double()
+                assert float((x - y).abs().max()) <= 5e-4 * max(1e-12, float(x.abs().max())), k   # (float-atomic order)
+        faint = dict(sc, opacities=sc["opacities"] * 0.3)            # tiles now saturate far deeper than the limits allow
+        hip.depth_limit_on = False
+        ref_f = fused(faint, cam, bg, nir, dL_rgb, dL_nir, False)
+        hip.depth_limit_on = True
+        got = fused(faint, cam, bg, nir, dL_rgb, dL_nir, False)
+        assert hip.depth_limit_stats["failed"] == failed0 + 1
+        assert torch.equal(got[0], ref_f[0]) and torch.equal(got[1], ref_f[1])
+    finally:
+        hip.tile_cull, hip.depth_limit_on = old
+        hip._cam_cache.clear()
+
+
 def test_extra_channel_argument_errors(hip):
     dev = torch.device("cuda")
     sc = synthetic.trained_like(100, seed=1, sh_degree=0)
