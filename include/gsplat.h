@@ -295,7 +295,12 @@ typedef struct GsStepState {
    * 0: gs_backward_step handles every Gaussian.  2: only the Gaussians that emitted instances in this view - the caller has
    * already run gs_step_uninstanced on the same state for the others. */
   int32_t phase;
-  int32_t _pad_phase;
+  /* The workspace rows between steps (single GPU, rows_override == NULL).  0: gs_backward_step clears the rows of the
+   * Gaussians with instances before the blend accumulates into them and leaves the sums behind (a probe may read them).
+   * 1: as 0, and the per-Gaussian kernel zeroes every row it has consumed - also when the step is a no-op on the device -
+   * so the workspace is all zero again when the call has run.  2: the caller guarantees exactly that state on entry (same
+   * workspace, last used by a call with rows_clean != 0, or zero-filled): no clear launch at all. */
+  int32_t rows_clean;
   void* phase1_done; /* with phase = 2: a hipEvent_t recorded behind gs_step_uninstanced on its stream, or NULL.  gs_backward_step
                         makes its stream wait for it AFTER the backward blend has been launched - the two then run side by
                         side - and before the per-Gaussian kernel.  NULL: the caller has ordered the two calls itself. */

@@ -356,6 +356,7 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
   a.antialiasing = v->antialiasing;
   a.has_invdepth = depth_mode;
   a.grad_rows = rows;
+  a.clean_rows = 0;
   a.splat = gv.splat;
   a.out = *grads;
   return a;
@@ -417,9 +418,11 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
   float* rows = (float*)workspace;
   const bool given_rows = step && step->rows_override;
+  if (step && (step->rows_clean < 0 || step->rows_clean > 2)) return GS_E_SHAPE;
+  const int rows_clean = (step && !given_rows) ? step->rows_clean : 0;
   if (given_rows) {
     rows = const_cast<float*>(step->rows_override);
-  } else {
+  } else if (rows_clean != 2) {  // (2: the previous step's per-Gaussian kernel left every row zero)
     GS_PROF(ST_BWD_MEMSET, s);
     launch_zero_rows(rows, (size_t)P, v->tile_cull ? gv.tiles_touched : nullptr, s);
   }
@@ -433,6 +436,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   }
   PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, grads);
   a.skip_uninstanced = v->tile_cull ? 1 : 0;  // (with the reference's lists every visible Gaussian has instances)
+  a.clean_rows = rows_clean != 0;
   if (step) {
     GS_PROF(ST_BWD_STEP, s);
     sa.hdr = gv.hdr;

@@ -288,6 +288,7 @@ struct PreprocessBwdArgs {
   int skip_uninstanced;  // rows come from the blend backward of THIS forward: a Gaussian that emitted no instance (culled spans,
                          // depth limits) has all-zero sums and so all-zero gradients - its geometry / SH backward is skipped
   const float* grad_rows;  // [P][GR_STRIDE]
+  int clean_rows;          // gs_backward_step (GsStepState.rows_clean): zero every row once it has been consumed
   const uint32_t* tiles_touched;  // [P] instances each Gaussian emitted in this forward (skip_uninstanced)
   const Splat* splat;
   GsGrads out;

@@ -250,6 +250,13 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   const bool failed = (sa.hdr->overflow | sa.hdr->trunc_failed) != 0u;
   if (grads_out && st.fail_flag && blockIdx.x == 0 && threadIdx.x == 0) *st.fail_flag = failed ? 1.0f : 0.0f;
   if (failed) {
+    if (a.clean_rows) {  // the blend backward may have accumulated into the rows of this invalid view: leave them zero
+      const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+      if (i < a.P && a.radii[i] > 0 && !(a.skip_uninstanced && a.tiles_touched[i] == 0)) {
+        float4* w = reinterpret_cast<float4*>(const_cast<float*>(a.grad_rows) + (size_t)i * GR_STRIDE);
+        w[0] = w[1] = w[2] = w[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     if (grads_out && st.max_radii2D) {  // this view contributes no statistics (the sum over ranks must stay finite)
       const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
       if (i < a.P) {
@@ -284,7 +291,13 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   ShSink dsh{s_sh + tid * SH_LDS_ROW, true};
 #pragma unroll
   for (int k = 0; k < SH_LDS_ROW; k++) dsh.p[k] = 0.f;
-  if (active) geometry_backward(a, idx, gb);
+  if (active) {
+    geometry_backward(a, idx, gb);
+    if (a.clean_rows && in_range) {  // the row is consumed: zero again for the next view's blend backward (no clear launch then)
+      float4* w = reinterpret_cast<float4*>(const_cast<float*>(a.grad_rows) + (size_t)idx * GR_STRIDE);
+      w[0] = w[1] = w[2] = w[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 
   // ---- view statistics (train.py:266-268, gaussian_model.py:471-473)
   if (in_range && st.max_radii2D && mine) {

@@ -97,7 +97,7 @@ class GsStepState(C.Structure):
                 ("step", C.c_int32 * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_radii2D", C.c_void_p), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
                 ("coef_dev", C.c_void_p), ("rows_override", C.c_void_p), ("grad_out", C.c_void_p * 5),
-                ("fail_flag", C.c_void_p), ("phase", C.c_int32), ("_pad_phase", C.c_int32),
+                ("fail_flag", C.c_void_p), ("phase", C.c_int32), ("rows_clean", C.c_int32),
                 ("phase1_done", C.c_void_p)]
 
 

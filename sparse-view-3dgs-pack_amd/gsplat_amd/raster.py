@@ -97,6 +97,7 @@ class RasterBackend:
         # per-Gaussian kernel) instead of gs_backward; the backward then returns no gradients at all
         self.fused_step = None
         self._side_streams = {}
+        self._rows_ws = {}        # (device, bytes) -> [persistent gradient-row workspace of the fused step, rows all zero?]
         self.two_phase_launches = 0
         self._uninst_done = None
         # one-shot, set together with fused_step by the train step: the opacities / scales / rotations of the next forward
@@ -667,11 +668,29 @@ class RasterBackend:
             _, _, _, wsb = self.scratch_bytes(P, W, H, R)
             # (the backward clears only the rows of Gaussians that emitted instances; a probe that reads the rows gets zeros
             # for the others too)
-            ws = (torch.zeros if self.keep_workspace else torch.empty)((wsb,), dtype=torch.uint8, device=device)
-            if self.keep_workspace:
-                self.last_workspace = ws
+            two_phase = self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and view.tile_cull != 0 and not step.grad_out[0]
+            if self.keep_workspace or step.rows_override or two_phase:
+                # (two-phase: the clear launch stays - it is the head start the side kernel needs.  Its 512 four-wave
+                # workgroups must find their slots before the blend's 8 160 one-wave workgroups are dealt out; launched at
+                # the same moment they trickle in behind them, 0.50 instead of 0.36 ms, and phase 2 waits: measured, with
+                # and without a high-priority side stream)
+                ws = (torch.zeros if self.keep_workspace else torch.empty)((wsb,), dtype=torch.uint8, device=device)
+                if self.keep_workspace:
+                    self.last_workspace = ws
+            else:
+                # one persistent workspace per size: the per-Gaussian kernel zeroes every row it consumes
+                # (GsStepState.rows_clean), so the rows are clean again after every step and no clear launch runs
+                key = (device.index, wsb)
+                ent = self._rows_ws.get(key)
+                if ent is None:
+                    if len(self._rows_ws) >= 4:
+                        self._rows_ws.clear()
+                    ent = self._rows_ws[key] = [torch.zeros((wsb,), dtype=torch.uint8, device=device), True]
+                ws = ent[0]
+                step.rows_clean = 2 if ent[1] else 1
+                ent[1] = False      # (until the call below has returned: a failed launch leaves them in an unknown state)
             s = self._scratch(geomBuffer, imgBuffer, binningBuffer, self._capacity_for(binningBuffer, P, W, H, R))
-            if self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and view.tile_cull != 0 and not step.grad_out[0]:
+            if two_phase:
                 main = torch.cuda.current_stream(device)
                 side = self._side_streams.get(device.index)
                 if side is None:
@@ -689,6 +708,8 @@ class RasterBackend:
             self.api.call("backward_step", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
                           dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(step), _ptr(ws), ws.numel(),
                           self._stream(device))
+            if step.rows_clean:
+                self._rows_ws[(device.index, wsb)][1] = True
             return (None,) * 8
 
         def out(name, shape):
