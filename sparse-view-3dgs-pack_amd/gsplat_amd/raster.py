@@ -670,7 +670,7 @@ class RasterBackend:
             # for the others too)
             two_phase = self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and view.tile_cull != 0 and not step.grad_out[0]
             if self.keep_workspace or step.rows_override or two_phase:
-                # (two-phase: the clear launch stays - it is the head start the side kernel needs.  Its 512 four-wave
+                # (two-phase: the clear launch stays - it is the head start the side kernel needs.  Its few hundred four-wave
                 # workgroups must find their slots before the blend's 8 160 one-wave workgroups are dealt out; launched at
                 # the same moment they trickle in behind them, 0.50 instead of 0.36 ms, and phase 2 waits: measured, with
                 # and without a high-priority side stream)
@@ -683,8 +683,8 @@ class RasterBackend:
                 key = (device.index, wsb)
                 ent = self._rows_ws.get(key)
                 if ent is None:
-                    if len(self._rows_ws) >= 4:
-                        self._rows_ws.clear()
+                    if len(self._rows_ws) >= 4:   # (sizes of a model that has since been densified: nothing replays them,
+                        self._rows_ws.clear()    #  a captured graph is keyed by the number of Gaussians)
                     ent = self._rows_ws[key] = [torch.zeros((wsb,), dtype=torch.uint8, device=device), True]
                 ws = ent[0]
                 step.rows_clean = 2 if ent[1] else 1
