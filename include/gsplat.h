@@ -450,6 +450,16 @@ int gs_l1_dwt2_fwd(const float* pred, const float* gt, int32_t C, int32_t H, int
  * GS_E_UNSUPPORTED (clamp first and call gs_l1_dwt2_fwd). */
 int gs_l1_dwt2_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, float* l1_sum,
                          float* band_sums, float* clamped_out, void* stream);
+/* gs_l1_dwt2_fwd_clamp and gs_patch_dwt_fwd in one pass, gs_l1_dwt2_bwd and gs_patch_dwt_bwd in one: the patch term's sums
+ * are the level-1 LH / HL / HH differences of the same 2 x 2 blocks, restricted to the selected patches (mask [H/ps * W/ps],
+ * loss_utils.py:395-442), and its gradient rides on the same band signs.  patch_sums[3] +=; patch_coef_dev[3] as coef_dev of
+ * gs_patch_dwt_bwd.  H, W and ps multiples of 4 and 16-byte aligned planes, else GS_E_UNSUPPORTED (use the separate calls). */
+int gs_l1_dwt2_patch_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps,
+                               const uint8_t* mask, float* l1_sum, float* band_sums, float* patch_sums,
+                               float* clamped_out, void* stream);
+int gs_l1_dwt2_patch_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps,
+                         const uint8_t* mask, const float* l1_coef_dev /*[1]*/, const float* coef_dev /*[8]*/,
+                         const float* patch_coef_dev /*[3]*/, float* grad_pred, int32_t accumulate, void* stream);
 int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
                    const float* l1_coef_dev /*[1]*/, const float* coef_dev /*[8]*/, float* grad_pred,
                    int32_t accumulate, void* stream);

@@ -497,12 +497,27 @@ int gso_l1_dwt2_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t 
   for (int64_t i = 0; i < n; i++) clamped_out[i] = fminf(fmaxf(raw[i], 0.f), 1.f);  // gaussian_renderer/__init__.py:119
   return gso_l1_dwt2_fwd(clamped_out, gt, C, H, W, l1_sum, band_sums, nullptr);
 }
+int gso_l1_dwt2_patch_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps, const uint8_t* mask,
+                                float* l1_sum, float* band_sums, float* patch_sums, float* clamped_out, void*) {
+  if (!mask || !patch_sums) return GS_E_NULL;
+  if (ps <= 0 || (ps % 4) != 0) return ps <= 0 ? GS_E_SHAPE : GS_E_UNSUPPORTED;
+  int rc = gso_l1_dwt2_fwd_clamp(raw, gt, C, H, W, l1_sum, band_sums, clamped_out, nullptr);
+  return rc ? rc : gso_patch_dwt_fwd(clamped_out, gt, C, H, W, ps, mask, patch_sums, nullptr);
+}
 int gso_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* l1_coef,
                     const float* coef, float* grad, int32_t accumulate, void*) {
   if (!l1_coef) return GS_E_NULL;
   if (C <= 0 || H <= 0 || W <= 0) return GS_E_SHAPE;
   int rc = gso_l1_bwd_dev(pred, gt, (int64_t)C * H * W, l1_coef, grad, accumulate, nullptr);
   return rc ? rc : gso_dwt2_l1_bwd(pred, gt, C, H, W, coef, grad, 1, nullptr);
+}
+int gso_l1_dwt2_patch_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps, const uint8_t* mask,
+                          const float* l1_coef, const float* coef, const float* patch_coef, float* grad, int32_t accumulate, void*) {
+  if (!mask || !patch_coef) return GS_E_NULL;
+  if (ps <= 0 || (ps % 4) != 0) return ps <= 0 ? GS_E_SHAPE : GS_E_UNSUPPORTED;
+  if ((H % 4) != 0 || (W % 4) != 0) return GS_E_UNSUPPORTED;
+  int rc = gso_l1_dwt2_bwd(pred, gt, C, H, W, l1_coef, coef, grad, accumulate, nullptr);
+  return rc ? rc : gso_patch_dwt_bwd(pred, gt, C, H, W, ps, mask, patch_coef, grad, 1, nullptr);
 }
 int gso_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1, float C2,
                      float* sum_out, float* d1, float* d2, float* d3, void*) {

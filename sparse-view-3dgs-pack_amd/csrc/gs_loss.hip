@@ -180,13 +180,20 @@ __device__ __forceinline__ void bands_of(const Px44& x, Blk44& o) {
 // sums[0..7] += band L1 sums; sums[8] (only when l1_sum != nullptr, added there) += sum |pred - gt|
 // clamped_out (FAST only): `pred` is the un-clamped render - the 4x4 block is clamped to [0, 1] as it is loaded and written
 // there, which is the torch.clamp pass of gaussian_renderer/__init__.py:119 without its own read of the image
+// patch_mask (FAST, patch size a multiple of 4, l1_sum given): the patch-DWT term (loss_utils.py:395-442) from the same
+// pass - its three sums are the level-1 LH / HL / HH differences of THE SAME 2x2 blocks, restricted to the selected
+// patches (a patch is a multiple of 4 pixels wide and starts on one: a thread's 4x4 block lies inside one patch), so
+// patch_dwt_kernel<false> and its launch disappear: patch_sums[0..2] += sum over selected patches of |d LH|, |d HL|, |d HH|.
 template <bool FAST>
 __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                                                int C, int H, int W, float* band_sums, float* l1_sum,
-                                                               float* __restrict__ clamped_out) {
+                                                               float* __restrict__ clamped_out,
+                                                               const uint8_t* __restrict__ patch_mask, int ps,
+                                                               float* patch_sums) {
   const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
   const int64_t total = (int64_t)C * h2 * w2;
-  float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int pnx = patch_mask ? W / ps : 0, pny = patch_mask ? H / ps : 0;
+  float s[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t o = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; o < total; o += (int64_t)gridDim.x * GS_BLOCK) {
     const int j2 = (int)(o % w2), i2 = (int)((o / w2) % h2), c = (int)(o / ((int64_t)w2 * h2));
     Px44 pa, pb;
@@ -204,13 +211,22 @@ __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __re
     Blk44 a, b;
     bands_of(pa, a);
     bands_of(pb, b);
+    bool in_patch = false;
+    if (FAST && patch_mask) {
+      const int py = (4 * i2) / ps, px = (4 * j2) / ps;
+      in_patch = py < pny && px < pnx && patch_mask[py * pnx + px] != 0;
+    }
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
       for (int cc = 0; cc < 2; cc++)
         if (FAST || (2 * i2 + r < h1 && 2 * j2 + cc < w1)) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) s[k] += fabsf(a.l1[r][cc][k] - b.l1[r][cc][k]);
+          for (int k = 0; k < 4; k++) {
+            const float d = fabsf(a.l1[r][cc][k] - b.l1[r][cc][k]);
+            s[k] += d;
+            if (FAST && k > 0 && in_patch) s[8 + k] += d;   // (9, 10, 11 = LH, HL, HH of the selected patches)
+          }
         }
 #pragma unroll
     for (int k = 0; k < 4; k++) s[4 + k] += fabsf(a.l2[k] - b.l2[k]);
@@ -223,20 +239,21 @@ __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __re
     }
   }
   if (l1_sum) {
-    // the nine sums go to two places: fold the L1 one through the same reduction, then route it
-    __shared__ float red9[GS_BLOCK / 64][9];
+    // the nine (twelve with the patch term) sums go to two (three) places: one reduction, then route them
+    __shared__ float red12[GS_BLOCK / 64][12];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
+    for (int k = 0; k < 12; k++) {
       float x = s[k];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
-      if ((threadIdx.x & 63) == 0) red9[threadIdx.x >> 6][k] = x;
+      if ((threadIdx.x & 63) == 0) red12[threadIdx.x >> 6][k] = x;
     }
     __syncthreads();
-    if (threadIdx.x < 9) {
+    if (threadIdx.x < 12) {
       float t = 0.f;
-      for (int w = 0; w < GS_BLOCK / 64; w++) t += red9[w][threadIdx.x];
-      if (t != 0.f) atomicAdd(threadIdx.x < 8 ? &band_sums[threadIdx.x] : l1_sum, t);
+      for (int w = 0; w < GS_BLOCK / 64; w++) t += red12[w][threadIdx.x];
+      if (t != 0.f)
+        atomicAdd(threadIdx.x < 8 ? &band_sums[threadIdx.x] : (threadIdx.x == 8 ? l1_sum : &patch_sums[threadIdx.x - 9]), t);
     }
   } else {
     float s8[8];
@@ -251,12 +268,18 @@ template <bool FAST>
 __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                                                int C, int H, int W, const float* __restrict__ coef,
                                                                const float* __restrict__ l1_coef, float* __restrict__ grad,
-                                                               int accumulate) {
+                                                               int accumulate, const uint8_t* __restrict__ patch_mask, int ps,
+                                                               const float* __restrict__ patch_coef) {
+  // patch_mask (FAST, patch size a multiple of 4): the gradient of the patch-DWT term from the same pass - inside a selected
+  // patch the level-1 LH / HL / HH signs take the patch coefficients on top of the global ones (see dwt2_l1_fwd_kernel)
   const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
   const int64_t total = (int64_t)C * h2 * w2;
-  float cf[8];
+  const int pnx = patch_mask ? W / ps : 0, pny = patch_mask ? H / ps : 0;
+  float cfg[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) cf[k] = coef[k];
+  for (int k = 0; k < 8; k++) cfg[k] = coef[k];
+  float cp[3] = {0.f, 0.f, 0.f};
+  if (patch_mask) { cp[0] = patch_coef[0]; cp[1] = patch_coef[1]; cp[2] = patch_coef[2]; }
   const float c1l = l1_coef ? l1_coef[0] : 0.f;
   for (int64_t o = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; o < total; o += (int64_t)gridDim.x * GS_BLOCK) {
     const int j2 = (int)(o % w2), i2 = (int)((o / w2) % h2), c = (int)(o / ((int64_t)w2 * h2));
@@ -266,6 +289,17 @@ __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_bwd_kernel(const float* __re
     Blk44 a, b;
     bands_of(pa, a);
     bands_of(pb, b);
+    float cf[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) cf[k] = cfg[k];
+    if (FAST && patch_mask) {
+      const int py = (4 * i2) / ps, px = (4 * j2) / ps;
+      if (py < pny && px < pnx && patch_mask[py * pnx + px] != 0) {
+        cf[1] += cp[0];
+        cf[2] += cp[1];
+        cf[3] += cp[2];
+      }
+    }
     // level-2 adjoint -> gradient of the four LL1 inputs (padded duplicates fold onto the last sample)
     float dl[2][2];
     {
@@ -819,31 +853,36 @@ static inline bool dwt2_fast(const void* a, const void* b, const void* g, int H,
   return (H % 4) == 0 && (W % 4) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)g) & 15) == 0);
 }
 static int dwt2_l1_fwd_launch(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* band_sums,
-                              float* l1_sum, hipStream_t s, float* clamped_out = nullptr) {
+                              float* l1_sum, hipStream_t s, float* clamped_out = nullptr, const uint8_t* patch_mask = nullptr,
+                              int ps = 0, float* patch_sums = nullptr) {
   const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
   // few, long-running workgroups: every workgroup ends in nine atomics on one cache line, and at 1500 workgroups
   // (1080p) their serialisation was 40 % of the kernel (25.9 us at a 4096 cap, 15.1 us at 512)
   const dim3 grid(nblocks((int64_t)C * h2 * w2, GS_BLOCK, 512));
   if (dwt2_fast(pred, gt, clamped_out, H, W))
-    hipLaunchKernelGGL(dwt2_l1_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum, clamped_out);
-  else if (clamped_out)
+    hipLaunchKernelGGL(dwt2_l1_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum, clamped_out,
+                       patch_mask, ps, patch_sums);
+  else if (clamped_out || patch_mask)
     return GS_E_UNSUPPORTED;  // (H, W multiples of 4 and 16-byte aligned planes only: clamp with torch otherwise)
   else
     hipLaunchKernelGGL(dwt2_l1_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum,
-                       (float*)nullptr);
+                       (float*)nullptr, (const uint8_t*)nullptr, 0, (float*)nullptr);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
 static int dwt2_l1_bwd_launch(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* coef_dev,
-                              const float* l1_coef_dev, float* grad_pred, int32_t accumulate, hipStream_t s) {
+                              const float* l1_coef_dev, float* grad_pred, int32_t accumulate, hipStream_t s,
+                              const uint8_t* patch_mask = nullptr, int ps = 0, const float* patch_coef = nullptr) {
   const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
   const dim3 grid(nblocks((int64_t)C * h2 * w2));
   if (dwt2_fast(pred, gt, grad_pred, H, W))
     hipLaunchKernelGGL(dwt2_l1_bwd_kernel<true>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, coef_dev, l1_coef_dev,
-                       grad_pred, accumulate);
+                       grad_pred, accumulate, patch_mask, ps, patch_coef);
+  else if (patch_mask)
+    return GS_E_UNSUPPORTED;
   else
     hipLaunchKernelGGL(dwt2_l1_bwd_kernel<false>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, coef_dev, l1_coef_dev,
-                       grad_pred, accumulate);
+                       grad_pred, accumulate, (const uint8_t*)nullptr, 0, (const float*)nullptr);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -877,6 +916,25 @@ int gs_l1_dwt2_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t H
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_DWT2_FWD, s);
   return dwt2_l1_fwd_launch(raw, gt, C, H, W, band_sums, l1_sum, s, clamped_out);
+}
+int gs_l1_dwt2_patch_fwd_clamp(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps, const uint8_t* mask,
+                               float* l1_sum, float* band_sums, float* patch_sums, float* clamped_out, void* stream) {
+  if (!raw || !gt || !band_sums || !l1_sum || !clamped_out || !mask || !patch_sums) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0 || ps <= 0 || H < ps || W < ps) return GS_E_SHAPE;
+  if (ps % 4 != 0) return GS_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT2_FWD, s);
+  return dwt2_l1_fwd_launch(raw, gt, C, H, W, band_sums, l1_sum, s, clamped_out, mask, ps, patch_sums);
+}
+int gs_l1_dwt2_patch_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps, const uint8_t* mask,
+                         const float* l1_coef_dev, const float* coef_dev, const float* patch_coef_dev, float* grad_pred,
+                         int32_t accumulate, void* stream) {
+  if (!pred || !gt || !coef_dev || !l1_coef_dev || !grad_pred || !mask || !patch_coef_dev) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0 || ps <= 0 || H < ps || W < ps) return GS_E_SHAPE;
+  if (ps % 4 != 0) return GS_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT2_BWD, s);
+  return dwt2_l1_bwd_launch(pred, gt, C, H, W, coef_dev, l1_coef_dev, grad_pred, accumulate, s, mask, ps, patch_coef_dev);
 }
 int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, const float* l1_coef_dev,
                    const float* coef_dev, float* grad_pred, int32_t accumulate, void* stream) {

@@ -158,6 +158,8 @@ PROTOTYPES = {
     "l1_bwd_dev": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P]),
     "l1_dwt2_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "l1_dwt2_fwd_clamp": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "l1_dwt2_patch_fwd_clamp": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "l1_dwt2_patch_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "l1_dwt2_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "ssim_fwd_sum": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "ssim_bwd_uniform": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P]),

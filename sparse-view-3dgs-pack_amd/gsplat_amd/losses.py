@@ -260,7 +260,15 @@ class FusedLGDWTLoss(torch.autograd.Function):
         Cc, H, W = raw.shape
         st = _stream(raw)
         d1, d2, d3 = torch.empty_like(raw), torch.empty_like(raw), torch.empty_like(raw)
-        if params.dwt_enable and H % 4 == 0 and W % 4 == 0:
+        # the patch term rides on the global DWT kernels when the sizes allow (its sums are level-1 band differences of the
+        # same 2 x 2 blocks, restricted to the selected patches): two launches less per step
+        patch_folded = bool(params.patch_enable and params.dwt_enable and H % 4 == 0 and W % 4 == 0
+                            and ctx_ps(params) % 4 == 0)
+        if patch_folded:
+            img = torch.empty_like(raw)
+            api.call("l1_dwt2_patch_fwd_clamp", raw.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
+                     sums.data_ptr(), sums[2:].data_ptr(), sums[10:].data_ptr(), img.data_ptr(), st)
+        elif params.dwt_enable and H % 4 == 0 and W % 4 == 0:
             # L1 and the eight band sums from one read of the two images - and the clamp: the kernel clamps the render as it
             # loads it and leaves the clamped image behind for the other terms (no torch.clamp pass: 9 us at 1080p)
             img = torch.empty_like(raw)
@@ -276,13 +284,13 @@ class FusedLGDWTLoss(torch.autograd.Function):
         partials = torch.empty((params.n_ssim_partials,), dtype=torch.float32, device=raw.device)
         api.call("ssim_fwd_partials", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, 0.01 ** 2, 0.03 ** 2,
                  partials.data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), st)
-        if params.patch_enable:
+        if params.patch_enable and not patch_folded:
             api.call("patch_dwt_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
                      sums[10:].data_ptr(), st)
         out = torch.empty((24,), dtype=torch.float32, device=raw.device)
         api.call("lgdwt_combine_p", sums.data_ptr(), partials.data_ptr(), partials.numel(), running_mean.data_ptr(),
                  C.byref(params.c), out.data_ptr(), st)
-        ctx.ops, ctx.params = ops, params
+        ctx.ops, ctx.params, ctx.patch_folded = ops, params, patch_folded
         ctx.save_for_backward(raw, img, gt, mask, d1, d2, d3, out)
         ctx.mark_non_differentiable(out)
         ctx.set_materialize_grads(False)   # no zero tensor for the unused gradient of `out`
@@ -301,12 +309,15 @@ class FusedLGDWTLoss(torch.autograd.Function):
         unit = ctx.ops._unit.get(g.device)
         coef = out[8:24] if (unit is not None and g.data_ptr() == unit.data_ptr()) else (out[8:24] * g).contiguous()
         grad = torch.empty_like(raw)
-        if params.dwt_enable:
+        if ctx.patch_folded:
+            api.call("l1_dwt2_patch_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
+                     coef.data_ptr(), coef[2:].data_ptr(), coef[10:].data_ptr(), grad.data_ptr(), 0, st)
+        elif params.dwt_enable:
             api.call("l1_dwt2_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, coef.data_ptr(), coef[2:].data_ptr(),
                      grad.data_ptr(), 0, st)
         else:
             api.call("l1_bwd_dev", img.data_ptr(), gt.data_ptr(), img.numel(), coef.data_ptr(), grad.data_ptr(), 0, st)
-        if params.patch_enable:
+        if params.patch_enable and not ctx.patch_folded:
             api.call("patch_dwt_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
                      coef[10:].data_ptr(), grad.data_ptr(), 1, st)
         api.call("ssim_bwd_uniform", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, coef[1:].data_ptr(), d1.data_ptr(),

@@ -153,6 +153,46 @@ def test_l1_dwt2_one_pass_equals_the_two_kernels_and_the_oracle(hip, oracle, H, 
     close(out["hip"][1], out["oracle"][1], 2e-5, "grad")
 
 
+@pytest.mark.parametrize("H,W,ps,acc", [(256, 384, 64, 0), (260, 392, 128, 1), (1080, 1920, 128, 0)])
+def test_patch_term_folded_into_the_dwt_kernels(hip, oracle, H, W, ps, acc):
+    """gs_l1_dwt2_patch_fwd_clamp / gs_l1_dwt2_patch_bwd (L1 + global 2-level DWT + patch DWT + clamp from one pass each
+    way) against the separate HIP kernels and against the oracle: the clamped image bit for bit, the twelve sums and the
+    gradient to rounding (the folded form adds the patch coefficients to the band coefficients BEFORE the Haar adjoint)."""
+    g = torch.Generator().manual_seed(H + ps)
+    gt = torch.rand((3, H, W), generator=g)
+    raw = gt + 0.2 * torch.randn((3, H, W), generator=g)          # un-clamped render: values outside [0, 1]
+    mask = (torch.rand(((H // ps) * (W // ps),), generator=g) < 0.4).to(torch.uint8)
+    coef = torch.rand((13,), generator=g) / (H * W)                # [c_l1, c_band x8, -, c_patch x3]
+    g0 = torch.randn((3, H, W), generator=g) * 1e-6
+    out = {}
+    for name, api, dev, folded in (("hip", hip.api, "cuda", True), ("hip_separate", hip.api, "cuda", False),
+                                   ("oracle", oracle.api, "cpu", True)):
+        r, t, m, c = raw.to(dev), gt.to(dev), mask.to(dev), coef.to(dev)
+        gr = g0.to(dev).clone()
+        sums = torch.zeros((13,), device=dev)                       # [l1, band x8, -, patch x3]
+        st = torch.cuda.current_stream().cuda_stream if dev == "cuda" else None
+        if folded:
+            img = torch.empty_like(r)
+            api.call("l1_dwt2_patch_fwd_clamp", r.data_ptr(), t.data_ptr(), 3, H, W, ps, m.data_ptr(), sums.data_ptr(),
+                     sums[1:].data_ptr(), sums[10:].data_ptr(), img.data_ptr(), st)
+            api.call("l1_dwt2_patch_bwd", img.data_ptr(), t.data_ptr(), 3, H, W, ps, m.data_ptr(), c.data_ptr(),
+                     c[1:].data_ptr(), c[10:].data_ptr(), gr.data_ptr(), acc, st)
+        else:
+            img = r.clamp(0, 1)
+            api.call("l1_dwt2_fwd", img.data_ptr(), t.data_ptr(), 3, H, W, sums.data_ptr(), sums[1:].data_ptr(), st)
+            api.call("patch_dwt_fwd", img.data_ptr(), t.data_ptr(), 3, H, W, ps, m.data_ptr(), sums[10:].data_ptr(), st)
+            api.call("l1_dwt2_bwd", img.data_ptr(), t.data_ptr(), 3, H, W, c.data_ptr(), c[1:].data_ptr(), gr.data_ptr(), acc, st)
+            api.call("patch_dwt_bwd", img.data_ptr(), t.data_ptr(), 3, H, W, ps, m.data_ptr(), c[10:].data_ptr(), gr.data_ptr(), 1, st)
+        out[name] = (img.cpu(), sums.cpu(), gr.cpu())
+    assert torch.equal(out["hip"][0], out["hip_separate"][0]) and torch.equal(out["hip"][0], out["oracle"][0])
+    assert float(out["hip"][1][10:].min()) > 0, "no selected patch contributed"
+    for other in ("hip_separate", "oracle"):
+        for k in list(range(9)) + [10, 11, 12]:
+            a, b = float(out["hip"][1][k]), float(out[other][1][k])
+            assert abs(a - b) <= 1e-5 * abs(b), (other, k, a, b)
+        close(out["hip"][2], out[other][2], 2e-5, "grad vs " + other)
+
+
 @pytest.mark.parametrize("H,W", [(1080, 1920), (131, 260), (33, 40)])
 def test_ssim_partials_equal_the_atomic_sum_and_the_oracle(hip, oracle, H, W):
     """gs_ssim_fwd_partials (one plain store per workgroup) + gs_lgdwt_combine_p against gs_ssim_fwd_sum +
