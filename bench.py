@@ -477,6 +477,62 @@ def main():
             tr.step(k)
             k += 1
         barrier()
+    # The LONG run, untimed by the driver: the timed region is twenty steps early in a run; what a few hundred more steps cost
+    # depends on how fast the model moves between two visits of a camera - the depth limits of a camera are the stop depths of
+    # its last visit, and a view whose tiles now saturate deeper is rendered again with full lists (a fall-back).  Two runs of
+    # GS_BENCH_SUSTAINED (default 600) eager steps each, continuing the timed model: (a) this bench's target - renders of an
+    # UNRELATED random scene, which the model can never fit: it keeps moving fast - and (b) a target the model is close to
+    # (the same scene with slightly different colours: a run that is converging, where training spends its time).
+    sustained = None
+    n_sus = int(os.environ.get("GS_BENCH_SUSTAINED", "600"))
+    if world == 1 and args.config == "c3" and depth_limit and n_sus > 0 and os.environ.get("GS_BENCH_OTHER_SCENES", "1") != "0":
+        from gsplat_amd import hip_backend as _hb3
+        be3 = _hb3()
+        sustained = {}
+
+        def run_sustained(trainer, label, what):
+            kk = 10_000
+            for _ in range(len(cams) + 2):
+                trainer.step(kk)
+                kk += 1
+            trainer.sync()
+            barrier()
+            d0 = dict(be3.depth_limit_stats)
+            t1 = time.perf_counter()
+            for _ in range(n_sus):
+                trainer.step(kk)
+                kk += 1
+            trainer.sync()
+            barrier()
+            dx = (time.perf_counter() - t1) / n_sus
+            d1 = dict(be3.depth_limit_stats)
+            levels = [0] * len(be3.SLACK)
+            for ci in range(len(cams)):
+                ent = be3.camera_entry(W, H, camera_key=("trainer", trainer.uid, ci), device_index=device.index)
+                if ent is not None:
+                    levels[ent["slack_level"]] += 1
+            sustained[label] = {"target": what, "steps": n_sus, "ms_per_step": dx * 1e3, "views_per_s": 1.0 / dx,
+                                "limited_views": d1["used"] - d0["used"], "fallbacks": d1["failed"] - d0["failed"],
+                                "cameras_per_slack_factor": dict(zip(["%.2f" % f for f in be3.SLACK], levels))}
+            log("sustained (%s): %.3f ms/step over %d steps, %d fall-backs" % (label, dx * 1e3, n_sus, d1["failed"] - d0["failed"]))
+
+        run_sustained(tr, "bench_target", "renders of an unrelated random scene (seed + 1): the model cannot fit it and keeps moving")
+        from gsplat_amd import synthetic as _syn
+        from gsplat_amd.trainer import GaussianModelLite as _GML, render as _render
+        from gsplat_amd._lib import hip_api as _hip_api
+        import diff_gaussian_rasterization as _dgr
+        g_near = torch.Generator().manual_seed(5)
+        near = dict(scene, shs=scene["shs"] + 0.02 * torch.randn(scene["shs"].shape, generator=g_near))
+        nm = _GML(near, device, api=_hip_api())
+        with torch.no_grad():
+            gts_near = [_render(c, nm, _dgr.GaussianRasterizer, _dgr.GaussianRasterizationSettings, torch.zeros(3, device=device))
+                        ["render"].clone() for c in cams]
+        del nm
+        tr3, _, _, _ = build_workload(args.config, device, rank, world, gts=gts_near)
+        tr3.depth_limit = "deferred"
+        run_sustained(tr3, "near_target", "renders of the same scene with slightly different colours: a run that is converging")
+        del tr3, gts_near
+
     # SURVEY 8(d)'s other inputs, untimed by the driver: the same step (same launch form as the timed region's choice is
     # not used here: eager, depth limits as in the timed region) on an init-like scene at SH degree 0 and on a scene
     # whose background never saturates - what the depth limits / early termination cannot shortcut
@@ -659,6 +715,7 @@ def main():
             "roofline": roofline,
             "reference_lists": ref_lists,
             "other_scenes": other or None,
+            "sustained": sustained,
             "data_parallel": dp_info,
             "step_times_ms": {"timed (config.lists)": dt / args.steps * 1e3,
                               "reference lists": None if ref_lists is None else ref_lists["ms_per_step"],

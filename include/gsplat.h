@@ -141,6 +141,10 @@ typedef struct GsScratch {
                                       captured graph of the step can tell, by polling its pinned block for the tag it
                                       uploaded before the replay, that the status of THAT replay has arrived (no stream
                                       synchronisation, no event inside the graph) */
+  const float* tile_depth_limit_slack; /* optional, device, one float >= 1 (NULL: 1): the bounds written to tile_depth_limit_out
+                                      are multiplied by it.  A caller whose model moves fast between two visits of a camera (early
+                                      training) raises it for the cameras whose limits fail and lowers it again when they hold:
+                                      longer lists, fewer repeated views.  Device memory so that a replayed graph sees changes. */
 } GsScratch;
 
 /* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by

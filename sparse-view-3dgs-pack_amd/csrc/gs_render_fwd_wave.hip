@@ -234,7 +234,7 @@ int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int 
 #define TO_THREADS 1024
 #define TO_BUCKETS 2048
 __device__ __forceinline__ void stop_depth_bound_item(const float* __restrict__ stop, float* __restrict__ out, int grid_x,
-                                                      int grid_y, int i);
+                                                      int grid_y, int i, float slack = 1.0f);
 // The same launch also serves the two per-camera exports when the caller asked for them in GsScratch (tile_order_out,
 // tile_depth_limit_out): the order is written twice, and the eight workgroups share the depth bounds among them.
 __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* __restrict__ tile_work,
@@ -242,13 +242,15 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* 
                                                                 uint32_t* __restrict__ order_out,
                                                                 const float* __restrict__ stop_depth,
                                                                 float* __restrict__ limit_out, int grid_x, int grid_y,
-                                                                const GeomHeader* __restrict__ hdr) {
+                                                                const GeomHeader* __restrict__ hdr,
+                                                                const float* __restrict__ slack_dev) {
   // a forward that ran out of binning capacity blended nothing and is about to be repeated with the SAME hints and
   // bounds (the geometry phase has already counted with them): it must not overwrite them with what it did not measure
   if (hdr->overflow) order_out = nullptr;
   if (blockIdx.x >= 8) {  // workgroups past the eight bands: the depth bounds, one item per thread
     const int i = (int)(blockIdx.x - 8) * TO_THREADS + (int)threadIdx.x;
-    if (!hdr->overflow && i < (int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y)) stop_depth_bound_item(stop_depth, limit_out, grid_x, grid_y, i);
+    if (!hdr->overflow && i < (int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y))
+      stop_depth_bound_item(stop_depth, limit_out, grid_x, grid_y, i, slack_dev ? fmaxf(*slack_dev, 1.0f) : 1.0f);
     return;
   }
   __shared__ uint32_t s_cnt[TO_BUCKETS];
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* 
 // gs_export_tile_stop_depth: per tile the largest stop depth of its 3 x 3 neighbourhood, then per aligned run of four
 // tiles of a row the largest of those bounds (reasons: gs_tilecull.h); one launch, both straight from the stop depths
 __device__ __forceinline__ void stop_depth_bound_item(const float* __restrict__ stop, float* __restrict__ out, int grid_x,
-                                                      int grid_y, int i) {
+                                                      int grid_y, int i, float slack) {
   const int T = grid_x * grid_y, segs_x = (int)depth_limit_segs_x((uint32_t)grid_x);
   int x0, x1, ty;  // tile columns whose 3 x 3 neighbourhoods are merged
   if (i < T) {
@@ -321,7 +323,7 @@ __device__ __forceinline__ void stop_depth_bound_item(const float* __restrict__ 
   float hi = -__builtin_inff();
   for (int y = max(ty - 1, 0); y <= min(ty + 1, grid_y - 1); y++)
     for (int x = max(x0 - 1, 0); x <= min(x1 + 1, grid_x - 1); x++) hi = fmaxf(hi, stop[y * grid_x + x]);
-  out[i] = hi;
+  out[i] = hi * slack;  // (GsScratch.tile_depth_limit_slack >= 1: +inf stays +inf)
 }
 __global__ void __launch_bounds__(256) stop_depth_bounds_kernel(const float* __restrict__ stop, float* __restrict__ out,
                                                                 int grid_x, int grid_y) {
@@ -336,9 +338,9 @@ int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, in
 }
 
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, uint32_t* order_out, const float* stop_depth,
-                      float* limit_out, int grid_x, int grid_y, const GeomHeader* hdr, hipStream_t s) {
+                      float* limit_out, int grid_x, int grid_y, const GeomHeader* hdr, hipStream_t s, const float* slack_dev) {
   const int extra = limit_out ? ((int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y) + TO_THREADS - 1) / TO_THREADS : 0;
   hipLaunchKernelGGL(tile_order_kernel, dim3(8 + extra), dim3(TO_THREADS), 0, s, tile_work, tile_order, T, (T + 7) / 8, order_out,
-                     stop_depth, limit_out, grid_x, grid_y, hdr);
+                     stop_depth, limit_out, grid_x, grid_y, hdr, slack_dev);
   return 0;
 }

@@ -62,6 +62,7 @@ class GsScratch(C.Structure):
         ("binned", C.c_int32),
         ("_pad", C.c_int32),
         ("step_tag", C.c_void_p),
+        ("tile_depth_limit_slack", C.c_void_p),
     ]
 
 

@@ -224,6 +224,10 @@ class RasterBackend:
                 self.depth_limit_stats["failed"] += 1
                 if st[2] != 0 or "regions" not in d:
                     d["cache"]["limit_ok"] = False
+                if st[2] != 0:
+                    self.limits_failed(d["cache"])
+            elif d.get("limited", False):
+                self.limits_held(d["cache"])
             return ok
         return verdict
 
@@ -301,7 +305,9 @@ class RasterBackend:
             c = self._cam_cache[key] = dict(order=default_order.to(device), order_ok=False,
                                             limit=torch.full((int(self.api.raw("tile_depth_limit_floats")(W, H)),), float("inf"),
                                                              dtype=torch.float32, device=device),
-                                            limit_ok=False, key=key)
+                                            limit_ok=False, key=key,
+                                            # adaptive slack on the exported bounds (GsScratch.tile_depth_limit_slack)
+                                            slack=torch.ones((1,), dtype=torch.float32, device=device), slack_level=0, held=0)
         else:
             self.camera_cache_stats["hits"] += 1
         return c
@@ -319,6 +325,31 @@ class RasterBackend:
         if device_index is None:
             device_index = viewmatrix.device.index if viewmatrix is not None and viewmatrix.is_cuda else torch.cuda.current_device()
         return self._cam_cache.get((device_index, int(W), int(H), ident))
+
+    # Adaptive slack of a camera's depth bounds.  The fixed margin (5 % + 0.02 in view depth) holds while the model moves
+    # slowly between two visits of a camera (a run that is converging: 2 repeated views in 2 000 at C3); early in training,
+    # or on a target the model cannot fit, tiles keep saturating deeper than their last bound allowed (38 % repeated views
+    # on bench.py's unrelated target after a few hundred steps).  So the bounds a camera EXPORTS are multiplied by a factor
+    # that rises when its limits fail and falls again after they have held for a while: longer lists instead of repeats.
+    SLACK = (1.0, 1.25, 1.6, 2.5)
+    SLACK_RELAX_AFTER = 24
+
+    def limits_failed(self, c):
+        if c is None:
+            return
+        c["held"] = 0
+        if c["slack_level"] < len(self.SLACK) - 1:
+            c["slack_level"] += 1
+            c["slack"].fill_(self.SLACK[c["slack_level"]])
+
+    def limits_held(self, c):
+        if c is None:
+            return
+        c["held"] += 1
+        if c["held"] >= self.SLACK_RELAX_AFTER and c["slack_level"] > 0:
+            c["held"] = 0
+            c["slack_level"] -= 1
+            c["slack"].fill_(self.SLACK[c["slack_level"]])
 
     @staticmethod
     def _scratch(geom, img, binning, capacity):
@@ -401,6 +432,7 @@ class RasterBackend:
                 scratch.tile_order_out = cache["order"].data_ptr()
             if use_limit:
                 scratch.tile_depth_limit_out = cache["limit"].data_ptr()
+                scratch.tile_depth_limit_slack = cache["slack"].data_ptr()
             self._render(scratch, fsgs, extra, view, g, out_color, out_invdepth, out_extra, stream)
 
         def remember(scratch):
@@ -518,7 +550,7 @@ class RasterBackend:
                     self.api.call("forward_status", C.byref(s), block.data_ptr(), stream)
                     done = torch.cuda.Event()
                     done.record(cur)
-                    self.deferred = dict(status=block, event=done, cache=cache)
+                    self.deferred = dict(status=block, event=done, cache=cache, limited=True)
                     remember(s)
                     return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
                 self.api.call("forward_status", C.byref(s), status.data_ptr(), stream)
@@ -526,8 +558,10 @@ class RasterBackend:
                 if int(status[2]) != 0:  # some tile needed entries that were cut: forget the limits, do the view again
                     self.depth_limit_stats["failed"] += 1
                     cache["limit_ok"] = False
+                    self.limits_failed(cache)
                     del binning
                     continue
+                self.limits_held(cache)
             remember(s)
             return (num_rendered, out_color, radii, geom, binning, img, out_invdepth) + tail
 
@@ -615,8 +649,10 @@ class RasterBackend:
                 if int(status[2]) != 0:
                     self.depth_limit_stats["failed"] += 1
                     cache["limit_ok"] = False
+                    self.limits_failed(cache)
                     del binning
                     continue
+                self.limits_held(cache)
             remember(s)
             return num_rendered, binning
 

@@ -1388,6 +1388,7 @@ class GraphedStep:
             ent["limit_ok"] = False
             ent["limit"].fill_(float("inf"))
             be.depth_limit_stats["failed"] += 1
+            be.limits_failed(ent)     # (this camera's exported bounds get more slack: RasterBackend.SLACK)
         if overflow or num_rendered > self.capacity:
             self.graphs.clear()
             self.capacity = None   # (the eager step that follows grows the backend's hint; the next capture reads it)
@@ -1439,6 +1440,10 @@ class GraphedStep:
                 break
         num_rendered, overflow, trunc_failed = int(st[0]), int(st[1]), int(st[2])
         if num_rendered <= p["capacity"] and not overflow and not trunc_failed:
+            if tr.depth_limit:
+                ent = self.camera_entry(p["ci"])
+                if ent is not None and ent["limit_ok"]:
+                    be.limits_held(ent)
             return
         ci = p["ci"]
         self._invalidate(ci, (num_rendered, overflow, trunc_failed))
