@@ -1239,6 +1239,7 @@ class GraphedStep:
         self.capacity = None
         self.coef = None
         self.replays = self.eager_steps = self.captures = 0
+        self.fail_kinds = {"limits": 0, "capacity": 0}   # why replays had to be repeated eagerly
         self._replay_pending = None
         self.s_loss = None
 
@@ -1382,6 +1383,7 @@ class GraphedStep:
         eager step that follows measures new ones into the same buffers).  A view that did not fit the capacity: every
         graph was captured with that capacity - all go, the next capture sizes it from the backend's grown hint."""
         num_rendered, overflow, trunc_failed = status
+        self.fail_kinds["limits" if trunc_failed else "capacity"] += 1
         be = self._backend()
         ent = self.camera_entry(ci)
         if trunc_failed and ent is not None:

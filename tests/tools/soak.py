@@ -40,7 +40,8 @@ tr, scene, cams, gts = bench.build_workload(cfg, dev, 0, 1, gts=gts)
 tr.depth_limit = "deferred"
 be = hip_backend()
 k = 0
-for form in ("eager", "graph"):
+forms = ("graph", "eager") if (len(sys.argv) > 4 and sys.argv[4] == "graph_first") else ("eager", "graph")
+for form in forms:
     gs = GraphedStep(tr) if form == "graph" else None
     s0 = dict(be.depth_limit_stats)
     t0 = time.time()
@@ -62,5 +63,5 @@ for form in ("eager", "graph"):
     print("%s: %d steps, %.3f ms/step, loss %.5f -> %.5f, limited views %d, fall-backs %d, optimizer t %d, two-phase launches %d%s"
           % (form, n, dt / n * 1e3, losses[0], losses[-1], s1["used"] - s0["used"], s1["failed"] - s0["failed"],
              tr.model.optimizer.t, be.two_phase_launches,
-             "" if gs is None else ", captures %d, replays %d, eager steps %d" % (gs.captures, gs.replays, gs.eager_steps)))
+             "" if gs is None else ", captures %d, replays %d, eager steps %d, failures %r" % (gs.captures, gs.replays, gs.eager_steps, gs.fail_kinds)))
 print("max memory allocated %.2f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30))
