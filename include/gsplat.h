@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4
 
 /* error codes (negative = caller error) */
 #define GS_OK 0
@@ -205,13 +205,13 @@ int gs_forward_render_x(const GsView* view, const GsGaussians* g, GsScratch* scr
 /* Backward of the whole rasterizer.  num_rendered is the value forward produced.
  * dL_dinvdepth may be NULL (then no inverse-depth gradient path runs).
  * workspace: >= backward_workspace_bytes from gs_scratch_bytes.
- * Accuracy against the reference algorithm (fp32): every gradient within 1e-4 of its tensor's largest entry, EXCEPT
- * dL_dscales / dL_drotations, which pass through the chain conic -> cov2D -> cov3D -> (scale, quaternion)
- * (backward.cu:248-275, 330-393): for needle-shaped footprints it cancels 3-4 digits, the reference's own fp32 formula is
- * 1.0e-3 / 2.0e-3 of the tensor's max away from the float64 image of its inputs at 1 M Gaussians / 1080p, and this
- * implementation (csrc/gs_backward_math.h: the same chain factored without the `denom - a c` cancellation) 1.6e-4 / 2.7e-4
- * on the same sums.  Against the reference formula these two tensors therefore differ by up to 2.1e-3 of max (rms 8e-4);
- * tests/test_gpu_fullsize.py asserts 3e-3 / 1e-3 and the decomposition, DESIGN.md section 2 has the analysis. */
+ * Accuracy (fp32 outputs): every gradient tensor within 1e-4 of its largest entry of the reference algorithm evaluated
+ * in exact arithmetic on the same blend sums.  For dL_dscales / dL_drotations that is a stronger statement than "1e-4 of
+ * the reference's fp32 run": the chain conic -> cov2D -> cov3D -> (scale, quaternion) (backward.cu:248-275, 330-393)
+ * cancels 3-4 digits for needle-shaped footprints, and the reference's own fp32 formula is 1.0e-3 / 2.0e-3 of the
+ * tensor's max away from the float64 image of its inputs at 1 M Gaussians / 1080p.  Here the blend sums are accumulated
+ * in float64 rows and that chain is evaluated in float64 (csrc/gs_backward_math.h), so these two tensors are the exact
+ * image rounded once and repeat from run to run; tests/test_gpu_fullsize.py asserts it, DESIGN.md section 2 has the analysis. */
 int gs_backward(const GsView* view, const GsGaussians* g, const int32_t* radii,
                 const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
                 const float* dL_dinvdepth, const GsGrads* grads, void* workspace,
@@ -281,7 +281,7 @@ typedef struct GsStepState {
                                 passed as kernel arguments.  A caller that REPLAYS a captured graph of the step must use
                                 this form (kernel arguments are frozen at capture) and refresh the buffer before each
                                 replay; step[] then only says which rows are skipped. */
-  const float* rows_override; /* parity probe, normally NULL: [P,16] blend sums to use INSTEAD of running stage 1 (layout:
+  const double* rows_override; /* parity probe, normally NULL: [P,16] float64 blend sums to use INSTEAD of running stage 1 (layout:
                                 gs_backward_from_rows) - lets a test hand the fused tail and the three-kernel tail the
                                 very same sums and compare them bit for bit */
   /* ---- data-parallel form (N > 1): gradients OUT instead of the Adam step ----
@@ -330,13 +330,14 @@ int gs_step_uninstanced(const GsView* view, const GsGaussians* g, const int32_t*
                         const GsScratch* scratch, const GsStepState* st, void* stream);
 
 /* Stage 2 of gs_backward on its own (parity export): the per-Gaussian chain rule from given sums of the blend
- * backward.  rows [P,16] (device): mean2D.x, mean2D.y, conic.xx, conic.xy, conic.yy, opacity, r, g, b, depth slot,
+ * backward.  rows [P,16] FLOAT64 (device): mean2D.x, mean2D.y, conic.xx, conic.xy, conic.yy, opacity, r, g, b, depth slot,
  * 4th channel, 5 pad - what stage 1 leaves in the workspace (backward.cu:593-635 accumulates the same ten sums with
- * atomics).  depth_mode: 0 none, 1 the depth slot is dL/d(inverse depth) (dr_aa), 2 dL/d(depth) (FSGS generation).
+ * float atomics; here a tile's fp32 totals are added into float64 slots, so the sums do not depend on the order the
+ * tiles arrive in).  depth_mode: 0 none, 1 the depth slot is dL/d(inverse depth) (dr_aa), 2 dL/d(depth) (FSGS generation).
  * Lets a test feed both implementations the SAME sums and so separate the (ill-conditioned)
  * conic -> scale / rotation chain from the accumulation that precedes it. */
 int gs_backward_from_rows(const GsView* view, const GsGaussians* g, const int32_t* radii,
-                          const GsScratch* scratch, const float* rows, int32_t depth_mode,
+                          const GsScratch* scratch, const double* rows, int32_t depth_mode,
                           const GsGrads* grads, void* stream);
 
 /* The order in which the backward blend of this view takes its tiles: 8 * ceil(T/8) entries, entry b = the tile of

@@ -377,7 +377,7 @@ int gso_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R, size_t out[3],
   out[0] = geom_bytes((size_t)P);
   out[1] = img_bytes((size_t)W * H, T);
   out[2] = binning_bytes((size_t)std::max<int64_t>(R, 1));
-  if (bwd_ws) *bwd_ws = 256 + (size_t)P * 16 * sizeof(float); /* receives the blend-backward sums (parity probe) */
+  if (bwd_ws) *bwd_ws = 256 + (size_t)P * 16 * sizeof(double); /* receives the blend-backward sums (parity probe) */
   return GS_OK;
 }
 
@@ -913,6 +913,135 @@ static void computeCov3D_bwd(int idx, V3 scl, float mod, V4 rot, const float* dL
   dL_drots[4 * idx + 3] = qw;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * The reference's conic -> cov2D -> cov3D -> (scale, quaternion) chain (backward.cu:162-275 and :330-393, the statements
+ * of computeCov2D_bwd / computeCov3D_bwd above) evaluated in DOUBLE from the fp32 parameters and the double sums: the
+ * reference algorithm in (practically) exact arithmetic.  Arbiter for dL_dscales / dL_drotations / dL_dcov3D, for which
+ * the fp32 run above is 2e-4 ... 2e-3 of the tensor's largest entry away from this image on needle-shaped footprints
+ * (tests/test_gpu_fullsize.py).  Switched on with gso_set_exact_chain(1); off by default - the fp32
+ * transcription stays what "the oracle" means everywhere else.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static int g_exact_chain = 0;
+struct M3d {
+  double c[3][3]; /* c[col][row], as M3 */
+};
+static inline M3d mat3d_cols(double a0, double a1, double a2, double b0, double b1, double b2, double c0, double c1, double c2) {
+  M3d m;
+  m.c[0][0] = a0; m.c[0][1] = a1; m.c[0][2] = a2;
+  m.c[1][0] = b0; m.c[1][1] = b1; m.c[1][2] = b2;
+  m.c[2][0] = c0; m.c[2][1] = c1; m.c[2][2] = c2;
+  return m;
+}
+static inline M3d muld(const M3d& A, const M3d& B) {
+  M3d R;
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) R.c[c][r] = A.c[0][r] * B.c[c][0] + A.c[1][r] * B.c[c][1] + A.c[2][r] * B.c[c][2];
+  return R;
+}
+static inline M3d transposed(const M3d& A) {
+  M3d R;
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) R.c[c][r] = A.c[r][c];
+  return R;
+}
+static inline M3d quat_to_Rd(V4 q) {
+  const double r = q.x, x = q.y, y = q.z, z = q.w;
+  return mat3d_cols(1. - 2. * (y * y + z * z), 2. * (x * y - r * z), 2. * (x * z + r * y), 2. * (x * y + r * z),
+                    1. - 2. * (x * x + z * z), 2. * (y * z - r * x), 2. * (x * z - r * y), 2. * (y * z + r * x),
+                    1. - 2. * (x * x + y * y));
+}
+/* dL_dconic (double sums) -> dL_dcov3D[6] (double), backward.cu:162-275 */
+static void exact_chain_cov2d(int idx, const GsView* v, const GsGaussians* g, const float* cov3D_given, double h_x, double h_y,
+                              const double dL_dconic[3], double dL_dopacity_v, double dL_dcov[6]) {
+  const float* vm = v->viewmatrix;
+  const double mx = g->means3D[3 * idx], my = g->means3D[3 * idx + 1], mz = g->means3D[3 * idx + 2];
+  double tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+  double ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+  const double tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+  const double limx = 1.3 * (double)v->tanfovx, limy = 1.3 * (double)v->tanfovy;
+  tx = fmin(limx, fmax(-limx, tx / tz)) * tz;
+  ty = fmin(limy, fmax(-limy, ty / tz)) * tz;
+  const M3d J = mat3d_cols(h_x / tz, 0.0, -(h_x * tx) / (tz * tz), 0.0, h_y / tz, -(h_y * ty) / (tz * tz), 0, 0, 0);
+  const M3d W = mat3d_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+  const M3d T = muld(W, J);
+  M3d Vrk;
+  if (g->scales) { /* forward.cu:114-148 in double */
+    const double mod = v->scale_modifier;
+    M3d S = mat3d_cols(mod * g->scales[3 * idx], 0, 0, 0, mod * g->scales[3 * idx + 1], 0, 0, 0, mod * g->scales[3 * idx + 2]);
+    const V4 rq = {g->rotations[4 * idx], g->rotations[4 * idx + 1], g->rotations[4 * idx + 2], g->rotations[4 * idx + 3]};
+    const M3d M = muld(S, quat_to_Rd(rq));
+    Vrk = muld(transposed(M), M);
+  } else {
+    const float* c = cov3D_given + 6 * (size_t)idx;
+    Vrk = mat3d_cols(c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]);
+  }
+  const M3d cov2D = muld(muld(transposed(T), transposed(Vrk)), T);
+  double c_xx = cov2D.c[0][0], c_xy = cov2D.c[0][1], c_yy = cov2D.c[1][1];
+  const double h_var = 0.3;
+  double dL_dc_xx = 0, dL_dc_xy = 0, dL_dc_yy = 0;
+  if (v->antialiasing) {
+    const double det_cov = c_xx * c_yy - c_xy * c_xy;
+    c_xx += h_var;
+    c_yy += h_var;
+    const double det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
+    const double hcs = sqrt(fmax(0.000025, det_cov / det_cov_plus_h_cov));
+    const double d_hcs = dL_dopacity_v * (double)g->opacities[idx];
+    const double d_inside_root = (det_cov / det_cov_plus_h_cov) <= 0.000025 ? 0. : d_hcs / (2 * hcs);
+    const double x = c_xx, y = c_yy, z = c_xy, w = h_var;
+    const double q = w * w + w * (x + y) + x * y - z * z;
+    const double denom_f = d_inside_root / (q * q);
+    dL_dc_xx = w * (w * y + y * y + z * z) * denom_f;
+    dL_dc_yy = w * (w * x + x * x + z * z) * denom_f;
+    dL_dc_xy = -2. * w * z * (w + x + y) * denom_f;
+  } else {
+    c_xx += h_var;
+    c_yy += h_var;
+  }
+  const double denom = c_xx * c_yy - c_xy * c_xy;
+  const double denom2inv = 1.0 / ((denom * denom) + 0.0000001);
+  const float denomf = (float)denom; /* the reference's own `denom2inv != 0` test is an fp32 underflow test */
+  if (1.0f / ((denomf * denomf) + 0.0000001f) != 0) {
+    dL_dc_xx += denom2inv * (-c_yy * c_yy * dL_dconic[0] + 2 * c_xy * c_yy * dL_dconic[1] + (denom - c_xx * c_yy) * dL_dconic[2]);
+    dL_dc_yy += denom2inv * (-c_xx * c_xx * dL_dconic[2] + 2 * c_xx * c_xy * dL_dconic[1] + (denom - c_xx * c_yy) * dL_dconic[0]);
+    dL_dc_xy += denom2inv * 2 * (c_xy * c_yy * dL_dconic[0] - (denom + 2 * c_xy * c_xy) * dL_dconic[1] + c_xx * c_xy * dL_dconic[2]);
+    dL_dcov[0] = (T.c[0][0] * T.c[0][0] * dL_dc_xx + T.c[0][0] * T.c[1][0] * dL_dc_xy + T.c[1][0] * T.c[1][0] * dL_dc_yy);
+    dL_dcov[3] = (T.c[0][1] * T.c[0][1] * dL_dc_xx + T.c[0][1] * T.c[1][1] * dL_dc_xy + T.c[1][1] * T.c[1][1] * dL_dc_yy);
+    dL_dcov[5] = (T.c[0][2] * T.c[0][2] * dL_dc_xx + T.c[0][2] * T.c[1][2] * dL_dc_xy + T.c[1][2] * T.c[1][2] * dL_dc_yy);
+    dL_dcov[1] = 2 * T.c[0][0] * T.c[0][1] * dL_dc_xx + (T.c[0][0] * T.c[1][1] + T.c[0][1] * T.c[1][0]) * dL_dc_xy + 2 * T.c[1][0] * T.c[1][1] * dL_dc_yy;
+    dL_dcov[2] = 2 * T.c[0][0] * T.c[0][2] * dL_dc_xx + (T.c[0][0] * T.c[1][2] + T.c[0][2] * T.c[1][0]) * dL_dc_xy + 2 * T.c[1][0] * T.c[1][2] * dL_dc_yy;
+    dL_dcov[4] = 2 * T.c[0][2] * T.c[0][1] * dL_dc_xx + (T.c[0][1] * T.c[1][2] + T.c[0][2] * T.c[1][1]) * dL_dc_xy + 2 * T.c[1][1] * T.c[1][2] * dL_dc_yy;
+  } else {
+    for (int i = 0; i < 6; i++) dL_dcov[i] = 0;
+  }
+}
+/* backward.cu:330-393 in double */
+static void exact_chain_cov3d(int idx, const GsView* v, const GsGaussians* g, const double d[6], float* dL_dscales, float* dL_drots) {
+  const V4 rot = {g->rotations[4 * idx], g->rotations[4 * idx + 1], g->rotations[4 * idx + 2], g->rotations[4 * idx + 3]};
+  const double r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+  const M3d R = quat_to_Rd(rot);
+  const double mod = v->scale_modifier;
+  const double sx = mod * g->scales[3 * idx], sy = mod * g->scales[3 * idx + 1], sz = mod * g->scales[3 * idx + 2];
+  const M3d S = mat3d_cols(sx, 0, 0, 0, sy, 0, 0, 0, sz);
+  M3d M = muld(S, R);
+  const M3d dL_dSigma = mat3d_cols(d[0], 0.5 * d[1], 0.5 * d[2], 0.5 * d[1], d[3], 0.5 * d[4], 0.5 * d[2], 0.5 * d[4], d[5]);
+  for (int c = 0; c < 3; c++)
+    for (int k = 0; k < 3; k++) M.c[c][k] *= 2.0;
+  const M3d dL_dM = muld(M, dL_dSigma);
+  const M3d Rt = transposed(R);
+  M3d D = transposed(dL_dM);
+  for (int j = 0; j < 3; j++)
+    dL_dscales[3 * idx + j] = (float)(Rt.c[j][0] * D.c[j][0] + Rt.c[j][1] * D.c[j][1] + Rt.c[j][2] * D.c[j][2]);
+  for (int k = 0; k < 3; k++) {
+    D.c[0][k] *= sx;
+    D.c[1][k] *= sy;
+    D.c[2][k] *= sz;
+  }
+  dL_drots[4 * idx + 0] = (float)(2 * z * (D.c[0][1] - D.c[1][0]) + 2 * y * (D.c[2][0] - D.c[0][2]) + 2 * x * (D.c[1][2] - D.c[2][1]));
+  dL_drots[4 * idx + 1] = (float)(2 * y * (D.c[1][0] + D.c[0][1]) + 2 * z * (D.c[2][0] + D.c[0][2]) + 2 * r * (D.c[1][2] - D.c[2][1]) - 4 * x * (D.c[2][2] + D.c[1][1]));
+  dL_drots[4 * idx + 2] = (float)(2 * x * (D.c[1][0] + D.c[0][1]) + 2 * r * (D.c[2][0] - D.c[0][2]) + 2 * z * (D.c[1][2] + D.c[2][1]) - 4 * y * (D.c[2][2] + D.c[0][0]));
+  dL_drots[4 * idx + 3] = (float)(2 * r * (D.c[0][1] - D.c[1][0]) + 2 * x * (D.c[2][0] + D.c[0][2]) + 2 * y * (D.c[1][2] + D.c[2][1]) - 4 * z * (D.c[1][1] + D.c[0][0]));
+}
+
 /* backward.cu:398-449 */
 static void preprocess_bwd_one(int idx, int D, int M, const GsView* v, const GsGaussians* g,
                                const int* radii, const uint8_t* clamped, const float* dL_dmean2D /*[P][3]*/,
@@ -955,7 +1084,7 @@ static void preprocess_bwd_one(int idx, int D, int M, const GsView* v, const GsG
  * of the blend backward, rows [P][16] = mean2D.x, mean2D.y, conic.xx, conic.xy, conic.yy, opacity, r, g, b, depth slot.
  * depth_mode: 0 none, 1 inverse depth (dr_aa), 2 depth (FSGS generation). */
 static void stage2_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const Geom& gs,
-                             const float* rows, int depth_mode, const GsGrads* out) {
+                             const double* rows, int depth_mode, const GsGrads* out) {
   const int P = g->P, W = v->image_width, H = v->image_height, M = g->M;
   const float focal_y = H / (2.0f * v->tanfovy);
   const float focal_x = W / (2.0f * v->tanfovx);
@@ -963,17 +1092,18 @@ static void stage2_from_rows(const GsView* v, const GsGaussians* g, const int32_
       dL_dcolors((size_t)P * 3, 0.f), dL_dinvd(P, 0.f), dL_dmeans3D((size_t)P * 3, 0.f), dL_dcov3D((size_t)P * 6, 0.f),
       dL_dsh((size_t)P * std::max(M, 1) * 3, 0.f), dL_dscales((size_t)P * 3, 0.f), dL_drot((size_t)P * 4, 0.f);
   for (int i = 0; i < P; i++) {
-    const float* a = rows + (size_t)i * 16;
-    dL_dmean2D[3 * i] = a[A_MX];
-    dL_dmean2D[3 * i + 1] = a[A_MY];
-    dL_dconic[3 * i] = a[A_CXX];
-    dL_dconic[3 * i + 1] = a[A_CXY];
-    dL_dconic[3 * i + 2] = a[A_CYY];
-    dL_dopacity[i] = a[A_OP];
-    dL_dcolors[3 * i] = a[A_CR];
-    dL_dcolors[3 * i + 1] = a[A_CG];
-    dL_dcolors[3 * i + 2] = a[A_CB];
-    dL_dinvd[i] = a[A_ID];
+    /* the reference's gradient tensors are fp32 (rasterize_points.cu:163-178): each sum is rounded ONCE here */
+    const double* a = rows + (size_t)i * 16;
+    dL_dmean2D[3 * i] = (float)a[A_MX];
+    dL_dmean2D[3 * i + 1] = (float)a[A_MY];
+    dL_dconic[3 * i] = (float)a[A_CXX];
+    dL_dconic[3 * i + 1] = (float)a[A_CXY];
+    dL_dconic[3 * i + 2] = (float)a[A_CYY];
+    dL_dopacity[i] = (float)a[A_OP];
+    dL_dcolors[3 * i] = (float)a[A_CR];
+    dL_dcolors[3 * i + 1] = (float)a[A_CG];
+    dL_dcolors[3 * i + 2] = (float)a[A_CB];
+    dL_dinvd[i] = (float)a[A_ID];
   }
   const float* cov3D_ptr = g->cov3D_precomp ? g->cov3D_precomp : gs.cov3D;
   const float* dinvd_ptr = depth_mode == 1 ? dL_dinvd.data() : nullptr;
@@ -986,6 +1116,18 @@ static void stage2_from_rows(const GsView* v, const GsGaussians* g, const int32_
     preprocess_bwd_one(i, v->sh_degree, M, v, g, radii, gs.clamped, dL_dmean2D.data(), dL_dmeans3D.data(),
                        dL_dcolors.data(), dL_dcov3D.data(), dL_dsh.data(), dL_dscales.data(), dL_drot.data(),
                        depth_mode == 2 ? dL_dinvd.data() : nullptr);
+  if (g_exact_chain) { /* dL_dcov3D / dL_dscales / dL_drotations: the same statements in double (see exact_chain_*) */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+      if (!(radii[i] > 0)) continue;
+      const double* a = rows + (size_t)i * 16;
+      const double dconic[3] = {a[A_CXX], a[A_CXY], a[A_CYY]};
+      double dcov[6];
+      exact_chain_cov2d(i, v, g, cov3D_ptr, (double)focal_x, (double)focal_y, dconic, a[A_OP], dcov);
+      for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = (float)dcov[k];
+      if (g->scales) exact_chain_cov3d(i, v, g, dcov, dL_dscales.data(), dL_drot.data());
+    }
+  }
   if (out->dL_dmeans3D) memcpy(out->dL_dmeans3D, dL_dmeans3D.data(), 12 * (size_t)P);
   if (out->dL_dmeans2D) memcpy(out->dL_dmeans2D, dL_dmean2D.data(), 12 * (size_t)P);
   if (out->dL_dsh && M > 0) memcpy(out->dL_dsh, dL_dsh.data(), 12 * (size_t)P * M);
@@ -997,7 +1139,7 @@ static void stage2_from_rows(const GsView* v, const GsGaussians* g, const int32_
 }
 
 int gso_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
-                           const float* rows, int32_t depth_mode, const GsGrads* out, void* /*stream*/) {
+                           const double* rows, int32_t depth_mode, const GsGrads* out, void* /*stream*/) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!s || !out) return GS_E_NULL;
@@ -1073,18 +1215,19 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
         }
     }
   }
-  /* the per-Gaussian sums (double accumulators rounded once) in the product's 16-float row layout */
-  std::vector<float> rows_own;
-  float* rows = nullptr;
-  if (ws && ws_bytes >= (size_t)P * 16 * sizeof(float)) {
-    rows = (float*)ws; /* parity probe: a test can compare this intermediate with the product's workspace */
+  /* the per-Gaussian sums (double accumulators; stage 2 rounds each once to the reference's fp32 gradient tensors) in
+   * the product's row layout: 16 float64 slots per Gaussian */
+  std::vector<double> rows_own;
+  double* rows = nullptr;
+  if (ws && ws_bytes >= (size_t)P * 16 * sizeof(double)) {
+    rows = (double*)ws; /* parity probe: a test can compare this intermediate with the product's workspace */
   } else {
     rows_own.resize((size_t)P * 16);
     rows = rows_own.data();
   }
   for (int i = 0; i < P; i++) {
     const double* a = &acc[(size_t)i * A_N];
-    for (int k = 0; k < 16; k++) rows[(size_t)i * 16 + k] = k < A_N ? (float)a[k] : 0.f;
+    for (int k = 0; k < 16; k++) rows[(size_t)i * 16 + k] = k < A_N ? a[k] : 0.0;
   }
   stage2_from_rows(v, g, radii, gs, rows, fs_dL_dalpha ? 2 : (dL_dinvdepth_img ? 1 : 0), out);
   return GS_OK;
@@ -1198,6 +1341,14 @@ int gso_test_project(int32_t P, const float* means, const float* projmatrix, flo
 int gso_set_fsgs_exact_T(int32_t on) {
   g_fsgs_exact_T = on != 0;
   return GS_OK;
+}
+
+/* 1: stage 2 evaluates the conic -> covariance -> (scale, quaternion) chain in double (exact_chain_*): the arbiter for
+ * dL_dscales / dL_drotations / dL_dcov3D.  Returns the previous setting. */
+int gso_set_exact_chain(int32_t on) {
+  const int old = g_exact_chain;
+  g_exact_chain = on != 0;
+  return old;
 }
 
 int gso_set_num_threads(int32_t n) {

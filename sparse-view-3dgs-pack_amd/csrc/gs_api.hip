@@ -74,7 +74,7 @@ int gs_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R_capacity, size_t
   out[0] = geom_bytes((size_t)P);
   out[1] = img_bytes((size_t)W * H, T);
   out[2] = bin_bytes((size_t)R_capacity);
-  if (bwd_ws) *bwd_ws = gs_align((size_t)P * GR_STRIDE * sizeof(float));
+  if (bwd_ws) *bwd_ws = gs_align((size_t)P * GR_ROW_BYTES);
   return GS_OK;
 }
 
@@ -329,7 +329,7 @@ int gs_backward_fsgs(const GsView* v, const GsGaussians* g, const int32_t* radii
 }
 
 static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians* g, const int32_t* radii, const GeomView& gv,
-                                             int depth_mode, const float* rows, const GsGrads* grads) {
+                                             int depth_mode, const gs_row_t* rows, const GsGrads* grads) {
   PreprocessBwdArgs a;
   a.P = g->P;
   a.D = v->sh_degree;
@@ -406,7 +406,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   const int P = g->P, W = v->image_width, H = v->image_height;
   if (P == 0) return GS_OK;
   if (!radii || !sc->geom || !sc->img || !workspace) return GS_E_NULL;
-  if (workspace_bytes < (size_t)P * GR_STRIDE * sizeof(float)) return GS_E_SCRATCH;
+  if (workspace_bytes < (size_t)P * GR_ROW_BYTES) return GS_E_SCRATCH;
   if (num_rendered < 0 || num_rendered > sc->binning_capacity) return GS_E_SHAPE;
   if (num_rendered > 0 && !sc->binning) return GS_E_NULL;
   hipStream_t s = (hipStream_t)stream;
@@ -416,12 +416,12 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   GeomView gv = geom_view(sc->geom, (size_t)P);
   ImgView iv = img_view(sc->img, N, T);
   SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
-  float* rows = (float*)workspace;
+  gs_row_t* rows = (gs_row_t*)workspace;
   const bool given_rows = step && step->rows_override;
   if (step && (step->rows_clean < 0 || step->rows_clean > 2)) return GS_E_SHAPE;
   const int rows_clean = (step && !given_rows) ? step->rows_clean : 0;
   if (given_rows) {
-    rows = const_cast<float*>(step->rows_override);
+    rows = const_cast<gs_row_t*>(step->rows_override);
   } else if (rows_clean != 2) {  // (2: the previous step's per-Gaussian kernel left every row zero)
     GS_PROF(ST_BWD_MEMSET, s);
     launch_zero_rows(rows, (size_t)P, v->tile_cull ? gv.tiles_touched : nullptr, s);
@@ -500,7 +500,7 @@ int gs_step_uninstanced(const GsView* v, const GsGaussians* g, const int32_t* ra
   return GS_OK;
 }
 
-int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, const float* rows,
+int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, const double* rows,
                           int32_t depth_mode, const GsGrads* grads, void* stream) {
   int rc = check_args(v, g);
   if (rc) return rc;

@@ -44,8 +44,18 @@ struct ShSink {
 //   a0, a1       rows of the 2x3 screen Jacobian A = J W:  a0 = j00 w0 + j02 w2,  a1 = j11 w1 + j12 w2
 //   Sigma        3D covariance (symmetric), p = Sigma a0, q = Sigma a1
 //   cov2D        (a, b, c) = (a0.p, a0.q, a1.q)  (+0.3 on the diagonal)
-// Values agree with backward.cu to fp32 rounding (the parity tests compare against the oracle's transcription of it);
 // the reference's deliberate deviations from plain calculus are kept and marked "quirk".
+//
+// ROUND 4: the covariance chain runs in FLOAT64.  conic -> cov2D -> cov3D -> (scale, quaternion) (backward.cu:248-275,
+// 330-393) is ill-conditioned: dL/dcov2D = -conic Gc conic cancels 3-4 digits for a needle-shaped footprint (det / trace^2
+// ~ 6e-4 at the worst Gaussian of the 1 M / 1080p workload), so ANY fp32 evaluation - the reference's formula or a better
+// factored one - sits 2e-4 ... 2e-3 of the tensor's largest entry away from the exact image of its own inputs, and a
+// 3e-7 run-to-run jitter of the conic sums (float atomics) became 1e-3 on dL_drotations.  The blend backward now accumulates
+// its per-tile totals into float64 rows (global_atomic_add_f64: sums of fp32 terms are exact in a 53-bit accumulator unless
+// the terms span more than ~2^20 in magnitude, hence independent of the order they arrive in), and the ~300 flop per
+// Gaussian with instances of this chain are evaluated in double from the fp32 PARAMETERS (Sigma and cov2D are recomputed,
+// not read back rounded): results are the float64 image of the sums, rounded once.  The kernel is HBM-bound and the chain
+// runs for a fifth of the Gaussians: no measurable cost.
 // ---------------------------------------------------------------------------------------------------------------
 struct Sym3 {  // symmetric 3x3, every entry counted once
   float xx, xy, xz, yy, yz, zz;
@@ -54,6 +64,18 @@ GS_DEV V3 sym_mul(const Sym3& S, V3 v) {
   return {S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z, S.xz * v.x + S.yz * v.y + S.zz * v.z};
 }
 GS_DEV V3 axpby(float a, V3 x, float b, V3 y) { return {a * x.x + b * y.x, a * x.y + b * y.y, a * x.z + b * y.z}; }
+
+struct D3 {
+  double x, y, z;
+};
+struct SymD {  // symmetric 3x3 in double, every entry counted once
+  double xx, xy, xz, yy, yz, zz;
+};
+GS_DEV double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+GS_DEV D3 dsym_mul(const SymD& S, D3 v) {
+  return {S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z, S.xz * v.x + S.yz * v.y + S.zz * v.z};
+}
+GS_DEV D3 daxpby(double a, D3 x, double b, D3 y) { return {a * x.x + b * y.x, a * x.y + b * y.y, a * x.z + b * y.z}; }
 
 // Gradient of the real-SH colour w.r.t. the SH coefficients and the view vector (replaces backward.cu:23-142).
 // The three colour channels share one basis, so the direction gradient only needs the 16 scalars
@@ -118,114 +140,142 @@ GS_DEV V3 sh_backward(int deg, V3 pos, V3 campos, const SH& sh, uint32_t clamped
   return inv_len * (grad - along * d);
 }
 
+// Sigma = R diag(s)^2 R^T in double from the fp32 parameters (forward.cu:114-148 forms it in fp32 and stores it rounded;
+// the exact image of the gradient is taken at the parameters, so the chain recomputes it), s = scale_modifier * scale,
+// R(q) the rotation matrix of the quaternion q = (r, x, y, z) taken as given (forward.cu:123: no normalisation).
+struct RotD {
+  D3 c0, c1, c2;  // columns of R
+};
+GS_DEV RotD quat_to_Rd(V4 quat) {
+  const double r = quat.x, x = quat.y, y = quat.z, z = quat.w;
+  RotD R;
+  R.c0 = {1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y + r * z), 2.0 * (x * z - r * y)};
+  R.c1 = {2.0 * (x * y - r * z), 1.0 - 2.0 * (x * x + z * z), 2.0 * (y * z + r * x)};
+  R.c2 = {2.0 * (x * z + r * y), 2.0 * (y * z - r * x), 1.0 - 2.0 * (x * x + y * y)};
+  return R;
+}
+GS_DEV SymD sigma_from_scale_rot(D3 s, const RotD& R) {
+  const double s0 = s.x * s.x, s1 = s.y * s.y, s2 = s.z * s.z;
+  return {s0 * R.c0.x * R.c0.x + s1 * R.c1.x * R.c1.x + s2 * R.c2.x * R.c2.x,
+          s0 * R.c0.x * R.c0.y + s1 * R.c1.x * R.c1.y + s2 * R.c2.x * R.c2.y,
+          s0 * R.c0.x * R.c0.z + s1 * R.c1.x * R.c1.z + s2 * R.c2.x * R.c2.z,
+          s0 * R.c0.y * R.c0.y + s1 * R.c1.y * R.c1.y + s2 * R.c2.y * R.c2.y,
+          s0 * R.c0.y * R.c0.z + s1 * R.c1.y * R.c1.z + s2 * R.c2.y * R.c2.z,
+          s0 * R.c0.z * R.c0.z + s1 * R.c1.z * R.c1.z + s2 * R.c2.z * R.c2.z};
+}
+
 // Backward of cov2D = A Sigma A^T + 0.3 I and of the anti-aliasing opacity factor (replaces backward.cu:147-326): from
 // the conic gradient (per matrix entry: the blend stage accumulates HALF the derivative w.r.t. the off-diagonal
-// coefficient) to G = dL/dSigma (symmetric, per entry) and dL/dmean through the Jacobian's dependence on t.
+// coefficient) to G = dL/dSigma (symmetric, per entry) and dL/dmean through the Jacobian's dependence on t.  All in double.
 struct Cov2DBack {
-  Sym3 G;
+  SymD G;
   V3 dmean;
   float dop;  // dL_dopacity after the anti-aliasing factor
 };
-GS_DEV Cov2DBack cov2d_backward(V3 mean, const float* c3, const float* vm, float fx, float fy, float tan_fovx,
-                                float tan_fovy, V3 g_conic /* xx, xy, yy */, float g_opacity, float opacity_raw,
-                                bool antialiasing, float g_invdepth /* dL/d(1/t.z), 0 if unused */) {
+GS_DEV Cov2DBack cov2d_backward(V3 mean, const SymD& Sg, const float* vm, float focal_x, float focal_y, float tan_fovx,
+                                float tan_fovy, D3 g_conic /* xx, xy, yy */, float g_opacity, float opacity_raw,
+                                bool antialiasing, double g_invdepth /* dL/d(1/t.z), 0 if unused */) {
   Cov2DBack o;
+  const double fx = focal_x, fy = focal_y;
   // view-space mean, clamped exactly as the forward clamps it (forward.cu:81-87); a clamped coordinate gets no gradient
-  V3 t = xform4x3(mean, vm);
-  const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-  const float rx = t.x / t.z, ry = t.y / t.z;
+  const double mx = mean.x, my = mean.y, mz = mean.z;
+  D3 t = {vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12], vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13],
+          vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14]};
+  const double limx = 1.3 * (double)tan_fovx, limy = 1.3 * (double)tan_fovy;
+  const double rx = t.x / t.z, ry = t.y / t.z;
   const bool free_x = !(rx < -limx || rx > limx), free_y = !(ry < -limy || ry > limy);
-  t.x = fminf(limx, fmaxf(-limx, rx)) * t.z;
-  t.y = fminf(limy, fmaxf(-limy, ry)) * t.z;
-  const float iz = 1.0f / t.z, iz2 = iz * iz;
-  const float j00 = fx * iz, j11 = fy * iz, j02 = -(fx * t.x) * iz2, j12 = -(fy * t.y) * iz2;
-  const V3 w0 = {vm[0], vm[4], vm[8]}, w1 = {vm[1], vm[5], vm[9]}, w2 = {vm[2], vm[6], vm[10]};
-  const V3 a0 = axpby(j00, w0, j02, w2), a1 = axpby(j11, w1, j12, w2);
-  const Sym3 Sg = {c3[0], c3[1], c3[2], c3[3], c3[4], c3[5]};
-  const V3 p = sym_mul(Sg, a0), q = sym_mul(Sg, a1);
-  float a = dot3(a0, p), b = dot3(a0, q), c = dot3(a1, q);
-  const float lowpass = 0.3f;
-  float ga = 0.f, gb = 0.f, gc = 0.f;  // dL/da, dL/db (b as ONE scalar filling both off-diagonal entries), dL/dc
+  t.x = fmin(limx, fmax(-limx, rx)) * t.z;
+  t.y = fmin(limy, fmax(-limy, ry)) * t.z;
+  const double iz = 1.0 / t.z, iz2 = iz * iz;
+  const double j00 = fx * iz, j11 = fy * iz, j02 = -(fx * t.x) * iz2, j12 = -(fy * t.y) * iz2;
+  const D3 w0 = {vm[0], vm[4], vm[8]}, w1 = {vm[1], vm[5], vm[9]}, w2 = {vm[2], vm[6], vm[10]};
+  const D3 a0 = daxpby(j00, w0, j02, w2), a1 = daxpby(j11, w1, j12, w2);
+  const D3 p = dsym_mul(Sg, a0), q = dsym_mul(Sg, a1);
+  double a = ddot(a0, p), b = ddot(a0, q), c = ddot(a1, q);
+  const double lowpass = 0.3;
+  double ga = 0.0, gb = 0.0, gc = 0.0;  // dL/da, dL/db (b as ONE scalar filling both off-diagonal entries), dL/dc
   o.dop = g_opacity;
   if (antialiasing) {
     // opacity' = opacity * sqrt(max(2.5e-5, det(cov) / det(cov + 0.3 I))), forward.cu:228-234
-    const float det0 = a * c - b * b;
+    const double det0 = a * c - b * b;
     a += lowpass;
     c += lowpass;
-    const float det1 = a * c - b * b;
-    const float ratio = det0 / det1;
-    const float h = sqrtf(fmaxf(0.000025f, ratio));
-    o.dop = g_opacity * h;
-    const float g_ratio = ratio <= 0.000025f ? 0.f : (g_opacity * opacity_raw) / (2.f * h);
+    const double det1 = a * c - b * b;
+    const double ratio = det0 / det1;
+    const double h = sqrt(fmax(0.000025, ratio));
+    o.dop = (float)((double)g_opacity * h);
+    const double g_ratio = ratio <= 0.000025 ? 0.0 : ((double)g_opacity * (double)opacity_raw) / (2.0 * h);
     // quirk (backward.cu:235-245): d(ratio)/d(a, b, c) in the closed form that is exact at the UN-shifted diagonal, but
     // evaluated at the shifted one.  With k = 0.3:  d/da = k (c^2 + k c + b^2) / D^2,  d/db = -2 k b (a + c + k) / D^2,
     // D = det + k (a + c) + k^2
-    const float D = lowpass * lowpass + lowpass * (a + c) + a * c - b * b;
-    const float f = g_ratio / (D * D);
+    const double D = lowpass * lowpass + lowpass * (a + c) + a * c - b * b;
+    const double f = g_ratio / (D * D);
     ga = lowpass * (lowpass * c + c * c + b * b) * f;
     gc = lowpass * (lowpass * a + a * a + b * b) * f;
-    gb = -2.f * lowpass * b * (lowpass + a + c) * f;
+    gb = -2.0 * lowpass * b * (lowpass + a + c) * f;
   } else {
     a += lowpass;
     c += lowpass;
   }
   // conic = inverse of [[a, b], [b, c]]:  dL/dcov2D = -conic Gc conic = -(adj Gc adj) / det^2,  adj = [[c, -b], [-b, a]];
   // 1/det^2 carries the reference's regulariser (backward.cu:252)
-  const float det = a * c - b * b;
-  const float k = 1.0f / (det * det + 0.0000001f);
-  const bool conic_part = k != 0.f;
+  const double det = a * c - b * b;
+  const double k = 1.0 / (det * det + 0.0000001);
+  // quirk (backward.cu:253): the reference leaves dL_dcov3D zero when ITS fp32 reciprocal underflows (det^2 = inf)
+  const float detf = (float)det;
+  const bool conic_part = (1.0f / (detf * detf + 0.0000001f)) != 0.f;
   if (conic_part) {
-    const float x00 = g_conic.x * c - g_conic.y * b, x01 = g_conic.y * a - g_conic.x * b;  // Gc adj
-    const float x10 = g_conic.y * c - g_conic.z * b, x11 = g_conic.z * a - g_conic.y * b;
+    const double x00 = g_conic.x * c - g_conic.y * b, x01 = g_conic.y * a - g_conic.x * b;  // Gc adj
+    const double x10 = g_conic.y * c - g_conic.z * b, x11 = g_conic.z * a - g_conic.y * b;
     ga -= k * (c * x00 - b * x10);
     gc -= k * (a * x11 - b * x01);
-    gb -= 2.f * k * (c * x01 - b * x11);
+    gb -= 2.0 * k * (c * x01 - b * x11);
+  }
+  // (the mean gradient first: p and q die here, before the six entries of G come alive - the kernel has 128 VGPRs)
+  // rows of A:  dL/da0 = 2 ga p + gb q,  dL/da1 = gb p + 2 gc q;  A = J W gives the four non-zero entries of J
+  {
+    const D3 dA0 = daxpby(2.0 * ga, p, gb, q), dA1 = daxpby(gb, p, 2.0 * gc, q);
+    const double dj00 = ddot(w0, dA0), dj02 = ddot(w2, dA0), dj11 = ddot(w1, dA1), dj12 = ddot(w2, dA1);
+    // J = [[fx/z, 0, -fx x/z^2], [0, fy/z, -fy y/z^2]];  quirk (backward.cu:310-313): in d/dz the clamped x, y are treated
+    // as constants although they were formed as (clamped ratio) * z
+    const double iz3 = iz2 * iz;
+    const double dtx = free_x ? -fx * iz2 * dj02 : 0.0;
+    const double dty = free_y ? -fy * iz2 * dj12 : 0.0;
+    const double dtz = -fx * iz2 * dj00 - fy * iz2 * dj11 + 2.0 * fx * t.x * iz3 * dj02 + 2.0 * fy * t.y * iz3 * dj12 -
+                       g_invdepth * iz2;
+    o.dmean = {(float)(dtx * w0.x + dty * w1.x + dtz * w2.x), (float)(dtx * w0.y + dty * w1.y + dtz * w2.y),
+               (float)(dtx * w0.z + dty * w1.z + dtz * w2.z)};
   }
   // dL/dSigma = ga a0 a0^T + gb/2 (a0 a1^T + a1 a0^T) + gc a1 a1^T = a0 u^T + a1 v^T
-  const float hb = 0.5f * gb;
-  const V3 u = axpby(ga, a0, hb, a1), v = axpby(hb, a0, gc, a1);
-  if (conic_part) {  // (the reference leaves dL_dcov3D zero when the regulariser's reciprocal underflows, backward.cu:253)
+  if (conic_part) {
+    const double hb = 0.5 * gb;
+    const D3 u = daxpby(ga, a0, hb, a1), v = daxpby(hb, a0, gc, a1);
     o.G = {a0.x * u.x + a1.x * v.x, a0.x * u.y + a1.x * v.y, a0.x * u.z + a1.x * v.z,
            a0.y * u.y + a1.y * v.y, a0.y * u.z + a1.y * v.z, a0.z * u.z + a1.z * v.z};
   } else {
-    o.G = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    o.G = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   }
-  // rows of A:  dL/da0 = 2 ga p + gb q,  dL/da1 = gb p + 2 gc q;  A = J W gives the four non-zero entries of J
-  const V3 dA0 = axpby(2.f * ga, p, gb, q), dA1 = axpby(gb, p, 2.f * gc, q);
-  const float dj00 = dot3(w0, dA0), dj02 = dot3(w2, dA0), dj11 = dot3(w1, dA1), dj12 = dot3(w2, dA1);
-  // J = [[fx/z, 0, -fx x/z^2], [0, fy/z, -fy y/z^2]];  quirk (backward.cu:310-313): in d/dz the clamped x, y are treated
-  // as constants although they were formed as (clamped ratio) * z
-  const float iz3 = iz2 * iz;
-  const float dtx = free_x ? -fx * iz2 * dj02 : 0.f;
-  const float dty = free_y ? -fy * iz2 * dj12 : 0.f;
-  const float dtz = -fx * iz2 * dj00 - fy * iz2 * dj11 + 2.f * fx * t.x * iz3 * dj02 + 2.f * fy * t.y * iz3 * dj12 -
-                    g_invdepth * iz2;
-  o.dmean = {dtx * w0.x + dty * w1.x + dtz * w2.x, dtx * w0.y + dty * w1.y + dtz * w2.y, dtx * w0.z + dty * w1.z + dtz * w2.z};
   return o;
 }
 
-// Backward of Sigma = R diag(s)^2 R^T (replaces backward.cu:330-393), s = scale_modifier * scale, R(q) the rotation of
-// the quaternion q = (r, x, y, z) taken as given (no normalisation Jacobian: the caller normalises, forward.cu:123).
+// Backward of Sigma = R diag(s)^2 R^T (replaces backward.cu:330-393), in double.
 // With r_j the j-th column of R:  Sigma = sum_j s_j^2 r_j r_j^T  =>  dL/ds_j = 2 s_j r_j^T G r_j  and
 // D = dL/dR = 2 G R diag(s)^2; the quaternion gradient contracts D with dR/dq.
 // quirk: dL/ds is returned w.r.t. s itself, without the factor scale_modifier (backward.cu:372-375) - the same thing on
 // the training path (scale_modifier = 1); tests/test_oracle_golden.py pins it against the reference's python autograd.
-GS_DEV void cov3d_backward(const Sym3& G, V3 scale, float scale_modifier, V4 quat, V3& dscale, float dq[4]) {
-  const float r = quat.x, x = quat.y, y = quat.z, z = quat.w;
-  const V3 s = scale_modifier * scale;
-  const V3 c0 = {1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y)};  // columns of R
-  const V3 c1 = {2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x)};
-  const V3 c2 = {2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y)};
-  const V3 k0 = sym_mul(G, c0), k1 = sym_mul(G, c1), k2 = sym_mul(G, c2);
-  dscale = {2.f * s.x * dot3(c0, k0), 2.f * s.y * dot3(c1, k1), 2.f * s.z * dot3(c2, k2)};
-  const V3 d0 = (2.f * s.x * s.x) * k0, d1 = (2.f * s.y * s.y) * k1, d2 = (2.f * s.z * s.z) * k2;  // columns of D
-  // R00 = 1-2(yy+zz) R01 = 2(xy-rz) R02 = 2(xz+ry) | R10 = 2(xy+rz) R11 = 1-2(xx+zz) R12 = 2(yz-rx) |
+GS_DEV void cov3d_backward(const SymD& G, D3 s, const RotD& R, V4 quat, V3& dscale, float dq[4]) {
+  const double r = quat.x, x = quat.y, y = quat.z, z = quat.w;
+  const D3 k0 = dsym_mul(G, R.c0), k1 = dsym_mul(G, R.c1), k2 = dsym_mul(G, R.c2);
+  dscale = {(float)(2.0 * s.x * ddot(R.c0, k0)), (float)(2.0 * s.y * ddot(R.c1, k1)), (float)(2.0 * s.z * ddot(R.c2, k2))};
+  const double e0 = 2.0 * s.x * s.x, e1 = 2.0 * s.y * s.y, e2 = 2.0 * s.z * s.z;
+  // columns of D; R00 = 1-2(yy+zz) R01 = 2(xy-rz) R02 = 2(xz+ry) | R10 = 2(xy+rz) R11 = 1-2(xx+zz) R12 = 2(yz-rx) |
   // R20 = 2(xz-ry) R21 = 2(yz+rx) R22 = 1-2(xx+yy);  D_ij = (column j).(component i)
-  const float D00 = d0.x, D10 = d0.y, D20 = d0.z, D01 = d1.x, D11 = d1.y, D21 = d1.z, D02 = d2.x, D12 = d2.y, D22 = d2.z;
-  dq[0] = 2.f * (z * (D10 - D01) + y * (D02 - D20) + x * (D21 - D12));
-  dq[1] = 2.f * (y * (D01 + D10) + z * (D02 + D20) + r * (D21 - D12)) - 4.f * x * (D11 + D22);
-  dq[2] = 2.f * (x * (D01 + D10) + r * (D02 - D20) + z * (D12 + D21)) - 4.f * y * (D00 + D22);
-  dq[3] = 2.f * (r * (D10 - D01) + x * (D02 + D20) + y * (D12 + D21)) - 4.f * z * (D00 + D11);
+  const double D00 = e0 * k0.x, D10 = e0 * k0.y, D20 = e0 * k0.z, D01 = e1 * k1.x, D11 = e1 * k1.y, D21 = e1 * k1.z;
+  const double D02 = e2 * k2.x, D12 = e2 * k2.y, D22 = e2 * k2.z;
+  dq[0] = (float)(2.0 * (z * (D10 - D01) + y * (D02 - D20) + x * (D21 - D12)));
+  dq[1] = (float)(2.0 * (y * (D01 + D10) + z * (D02 + D20) + r * (D21 - D12)) - 4.0 * x * (D11 + D22));
+  dq[2] = (float)(2.0 * (x * (D01 + D10) + r * (D02 - D20) + z * (D12 + D21)) - 4.0 * y * (D00 + D22));
+  dq[3] = (float)(2.0 * (r * (D10 - D01) + x * (D02 + D20) + y * (D12 + D21)) - 4.0 * z * (D00 + D11));
 }
 
 // Projection part of the mean gradient (replaces backward.cu:419-440): pixel mean = ndc2Pix((PV m).xy / ((PV m).w + 1e-7));
@@ -254,44 +304,53 @@ struct GeomBack {
   V3 dscale;
   float dq[4];
 };
-// idx must be a visible Gaussian (radii > 0); reads its 16-float row of blend-backward sums (layout: GR_* of gs_common.h)
+// idx must be a visible Gaussian (radii > 0); reads its row of blend-backward sums (float64, layout: GR_* of gs_common.h)
 GS_DEV void geometry_backward(const PreprocessBwdArgs& a, int idx, GeomBack& o) {
-  const float4* gr = reinterpret_cast<const float4*>(a.grad_rows + (size_t)idx * GR_STRIDE);
-  const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
-  o.dmean2D_x = g0.x;
-  o.dmean2D_y = g0.y;
-  o.dcolor = {g1.z, g1.w, g2.x};
-  o.dextra = g2.z;
+  const double2* gr = reinterpret_cast<const double2*>(a.grad_rows + (size_t)idx * GR_STRIDE);
+  const double2 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4], g5 = gr[5];
+  // [mx my] [cxx cxy] [cyy op] [r g] [b id] [extra -]
+  o.dmean2D_x = (float)g0.x;
+  o.dmean2D_y = (float)g0.y;
+  o.dcolor = {(float)g3.x, (float)g3.y, (float)g4.x};
+  o.dextra = (float)g5.x;
   const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-  float c3[6];
-  {
+  // Sigma in double: from the parameters when they are there, else the caller's precomputed covariance as given
+  SymD Sg;
+  RotD R = {};
+  D3 s = {0.0, 0.0, 0.0};
+  V4 rq = {1.f, 0.f, 0.f, 0.f};
+  if (a.scales) {
+    const V3 scl = load_scales(a.scales, idx, a.raw_activations);
+    rq = load_rotation(a.rotations, idx, a.raw_activations);
+    const double mod = a.scale_modifier;
+    s = {mod * scl.x, mod * scl.y, mod * scl.z};
+    R = quat_to_Rd(rq);
+    Sg = sigma_from_scale_rot(s, R);
+  } else {
     const float2* cv = reinterpret_cast<const float2*>(a.cov3D + 6 * (size_t)idx);
     const float2 v0 = cv[0], v1 = cv[1], v2 = cv[2];
-    c3[0] = v0.x; c3[1] = v0.y; c3[2] = v1.x; c3[3] = v1.y; c3[4] = v2.x; c3[5] = v2.y;
+    Sg = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y};
   }
   // slot GR_ID holds dL/d(inverse depth) (dr_aa) or dL/d(depth) (FSGS generation); only the former enters through t.z
-  const Cov2DBack cb = cov2d_backward(mean, c3, a.viewmatrix, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy,
-                                      {g0.z, g0.w, g1.x}, g1.y, a.antialiasing ? load_opacity(a.opacities, idx, a.raw_activations) : 0.f,
-                                      a.antialiasing != 0, a.has_invdepth == 1 ? g2.y : 0.f);
+  const Cov2DBack cb = cov2d_backward(mean, Sg, a.viewmatrix, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy,
+                                      {g1.x, g1.y, g2.x}, (float)g2.y,
+                                      a.antialiasing ? load_opacity(a.opacities, idx, a.raw_activations) : 0.f,
+                                      a.antialiasing != 0, a.has_invdepth == 1 ? g4.y : 0.0);
   o.dop = cb.dop;
-  o.dcov[0] = cb.G.xx; o.dcov[1] = 2.f * cb.G.xy; o.dcov[2] = 2.f * cb.G.xz;
-  o.dcov[3] = cb.G.yy; o.dcov[4] = 2.f * cb.G.yz; o.dcov[5] = cb.G.zz;
+  o.dcov[0] = (float)cb.G.xx; o.dcov[1] = (float)(2.0 * cb.G.xy); o.dcov[2] = (float)(2.0 * cb.G.xz);
+  o.dcov[3] = (float)cb.G.yy; o.dcov[4] = (float)(2.0 * cb.G.yz); o.dcov[5] = (float)cb.G.zz;
   o.dmean = cb.dmean + projection_backward(mean, a.projmatrix, o.dmean2D_x, o.dmean2D_y);
   if (a.has_invdepth == 2) {
     // FSGS generation (-confidence fork, backward.cu:394-403): depth = (row 2 of the view matrix).(m, 1), divided by
     // the homogeneous row as that fork writes it
     const float* vm = a.viewmatrix;
     const float zc = vm[2] * mean.x + vm[6] * mean.y + vm[10] * mean.z + vm[14];
-    const float gd = g2.y;
+    const float gd = (float)g4.y;
     o.dmean = o.dmean + V3{(vm[2] - vm[3] * zc) * gd, (vm[6] - vm[7] * zc) * gd, (vm[10] - vm[11] * zc) * gd};
   }
   o.dscale = {0.f, 0.f, 0.f};
   o.dq[0] = o.dq[1] = o.dq[2] = o.dq[3] = 0.f;
-  if (a.scales) {
-    const V3 scl = load_scales(a.scales, idx, a.raw_activations);
-    const V4 rq = load_rotation(a.rotations, idx, a.raw_activations);
-    cov3d_backward(cb.G, scl, a.scale_modifier, rq, o.dscale, o.dq);
-  }
+  if (a.scales) cov3d_backward(cb.G, s, R, rq, o.dscale, o.dq);
 }
 
 // SH half: writes the Gaussian's dL_dsh row through `dsh`, returns the view-direction part of dL_dmean

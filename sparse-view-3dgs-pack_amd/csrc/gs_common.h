@@ -152,8 +152,14 @@ static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T
 // binning buffer = one SortBufs over the instances: keys = tile id, values = Gaussian index
 static inline __host__ __device__ size_t bin_bytes(size_t cap) { return sort_bytes(cap); }
 
-// per-Gaussian gradient row accumulated by the backward blend (one 64-B line per Gaussian)
+// per-Gaussian gradient row accumulated by the backward blend: FLOAT64 slots (round 4), one 128-B line per Gaussian.
+// A tile's totals are fp32 (fixed lane order, fixed reduction tree: deterministic); what is run-dependent is the order in
+// which the tiles' totals arrive at a Gaussian's row.  In a 53-bit accumulator a sum of 24-bit terms is exact - hence the
+// same whatever the order - unless the terms span more than ~2^20 in magnitude, and then differs in the 16th digit; fp32
+// rows differed in the 7th, which the conic -> covariance chain amplifies a thousandfold (gs_backward_math.h).
 enum { GR_MX = 0, GR_MY, GR_CXX, GR_CXY, GR_CYY, GR_OP, GR_CR, GR_CG, GR_CB, GR_ID, GR_EXTRA, GR_N, GR_STRIDE = 16 };
+typedef double gs_row_t;
+#define GR_ROW_BYTES (GR_STRIDE * sizeof(gs_row_t))
 
 // rasterizer_impl.cu:35-50 (host)
 static inline uint32_t gs_higher_msb(uint32_t n) {
@@ -259,11 +265,11 @@ int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, in
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, uint32_t* order_out, const float* stop_depth,
                       float* limit_out, int grid_x, int grid_y, const GeomHeader* hdr, hipStream_t s,
                       const float* slack_dev = nullptr);
-int launch_zero_rows(float* rows, size_t P, const uint32_t* tiles_touched, hipStream_t s);
+int launch_zero_rows(gs_row_t* rows, size_t P, const uint32_t* tiles_touched, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                            const uint32_t* tile_work, const uint32_t* tile_order, const float* dL_dpix,
-                           const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs, hipStream_t s);
+                           const float* dL_dinvdepth, const float* dL_dextra, gs_row_t* grad_rows, int fsgs, hipStream_t s);
 
 int launch_blend_stats(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y, const Splat* splat,
                        const uint32_t* n_contrib, const uint32_t* tile_work, unsigned long long* out, hipStream_t s);
@@ -288,7 +294,7 @@ struct PreprocessBwdArgs {
   int raw_activations;  // GsGaussians.raw_activations
   int skip_uninstanced;  // rows come from the blend backward of THIS forward: a Gaussian that emitted no instance (culled spans,
                          // depth limits) has all-zero sums and so all-zero gradients - its geometry / SH backward is skipped
-  const float* grad_rows;  // [P][GR_STRIDE]
+  const gs_row_t* grad_rows;  // [P][GR_STRIDE] float64
   int clean_rows;          // gs_backward_step (GsStepState.rows_clean): zero every row once it has been consumed
   const uint32_t* tiles_touched;  // [P] instances each Gaussian emitted in this forward (skip_uninstanced)
   const Splat* splat;

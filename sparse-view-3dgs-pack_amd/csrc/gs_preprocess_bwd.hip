@@ -8,13 +8,17 @@
 // (cov2D part) + (projection part) + (SH view-direction part).
 // The kernel writes EVERY row of every output (zeros for culled Gaussians), which replaces the
 // reference's 304 B/Gaussian of cudaMemset (rasterize_points.cu:163-172).
-// Per visible Gaussian: reads 64 B gradient row + 64 B splat + 24 B cov3D + 12+12+16+4 inputs
+// Per visible Gaussian: reads 96 B gradient row (float64 sums) + 64 B splat + 24 B cov3D + 12+12+16+4 inputs
 // + 192 B SH; writes 12+12+192+12+4+12+16+24 B.
 #include "gs_common.h"
 #include "gs_math.h"
 #include "gs_backward_math.h"
 
-__global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+// waves per SIMD the per-Gaussian kernels are compiled for: the float64 covariance chain (gs_backward_math.h) wants ~170 VGPRs
+#ifndef GS_PBWD_OCC
+#define GS_PBWD_OCC 4
+#endif
+__global__ void __launch_bounds__(GS_BLOCK, GS_PBWD_OCC) preprocess_bwd_kernel(PreprocessBwdArgs a) {
   // dL_dsh rows (192 B per Gaussian) leave through LDS so that every store instruction of a wave covers 1 KiB of
   // consecutive addresses; written per lane (12 x 16 B at a 192-B stride) the same bytes cost 2.3x the HBM write
   // traffic (rocprofv3 WRITE_SIZE, profiles/).  Row stride 19 words (odd): conflict-free per-lane writes.
@@ -239,7 +243,7 @@ __device__ __forceinline__ void grad_block(float* __restrict__ out, int first, i
 // blend: a pure HBM stream (parameters and moments of four fifths of the Gaussians with depth-limited lists) beside a
 // kernel that is bound by vector issue.  Same arithmetic per element in every phase.
 template <int PHASE>
-__global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(PreprocessBwdArgs a, StepArgs sa) {
+__global__ void __launch_bounds__(GS_BLOCK, GS_PBWD_OCC) preprocess_bwd_step_kernel(PreprocessBwdArgs a, StepArgs sa) {
   __shared__ float s_sh[GS_BLOCK * SH_LDS_ROW];
   __shared__ float s_g[SG_TOTAL];
   __shared__ unsigned char s_sel[PHASE == 0 ? 1 : GS_BLOCK];
@@ -253,8 +257,8 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
     if (a.clean_rows) {  // the blend backward may have accumulated into the rows of this invalid view: leave them zero
       const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
       if (i < a.P && a.radii[i] > 0 && !(a.skip_uninstanced && a.tiles_touched[i] == 0)) {
-        float4* w = reinterpret_cast<float4*>(const_cast<float*>(a.grad_rows) + (size_t)i * GR_STRIDE);
-        w[0] = w[1] = w[2] = w[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* w = reinterpret_cast<float4*>(const_cast<gs_row_t*>(a.grad_rows) + (size_t)i * GR_STRIDE);
+        w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = make_float4(0.f, 0.f, 0.f, 0.f);  // the twelve slots in use
       }
     }
     if (grads_out && st.max_radii2D) {  // this view contributes no statistics (the sum over ranks must stay finite)
@@ -294,8 +298,8 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   if (active) {
     geometry_backward(a, idx, gb);
     if (a.clean_rows && in_range) {  // the row is consumed: zero again for the next view's blend backward (no clear launch then)
-      float4* w = reinterpret_cast<float4*>(const_cast<float*>(a.grad_rows) + (size_t)idx * GR_STRIDE);
-      w[0] = w[1] = w[2] = w[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4* w = reinterpret_cast<float4*>(const_cast<gs_row_t*>(a.grad_rows) + (size_t)idx * GR_STRIDE);
+      w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = make_float4(0.f, 0.f, 0.f, 0.f);  // the twelve slots in use
     }
   }
 

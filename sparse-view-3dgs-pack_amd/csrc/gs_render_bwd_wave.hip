@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
     const Splat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_work,
     const uint32_t* __restrict__ tile_order, const float* __restrict__ dL_dpixels,
-    const float* __restrict__ dL_invdepths, const float* __restrict__ dL_dextra, float* __restrict__ grad_rows) {
+    const float* __restrict__ dL_invdepths, const float* __restrict__ dL_dextra, gs_row_t* __restrict__ grad_rows) {
   __shared__ float4 s_a[WB];  // x, y, invdepth, -
   __shared__ float4 s_c[WB];  // conic, opacity
   __shared__ float4 s_k[WB];  // rgb, 4th channel
@@ -248,7 +248,9 @@ __global__ void __launch_bounds__(64, (HAS_INVDEPTH || HAS_EXTRA) ? 3 : 4) rende
       const float t2m = dppw<0x128, 0xf, true>(t2);                             //  ... row_ror:8: lane 15 -> lane 7)
       // (no "!= 0" test: an entry that reaches this point has a touched pixel, its sums are non-zero in practice)
       const float tot = (lr == 15 ? t0 : (lr == 0 ? t1 : t2m)) * lane_scale;
-      if (lane_adds) atomicAdd(grad_rows + (size_t)s_id[j] * GR_STRIDE + lane_slot, tot);
+      // float64 slots (gs_common.h): the tile's fp32 total joins the Gaussian's row without a rounding that depends on
+      // which tiles came before it - one global_atomic_add_f64 instruction, twelve lanes, one 128-byte line
+      if (lane_adds) atomicAdd(grad_rows + (size_t)s_id[j] * GR_STRIDE + lane_slot, (double)tot);
     }
   }
 }
@@ -316,16 +318,17 @@ int launch_blend_stats(const uint2* ranges, const uint32_t* point_list, int W, i
   return 0;
 }
 
-// zero fill of the gradient rows (GR_STRIDE = 16 floats = four float4 per row).  With tiles_touched given only the rows of
+// zero fill of the gradient rows (GR_STRIDE = 16 doubles = eight float4 per row).  With tiles_touched given only the rows of
 // Gaussians that emitted instances are cleared: no atomic lands anywhere else and the per-Gaussian stage does not read the
 // others (PreprocessBwdArgs.skip_uninstanced) - a fifth of the rows with depth-limited lists.
 __global__ void __launch_bounds__(GS_BLOCK) zero_rows_kernel(float4* __restrict__ p, size_t n4,
                                                              const uint32_t* __restrict__ tiles_touched) {
   const size_t i = (size_t)blockIdx.x * GS_BLOCK + threadIdx.x;
-  if (i < n4 && (!tiles_touched || tiles_touched[i >> 2] != 0)) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4 && (!tiles_touched || tiles_touched[i >> 3] != 0)) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-int launch_zero_rows(float* rows, size_t P, const uint32_t* tiles_touched, hipStream_t s) {
-  const size_t n4 = P * (GR_STRIDE / 4);
+int launch_zero_rows(gs_row_t* rows, size_t P, const uint32_t* tiles_touched, hipStream_t s) {
+  static_assert(GR_ROW_BYTES == 128, "eight float4 per row");
+  const size_t n4 = P * (GR_ROW_BYTES / 16);
   if (n4) hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n4 + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, s,
                              reinterpret_cast<float4*>(rows), n4, tiles_touched);
   return 0;
@@ -334,7 +337,7 @@ int launch_zero_rows(float* rows, size_t P, const uint32_t* tiles_touched, hipSt
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,
                            const uint32_t* tile_work, const uint32_t* tile_order, const float* dL_dpix,
-                           const float* dL_dinvdepth, const float* dL_dextra, float* grad_rows, int fsgs, hipStream_t s) {
+                           const float* dL_dinvdepth, const float* dL_dextra, gs_row_t* grad_rows, int fsgs, hipStream_t s) {
 #define GS_BWD_WAVE(ID, EX, FS)                                                                                           \
   hipLaunchKernelGGL((render_bwd_wave_kernel<ID, EX, FS>), dim3(((grid_x * grid_y + 7) / 8) * 8), dim3(64), 0, s, ranges, point_list, W, H, \
                      grid_x, splat, bg, final_T, n_contrib, tile_work, tile_order, dL_dpix, dL_dinvdepth, dL_dextra, grad_rows)

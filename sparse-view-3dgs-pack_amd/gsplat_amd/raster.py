@@ -105,7 +105,7 @@ class RasterBackend:
         # (GsGaussians.raw_activations): no activation kernel, no activated copies
         self.raw_activations = False
         self._raw_backward = False
-        # parity probes: keep the backward workspace (the per-Gaussian 16-float gradient rows of the blend backward)
+        # parity probes: keep the backward workspace (the per-Gaussian 16-slot float64 gradient rows of the blend backward)
         self.keep_workspace = False
         self.last_workspace = None
 
@@ -823,7 +823,7 @@ class RasterBackend:
                            cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, H, W, sh, degree, campos, geomBuffer,
                            antialiasing, depth_mode=0):
         """Stage 2 of the backward alone (gs_backward_from_rows): the per-Gaussian chain rule applied to GIVEN sums of the
-        blend backward, rows [P,16].  Same return tuple as rasterize_gaussians_backward.  Parity tests only."""
+        blend backward, rows [P,16] float64.  Same return tuple as rasterize_gaussians_backward.  Parity tests only."""
         self._check_device(means3D)
         device = means3D.device
         P = int(means3D.shape[0])
@@ -845,7 +845,8 @@ class RasterBackend:
         grads.dL_dsh, grads.dL_dcolors, grads.dL_dopacity = _ptr(out["sh"]), _ptr(out["colors"]), out["opacity"].data_ptr()
         grads.dL_dscales, grads.dL_drotations = out["scales"].data_ptr(), out["rotations"].data_ptr()
         grads.dL_dcov3D = _ptr(out["cov3D"])
-        rows = _prep(rows, device)
+        rows = rows.to(device=device, dtype=torch.float64).contiguous()
+        assert rows.shape == (P, 16)
         s = self._scratch(geomBuffer, torch.empty(0, dtype=torch.uint8, device=device),
                           torch.empty(0, dtype=torch.uint8, device=device), 0)
         self.api.call("backward_from_rows", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),

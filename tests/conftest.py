@@ -23,6 +23,20 @@ def oracle():
     return oracle_lib.get()
 
 
+@pytest.fixture(autouse=True)
+def _gpu_parity_uses_the_exact_chain(request):
+    """GPU parity tests hold EVERY gradient tensor to 1e-4.  For dL_dscales / dL_drotations / dL_dcov3D the oracle's fp32
+    transcription of the reference formula is not a meaningful arbiter at that bar (it is 2e-4 ... 2e-3 away from the exact
+    image of its own inputs), so while a test marked `gpu` runs the oracle evaluates that chain in
+    double (Oracle.exact_chain).  tests/test_gpu_fullsize.py switches it per call and reports the fp32 distance too; the
+    CPU suite keeps testing the fp32 transcription (against tests/dense_reference.py at its own, wider, bars)."""
+    if request.node.get_closest_marker("gpu") is None or "oracle" not in request.fixturenames:
+        yield
+        return
+    with request.getfixturevalue("oracle").exact_chain():
+        yield
+
+
 @pytest.fixture(scope="session")
 def hip():
     """The product backend (libgsplat_hip.so).  Raises if it cannot be loaded - GPU tests must never

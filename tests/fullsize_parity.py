@@ -4,8 +4,8 @@ tests/tools/c3_grad_probe.py.  Test infrastructure: drives both backends through
 (gsplat_amd.raster.RasterBackend) the drop-in packages use.
 
 What the blend backward accumulates per Gaussian (backward.cu:593-635, one float atomicAdd per pixel and slot in the
-reference, in a run-dependent order) is kept by the oracle in double and rounded once; the product sums in fp32
-registers per tile and adds the tile totals with float atomics.  `compare_view` reports, per tensor,
+reference, in a run-dependent order) is kept by the oracle in double (and rounded once where its stage 2 reads it); the
+product sums in fp32 registers per tile and adds the tile totals into float64 rows.  `compare_view` reports, per tensor,
 max|hip - oracle| / max|oracle| and rms(hip - oracle) / rms(oracle).
 """
 import torch
@@ -34,7 +34,7 @@ def forward(backend, scene, cam, device, bg, antialiasing=False):
 
 
 def backward(backend, fw, dL_dcolor, dL_dinvdepth=None):
-    """-> (dict of the eight gradient tensors, [P,16] rows of the blend backward)"""
+    """-> (dict of the eight gradient tensors, [P,16] float64 rows of the blend backward)"""
     a = fw["args"]
     dev = a["means3D"].device
     backend.keep_workspace = True
@@ -51,7 +51,7 @@ def backward(backend, fw, dL_dcolor, dL_dinvdepth=None):
         backend.keep_workspace = False
         backend.last_workspace = None
     P = a["means3D"].shape[0]
-    rows = ws[: P * 64].view(torch.float32).reshape(P, 16).cpu().clone()
+    rows = ws[: P * 128].view(torch.float64).reshape(P, 16).cpu().clone()  # float64 sums (include/gsplat.h, gs_backward_from_rows)
     grads = {n: (None if t is None else t.detach().cpu()) for n, t in zip(GRAD_NAMES, out)}
     return grads, rows
 

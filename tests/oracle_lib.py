@@ -68,8 +68,24 @@ class Oracle:
 
         self.FsgsRasterizer = OracleRasterizerFsgs
         self.FsgsSettings = dgr_fsgs.GaussianRasterizationSettings
-        for name in ("gso_test_sh_fwd", "gso_test_sh_bwd", "gso_knn_mean_dist2_ex"):
+        for name in ("gso_test_sh_fwd", "gso_test_sh_bwd", "gso_knn_mean_dist2_ex", "gso_set_exact_chain"):
             getattr(lib, name).restype = C.c_int
+
+    def exact_chain(self, on=True):
+        """Context manager: while active the oracle's backward evaluates the reference's conic -> cov2D -> cov3D ->
+        (scale, quaternion) chain (backward.cu:162-275, 330-393) in DOUBLE - the arbiter for dL_dscales / dL_drotations /
+        dL_dcov3D, for which its fp32 transcription is itself 2e-4 ... 2e-3 of the tensor's largest entry away from the
+        exact image on needle-shaped footprints (oracle/gs_oracle.cpp: exact_chain_*).  Everything else is unchanged."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = self.lib.gso_set_exact_chain(C.c_int32(1 if on else 0))
+            try:
+                yield self
+            finally:
+                self.lib.gso_set_exact_chain(C.c_int32(old))
+        return cm()
 
 
 def get():

@@ -61,8 +61,8 @@ def test_host_run_of_the_kernel_math_matches_the_oracle_stage_two(oracle, host_m
     assert int((radii > 0).sum()) > P // 3
     st = be.export_state(P, W, H, R, geom, binning, img)
     gen = torch.Generator().manual_seed(case["seed"])
-    rows = torch.zeros((P, 16))
-    rows[:, :10] = torch.randn((P, 10), generator=gen) * torch.tensor([3.0, 3.0, 50.0, 50.0, 50.0, 1.0, 1.0, 1.0, 1.0, 2.0])
+    rows = torch.zeros((P, 16), dtype=torch.float64)  # the row layout of gs_backward_from_rows: float64 slots
+    rows[:, :10] = (torch.randn((P, 10), generator=gen) * torch.tensor([3.0, 3.0, 50.0, 50.0, 50.0, 1.0, 1.0, 1.0, 1.0, 2.0])).double()
     rows[radii <= 0] = 0  # the blend backward never touches a culled Gaussian
     args = (rows, bg, sc["means3D"], radii, g("colors_precomp"), sc["opacities"], g("scales"), g("rotations"),
             sc.get("scale_modifier", 1.0), g("cov3D_precomp"), cam.world_view_transform, cam.full_proj_transform,

@@ -59,7 +59,7 @@ def test_fused_tail_equals_the_three_kernels_bit_for_bit(hip, skip, deg):
             a._step_camera(it, True, skip)
             torch.cuda.synchronize()
             P = a.model.P
-            rows = hip.last_workspace[: P * 64].view(torch.float32).clone()
+            rows = hip.last_workspace[: P * 128].view(torch.float64).clone()
         finally:
             hip.keep_workspace, hip.last_workspace = False, None
         b.rows_override = rows
@@ -79,8 +79,8 @@ def test_two_phase_step_leaves_the_bits_of_the_one_launch_step(hip):
     a, b = make(hip, True), make(hip, True)
     P = a.model.P
     g = torch.Generator().manual_seed(13)
-    rows = torch.zeros((P, 16))
-    rows[:, :9] = torch.randn((P, 9), generator=g) * 1e-3
+    rows = torch.zeros((P, 16), dtype=torch.float64)  # float64 slots (gs_backward_from_rows)
+    rows[:, :9] = (torch.randn((P, 9), generator=g) * 1e-3).double()
     rows = rows.cuda()
     a.rows_override = b.rows_override = rows
     a.depth_limit = b.depth_limit = "deferred"
@@ -160,8 +160,8 @@ def test_graphed_step_equals_the_eager_fused_step(hip):
     a, b = make(hip, True), make(hip, True)
     P = a.model.P
     g = torch.Generator().manual_seed(11)
-    rows = torch.zeros((P, 16))
-    rows[:, :9] = torch.randn((P, 9), generator=g) * 1e-3
+    rows = torch.zeros((P, 16), dtype=torch.float64)  # float64 slots (gs_backward_from_rows)
+    rows[:, :9] = (torch.randn((P, 9), generator=g) * 1e-3).double()
     rows = rows.cuda()
     a.rows_override = b.rows_override = rows
     gs = GraphedStep(b)
@@ -215,8 +215,8 @@ def test_graphed_step_recaptures_after_a_restore_of_the_same_size(hip):
     a, b = make(hip, True), make(hip, True)
     P = a.model.P
     g = torch.Generator().manual_seed(12)
-    rows = torch.zeros((P, 16))
-    rows[:, :9] = torch.randn((P, 9), generator=g) * 1e-3
+    rows = torch.zeros((P, 16), dtype=torch.float64)  # float64 slots (gs_backward_from_rows)
+    rows[:, :9] = (torch.randn((P, 9), generator=g) * 1e-3).double()
     rows = rows.cuda()
     a.rows_override = b.rows_override = rows
     gs = GraphedStep(b)

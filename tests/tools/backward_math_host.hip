@@ -8,7 +8,7 @@
 #include "../../sparse-view-3dgs-pack_amd/csrc/gs_backward_math.h"
 
 extern "C" int bm_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const float* cov3D,
-                                     const uint8_t* clamped /*[P,3]*/, const float* rows /*[P,16]*/, int32_t depth_mode,
+                                     const uint8_t* clamped /*[P,3]*/, const double* rows /*[P,16]*/, int32_t depth_mode,
                                      const GsGrads* out) {
   const int P = g->P;
   std::vector<Splat> splat((size_t)P);
