@@ -134,7 +134,9 @@ typedef struct GsScratch {
                                       are read before they are written; a forward that overflowed its binning capacity
                                       writes neither, so that it can be repeated with the same hint and bounds) */
   int32_t binned;                  /* 1: gs_forward_bin has already built the instance lists of this view in these buffers;
-                                      gs_forward_render* then only blends */
+                                      gs_forward_render* then only blends.  Written by the library: gs_forward_geometry
+                                      clears it (a new geometry state invalidates any lists), gs_forward_bin sets it - a
+                                      caller that re-uses one GsScratch across views need not touch it */
   int32_t _pad;
   const uint32_t* step_tag;        /* optional, device: gs_forward_status then copies TWELVE words out - the four status words,
                                       four reserved ones, *step_tag, three reserved - so that a caller that replays a
@@ -204,7 +206,8 @@ int gs_forward_render_x(const GsView* view, const GsGaussians* g, GsScratch* scr
 
 /* Backward of the whole rasterizer.  num_rendered is the value forward produced.
  * dL_dinvdepth may be NULL (then no inverse-depth gradient path runs).
- * workspace: >= backward_workspace_bytes from gs_scratch_bytes.
+ * workspace: >= backward_workspace_bytes from gs_scratch_bytes (per Gaussian one 128-byte row of float64 blend sums -
+ * stage 1 - and one 80-byte record of stage 2's float64 covariance chain).
  * Accuracy (fp32 outputs): every gradient tensor within 1e-4 of its largest entry of the reference algorithm evaluated
  * in exact arithmetic on the same blend sums.  For dL_dscales / dL_drotations that is a stronger statement than "1e-4 of
  * the reference's fp32 run": the chain conic -> cov2D -> cov3D -> (scale, quaternion) (backward.cu:248-275, 330-393)
@@ -335,10 +338,11 @@ int gs_step_uninstanced(const GsView* view, const GsGaussians* g, const int32_t*
  * float atomics; here a tile's fp32 totals are added into float64 slots, so the sums do not depend on the order the
  * tiles arrive in).  depth_mode: 0 none, 1 the depth slot is dL/d(inverse depth) (dr_aa), 2 dL/d(depth) (FSGS generation).
  * Lets a test feed both implementations the SAME sums and so separate the (ill-conditioned)
- * conic -> scale / rotation chain from the accumulation that precedes it. */
+ * conic -> scale / rotation chain from the accumulation that precedes it.  workspace: as gs_backward (stage 2 keeps its
+ * per-Gaussian records there). */
 int gs_backward_from_rows(const GsView* view, const GsGaussians* g, const int32_t* radii,
                           const GsScratch* scratch, const double* rows, int32_t depth_mode,
-                          const GsGrads* grads, void* stream);
+                          const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The order in which the backward blend of this view takes its tiles: 8 * ceil(T/8) entries, entry b = the tile of
  * workgroup b (0xFFFFFFFF: none), per XCD band of the image by decreasing number of list entries the tile visits.  One
@@ -362,8 +366,14 @@ int gs_export_tile_stop_depth(const GsScratch* scratch, int32_t W, int32_t H, fl
  * out[2] = trunc_failed (a depth-limited tile ran out of list entries: outputs invalid, see GsScratch.tile_depth_limit),
  * out[3] = 0, or with GsView.tile_cull = 2 the largest number of Gaussians any 4 x 4-tile region received (the region
  * buckets hold binning_capacity / regions entries each, at most 16 384: a larger value set `overflow` too).  Valid after
- * `stream` has been synchronised. */
-int gs_forward_status(const GsScratch* scratch, uint32_t* out /*[4] host*/, void* stream);
+ * `stream` has been synchronised.
+ * With GsScratch.step_tag set the copy is 12 words: out[8] = *step_tag as the device held it when this call ran, out[9] =
+ * GS_STATUS_CHECK(out[8], out[0], out[1], out[2]).  A host that polls out[8] for its tag instead of synchronising must not
+ * trust out[0..2] until out[9] matches them: nothing orders the bytes of a device-to-host copy for a concurrent reader. */
+#define GS_STATUS_CHECK(tag, num_rendered, overflow, trunc_failed) \
+  ((((uint32_t)(tag)) * 2654435761u) ^ (((uint32_t)(num_rendered)) * 40503u) ^ (((uint32_t)(overflow)) << 30) ^ \
+   (((uint32_t)(trunc_failed)) << 31) ^ 0x5bd1e995u)
+int gs_forward_status(const GsScratch* scratch, uint32_t* out /*[4] or [12] host*/, void* stream);
 /* Developer statistics of the last forward on this scratch: what the backward blend's loop meets.  out (device, 8 x u64,
  * zeroed by the caller) += [entries visited, entries with a valid pixel, (entry, quadrant) pairs with a valid pixel,
  * valid (entry, pixel) pairs, tiles with work, list entries of those tiles, 0, 0].  tests/tools/blend_stats.py */

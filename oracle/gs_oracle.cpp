@@ -1139,7 +1139,8 @@ static void stage2_from_rows(const GsView* v, const GsGaussians* g, const int32_
 }
 
 int gso_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* s,
-                           const double* rows, int32_t depth_mode, const GsGrads* out, void* /*stream*/) {
+                           const double* rows, int32_t depth_mode, const GsGrads* out, void* /*workspace*/,
+                           size_t /*workspace_bytes*/, void* /*stream*/) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!s || !out) return GS_E_NULL;

@@ -74,7 +74,7 @@ int gs_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R_capacity, size_t
   out[0] = geom_bytes((size_t)P);
   out[1] = img_bytes((size_t)W * H, T);
   out[2] = bin_bytes((size_t)R_capacity);
-  if (bwd_ws) *bwd_ws = gs_align((size_t)P * GR_ROW_BYTES);
+  if (bwd_ws) *bwd_ws = bwd_workspace_bytes((size_t)P);
   return GS_OK;
 }
 
@@ -83,6 +83,7 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !sc->geom) return GS_E_NULL;
+  sc->binned = 0;  // a new geometry state invalidates whatever lists these buffers held (gs_forward_bin sets it again)
   hipStream_t s = (hipStream_t)stream;
   const int P = g->P;
   if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
@@ -329,7 +330,7 @@ int gs_backward_fsgs(const GsView* v, const GsGaussians* g, const int32_t* radii
 }
 
 static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians* g, const int32_t* radii, const GeomView& gv,
-                                             int depth_mode, const gs_row_t* rows, const GsGrads* grads) {
+                                             int depth_mode, const gs_row_t* rows, float* recs, const GsGrads* grads) {
   PreprocessBwdArgs a;
   a.P = g->P;
   a.D = v->sh_degree;
@@ -356,6 +357,7 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
   a.antialiasing = v->antialiasing;
   a.has_invdepth = depth_mode;
   a.grad_rows = rows;
+  a.grad_recs = recs;
   a.clean_rows = 0;
   a.splat = gv.splat;
   a.out = *grads;
@@ -406,7 +408,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   const int P = g->P, W = v->image_width, H = v->image_height;
   if (P == 0) return GS_OK;
   if (!radii || !sc->geom || !sc->img || !workspace) return GS_E_NULL;
-  if (workspace_bytes < (size_t)P * GR_ROW_BYTES) return GS_E_SCRATCH;
+  if (workspace_bytes < bwd_workspace_bytes((size_t)P)) return GS_E_SCRATCH;
   if (num_rendered < 0 || num_rendered > sc->binning_capacity) return GS_E_SHAPE;
   if (num_rendered > 0 && !sc->binning) return GS_E_NULL;
   hipStream_t s = (hipStream_t)stream;
@@ -417,6 +419,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   ImgView iv = img_view(sc->img, N, T);
   SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
   gs_row_t* rows = (gs_row_t*)workspace;
+  float* recs = reinterpret_cast<float*>((char*)workspace + gs_align((size_t)P * GR_ROW_BYTES));
   const bool given_rows = step && step->rows_override;
   if (step && (step->rows_clean < 0 || step->rows_clean > 2)) return GS_E_SHAPE;
   const int rows_clean = (step && !given_rows) ? step->rows_clean : 0;
@@ -434,9 +437,13 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     }
     GS_LAUNCH_CHECK(s, v->debug);
   }
-  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, grads);
+  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, recs, grads);
   a.skip_uninstanced = v->tile_cull ? 1 : 0;  // (with the reference's lists every visible Gaussian has instances)
   a.clean_rows = rows_clean != 0;
+  {  // float64 sums -> fp32 records (the covariance chain in double); cleans the rows it read when asked to
+    GS_PROF(ST_CHAIN, s);
+    launch_chain(a, step ? gv.hdr : nullptr, s);
+  }
   if (step) {
     GS_PROF(ST_BWD_STEP, s);
     sa.hdr = gv.hdr;
@@ -484,7 +491,7 @@ int gs_step_uninstanced(const GsView* v, const GsGaussians* g, const int32_t* ra
   hipStream_t s = (hipStream_t)stream;
   GeomView gv = geom_view(sc->geom, (size_t)P);
   const GsGrads none = {};
-  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, 0, nullptr, &none);
+  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, 0, nullptr, nullptr, &none);
   a.skip_uninstanced = 1;
   sa.hdr = gv.hdr;
   sa.phase = 1;
@@ -501,7 +508,7 @@ int gs_step_uninstanced(const GsView* v, const GsGaussians* g, const int32_t* ra
 }
 
 int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, const double* rows,
-                          int32_t depth_mode, const GsGrads* grads, void* stream) {
+                          int32_t depth_mode, const GsGrads* grads, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !grads) return GS_E_NULL;
@@ -509,12 +516,15 @@ int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* 
   if (depth_mode < 0 || depth_mode > 2) return GS_E_SHAPE;
   const int P = g->P;
   if (P == 0) return GS_OK;
-  if (!radii || !sc->geom || !rows) return GS_E_NULL;
+  if (!radii || !sc->geom || !rows || !workspace) return GS_E_NULL;
   if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
+  if (workspace_bytes < bwd_workspace_bytes((size_t)P)) return GS_E_SCRATCH;
   hipStream_t s = (hipStream_t)stream;
   GeomView gv = geom_view(sc->geom, (size_t)P);
-  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, depth_mode, rows, grads);
+  float* recs = reinterpret_cast<float*>((char*)workspace + gs_align((size_t)P * GR_ROW_BYTES));  // (the rows part stays unused)
+  PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, depth_mode, rows, recs, grads);
   (void)hipGetLastError();
+  launch_chain(a, nullptr, s);
   launch_preprocess_bwd(a, s);
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
@@ -636,7 +646,14 @@ size_t gs_tile_depth_limit_floats(int32_t W, int32_t H) {
   return depth_limit_floats((uint32_t)((W + TILE_X - 1) / TILE_X), (uint32_t)((H + TILE_Y - 1) / TILE_Y));
 }
 
-__global__ void status_tag_kernel(GeomHeader* hdr, const uint32_t* __restrict__ tag) { hdr->step_tag = *tag; }
+// the tag of the replay plus a check word over (tag, status words): a host that POLLS the pinned copy of this block for the
+// tag cannot know in which order the bytes of the device-to-host copy land - it accepts the block only when the check word
+// matches what it reads (gs_forward_status)
+__global__ void status_tag_kernel(GeomHeader* hdr, const uint32_t* __restrict__ tag) {
+  const uint32_t t = *tag;
+  hdr->step_tag = t;
+  hdr->pad[0] = gs_status_check(t, hdr->num_rendered, hdr->overflow, hdr->trunc_failed);
+}
 
 int gs_forward_status(const GsScratch* sc, uint32_t* out, void* stream) {
   if (!sc || !sc->geom || !out) return GS_E_NULL;

@@ -71,11 +71,18 @@ struct D3 {
 struct SymD {  // symmetric 3x3 in double, every entry counted once
   double xx, xy, xz, yy, yz, zz;
 };
-GS_DEV double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+GS_DEV double ddot(D3 a, D3 b) {
+#pragma clang fp contract(fast)
+  return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 GS_DEV D3 dsym_mul(const SymD& S, D3 v) {
+#pragma clang fp contract(fast)
   return {S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z, S.xz * v.x + S.yz * v.y + S.zz * v.z};
 }
-GS_DEV D3 daxpby(double a, D3 x, double b, D3 y) { return {a * x.x + b * y.x, a * x.y + b * y.y, a * x.z + b * y.z}; }
+GS_DEV D3 daxpby(double a, D3 x, double b, D3 y) {
+#pragma clang fp contract(fast)
+  return {a * x.x + b * y.x, a * x.y + b * y.y, a * x.z + b * y.z};
+}
 
 // Gradient of the real-SH colour w.r.t. the SH coefficients and the view vector (replaces backward.cu:23-142).
 // The three colour channels share one basis, so the direction gradient only needs the 16 scalars
@@ -155,6 +162,7 @@ GS_DEV RotD quat_to_Rd(V4 quat) {
   return R;
 }
 GS_DEV SymD sigma_from_scale_rot(D3 s, const RotD& R) {
+#pragma clang fp contract(fast)
   const double s0 = s.x * s.x, s1 = s.y * s.y, s2 = s.z * s.z;
   return {s0 * R.c0.x * R.c0.x + s1 * R.c1.x * R.c1.x + s2 * R.c2.x * R.c2.x,
           s0 * R.c0.x * R.c0.y + s1 * R.c1.x * R.c1.y + s2 * R.c2.x * R.c2.y,
@@ -175,6 +183,7 @@ struct Cov2DBack {
 GS_DEV Cov2DBack cov2d_backward(V3 mean, const SymD& Sg, const float* vm, float focal_x, float focal_y, float tan_fovx,
                                 float tan_fovy, D3 g_conic /* xx, xy, yy */, float g_opacity, float opacity_raw,
                                 bool antialiasing, double g_invdepth /* dL/d(1/t.z), 0 if unused */) {
+#pragma clang fp contract(fast)  // (the file is built without contraction for the fp32 bit-exactness rules; the double chain may fuse)
   Cov2DBack o;
   const double fx = focal_x, fy = focal_y;
   // view-space mean, clamped exactly as the forward clamps it (forward.cu:81-87); a clamped coordinate gets no gradient
@@ -182,11 +191,11 @@ GS_DEV Cov2DBack cov2d_backward(V3 mean, const SymD& Sg, const float* vm, float 
   D3 t = {vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12], vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13],
           vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14]};
   const double limx = 1.3 * (double)tan_fovx, limy = 1.3 * (double)tan_fovy;
-  const double rx = t.x / t.z, ry = t.y / t.z;
+  const double iz = 1.0 / t.z, iz2 = iz * iz;
+  const double rx = t.x * iz, ry = t.y * iz;
   const bool free_x = !(rx < -limx || rx > limx), free_y = !(ry < -limy || ry > limy);
   t.x = fmin(limx, fmax(-limx, rx)) * t.z;
   t.y = fmin(limy, fmax(-limy, ry)) * t.z;
-  const double iz = 1.0 / t.z, iz2 = iz * iz;
   const double j00 = fx * iz, j11 = fy * iz, j02 = -(fx * t.x) * iz2, j12 = -(fy * t.y) * iz2;
   const D3 w0 = {vm[0], vm[4], vm[8]}, w1 = {vm[1], vm[5], vm[9]}, w2 = {vm[2], vm[6], vm[10]};
   const D3 a0 = daxpby(j00, w0, j02, w2), a1 = daxpby(j11, w1, j12, w2);
@@ -264,6 +273,7 @@ GS_DEV Cov2DBack cov2d_backward(V3 mean, const SymD& Sg, const float* vm, float 
 // quirk: dL/ds is returned w.r.t. s itself, without the factor scale_modifier (backward.cu:372-375) - the same thing on
 // the training path (scale_modifier = 1); tests/test_oracle_golden.py pins it against the reference's python autograd.
 GS_DEV void cov3d_backward(const SymD& G, D3 s, const RotD& R, V4 quat, V3& dscale, float dq[4]) {
+#pragma clang fp contract(fast)
   const double r = quat.x, x = quat.y, y = quat.z, z = quat.w;
   const D3 k0 = dsym_mul(G, R.c0), k1 = dsym_mul(G, R.c1), k2 = dsym_mul(G, R.c2);
   dscale = {(float)(2.0 * s.x * ddot(R.c0, k0)), (float)(2.0 * s.y * ddot(R.c1, k1)), (float)(2.0 * s.z * ddot(R.c2, k2))};
@@ -292,8 +302,13 @@ GS_DEV V3 projection_backward(V3 m, const float* proj, float gx, float gy) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// One Gaussian of the backward per-Gaussian stage, in the two halves the kernel runs (the geometry outputs are stored
-// before the 48 SH coefficients are loaded, which keeps the kernel at 86 VGPRs / 5 waves per SIMD).
+// One Gaussian of the backward per-Gaussian stage.  It runs in two kernels (gs_preprocess_bwd.hip):
+//   chain_kernel            reads the Gaussian's float64 row of blend sums, runs the float64 covariance chain and leaves
+//                           a 20-float RECORD of fp32 results (layout GC_*); ~170 VGPRs, only Gaussians with instances
+//   preprocess_bwd*_kernel  the streaming kernels: projection part of the mean gradient, SH backward, and - fused step -
+//                           activation backward, statistics, Adam; fp32 only, 5 waves per SIMD
+// (Inlined into the streaming kernels the double chain held them at 128 VGPRs with 36-58 spilled, or at 3 waves per SIMD:
+// +29 ... +62 us per C3 step; as its own launch it costs ~10 us and cleans the rows on the way.)
 // ---------------------------------------------------------------------------------------------------------------
 struct GeomBack {
   V3 dmean;                  // (cov2D part) + (projection part) [+ depth part of the FSGS generation]
@@ -304,15 +319,12 @@ struct GeomBack {
   V3 dscale;
   float dq[4];
 };
-// idx must be a visible Gaussian (radii > 0); reads its row of blend-backward sums (float64, layout: GR_* of gs_common.h)
-GS_DEV void geometry_backward(const PreprocessBwdArgs& a, int idx, GeomBack& o) {
-  const double2* gr = reinterpret_cast<const double2*>(a.grad_rows + (size_t)idx * GR_STRIDE);
+// chain_kernel, one Gaussian: idx must be visible (radii > 0) and - when skip_uninstanced - have instances; reads its row
+// of blend-backward sums (float64, layout GR_* of gs_common.h) and fills rec[GC_STRIDE]
+GS_DEV void chain_from_row(const PreprocessBwdArgs& a, int idx, const gs_row_t* row, float* rec) {
+  const double2* gr = reinterpret_cast<const double2*>(row);
   const double2 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4], g5 = gr[5];
   // [mx my] [cxx cxy] [cyy op] [r g] [b id] [extra -]
-  o.dmean2D_x = (float)g0.x;
-  o.dmean2D_y = (float)g0.y;
-  o.dcolor = {(float)g3.x, (float)g3.y, (float)g4.x};
-  o.dextra = (float)g5.x;
   const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
   // Sigma in double: from the parameters when they are there, else the caller's precomputed covariance as given
   SymD Sg;
@@ -336,21 +348,52 @@ GS_DEV void geometry_backward(const PreprocessBwdArgs& a, int idx, GeomBack& o) 
                                       {g1.x, g1.y, g2.x}, (float)g2.y,
                                       a.antialiasing ? load_opacity(a.opacities, idx, a.raw_activations) : 0.f,
                                       a.antialiasing != 0, a.has_invdepth == 1 ? g4.y : 0.0);
-  o.dop = cb.dop;
-  o.dcov[0] = (float)cb.G.xx; o.dcov[1] = (float)(2.0 * cb.G.xy); o.dcov[2] = (float)(2.0 * cb.G.xz);
-  o.dcov[3] = (float)cb.G.yy; o.dcov[4] = (float)(2.0 * cb.G.yz); o.dcov[5] = (float)cb.G.zz;
-  o.dmean = cb.dmean + projection_backward(mean, a.projmatrix, o.dmean2D_x, o.dmean2D_y);
+  V3 dmean = cb.dmean;
   if (a.has_invdepth == 2) {
     // FSGS generation (-confidence fork, backward.cu:394-403): depth = (row 2 of the view matrix).(m, 1), divided by
     // the homogeneous row as that fork writes it
     const float* vm = a.viewmatrix;
     const float zc = vm[2] * mean.x + vm[6] * mean.y + vm[10] * mean.z + vm[14];
     const float gd = (float)g4.y;
-    o.dmean = o.dmean + V3{(vm[2] - vm[3] * zc) * gd, (vm[6] - vm[7] * zc) * gd, (vm[10] - vm[11] * zc) * gd};
+    dmean = dmean + V3{(vm[2] - vm[3] * zc) * gd, (vm[6] - vm[7] * zc) * gd, (vm[10] - vm[11] * zc) * gd};
   }
+  float c[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (a.scales) {
+    V3 dscale;
+    cov3d_backward(cb.G, s, R, rq, dscale, c + 3);
+    c[0] = dscale.x; c[1] = dscale.y; c[2] = dscale.z;
+  } else {  // precomputed covariance: its gradient takes the seven slots instead
+    c[0] = (float)cb.G.xx; c[1] = (float)(2.0 * cb.G.xy); c[2] = (float)(2.0 * cb.G.xz);
+    c[3] = (float)cb.G.yy; c[4] = (float)(2.0 * cb.G.yz); c[5] = (float)cb.G.zz;
+  }
+  float4* o = reinterpret_cast<float4*>(rec);
+  o[0] = make_float4((float)g0.x, (float)g0.y, dmean.x, dmean.y);
+  o[1] = make_float4(dmean.z, cb.dop, c[0], c[1]);
+  o[2] = make_float4(c[2], c[3], c[4], c[5]);
+  o[3] = make_float4(c[6], (float)g3.x, (float)g3.y, (float)g4.x);
+  o[4] = make_float4((float)g5.x, 0.f, 0.f, 0.f);
+}
+
+// streaming kernels, one Gaussian (same precondition): from its record to everything but the SH half
+GS_DEV void geometry_backward(const PreprocessBwdArgs& a, int idx, GeomBack& o) {
+  const float4* rc = reinterpret_cast<const float4*>(a.grad_recs + (size_t)idx * GC_STRIDE);
+  const float4 r0 = rc[0], r1 = rc[1], r2 = rc[2], r3 = rc[3];
+  o.dmean2D_x = r0.x;
+  o.dmean2D_y = r0.y;
+  o.dop = r1.y;
+  o.dcolor = {r3.y, r3.z, r3.w};
+  o.dextra = a.out.dL_dextra ? a.grad_recs[(size_t)idx * GC_STRIDE + GC_EXTRA] : 0.f;
+  const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+  o.dmean = V3{r0.z, r0.w, r1.x} + projection_backward(mean, a.projmatrix, o.dmean2D_x, o.dmean2D_y);
   o.dscale = {0.f, 0.f, 0.f};
   o.dq[0] = o.dq[1] = o.dq[2] = o.dq[3] = 0.f;
-  if (a.scales) cov3d_backward(cb.G, s, R, rq, o.dscale, o.dq);
+  o.dcov[0] = o.dcov[1] = o.dcov[2] = o.dcov[3] = o.dcov[4] = o.dcov[5] = 0.f;
+  if (a.scales) {
+    o.dscale = {r1.z, r1.w, r2.x};
+    o.dq[0] = r2.y; o.dq[1] = r2.z; o.dq[2] = r2.w; o.dq[3] = r3.x;
+  } else {
+    o.dcov[0] = r1.z; o.dcov[1] = r1.w; o.dcov[2] = r2.x; o.dcov[3] = r2.y; o.dcov[4] = r2.z; o.dcov[5] = r2.w;
+  }
 }
 
 // SH half: writes the Gaussian's dL_dsh row through `dsh`, returns the view-direction part of dL_dmean

@@ -35,7 +35,7 @@ struct GeomHeader {
   uint32_t n_ordered;     // Gaussians in the depth order = those that emit instances (the sort's first pass drops the rest)
   uint32_t region_mode;   // 1: the lists of this view were built by region binning (gs_regionbin.hip), 0: by the LSD path
   uint32_t step_tag;      // word 8: GsScratch.step_tag as gs_forward_status found it
-  uint32_t pad[55];
+  uint32_t pad[55];       // pad[0] = word 9: GS_STATUS_CHECK over (step_tag, num_rendered, overflow, trunc_failed)
 };
 static_assert(sizeof(GeomHeader) == 256, "header is one 256-B block");
 
@@ -55,6 +55,9 @@ struct __attribute__((aligned(64))) Splat {
 };
 static_assert(sizeof(Splat) == 64, "Splat is one 64-B line");
 
+static inline __host__ __device__ uint32_t gs_status_check(uint32_t tag, uint32_t nr, uint32_t ov, uint32_t tf) {
+  return GS_STATUS_CHECK(tag, nr, ov, tf);
+}
 static inline __host__ __device__ size_t gs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // radix sort geometry: 8-bit digits, 256 threads x 16 keys per workgroup
@@ -160,6 +163,13 @@ static inline __host__ __device__ size_t bin_bytes(size_t cap) { return sort_byt
 enum { GR_MX = 0, GR_MY, GR_CXX, GR_CXY, GR_CYY, GR_OP, GR_CR, GR_CG, GR_CB, GR_ID, GR_EXTRA, GR_N, GR_STRIDE = 16 };
 typedef double gs_row_t;
 #define GR_ROW_BYTES (GR_STRIDE * sizeof(gs_row_t))
+// per-Gaussian RECORD the chain kernel leaves for the streaming kernels (gs_backward_math.h): fp32, five float4.
+// mean2D gradient | covariance part of the mean gradient | opacity gradient (after the anti-aliasing factor) | seven slots:
+// dL_dscale[3] + dL_dquaternion[4], or dL_dcov3D[6] when the covariance was given | colour gradient | 4th channel
+enum { GC_MX = 0, GC_MY, GC_DMX, GC_DMY, GC_DMZ, GC_DOP, GC_C0, GC_R = GC_C0 + 7, GC_G, GC_B, GC_EXTRA, GC_STRIDE = 20 };
+#define GC_REC_BYTES (GC_STRIDE * sizeof(float))
+// backward workspace = rows [P][GR_STRIDE] float64, then records [P][GC_STRIDE] fp32
+static inline __host__ __device__ size_t bwd_workspace_bytes(size_t P) { return gs_align(P * GR_ROW_BYTES) + gs_align(P * GC_REC_BYTES); }
 
 // rasterizer_impl.cu:35-50 (host)
 static inline uint32_t gs_higher_msb(uint32_t n) {
@@ -294,12 +304,16 @@ struct PreprocessBwdArgs {
   int raw_activations;  // GsGaussians.raw_activations
   int skip_uninstanced;  // rows come from the blend backward of THIS forward: a Gaussian that emitted no instance (culled spans,
                          // depth limits) has all-zero sums and so all-zero gradients - its geometry / SH backward is skipped
-  const gs_row_t* grad_rows;  // [P][GR_STRIDE] float64
-  int clean_rows;          // gs_backward_step (GsStepState.rows_clean): zero every row once it has been consumed
+  const gs_row_t* grad_rows;  // [P][GR_STRIDE] float64: read by the chain kernel only
+  float* grad_recs;           // [P][GC_STRIDE]: written by the chain kernel, read by the streaming kernels
+  int clean_rows;          // gs_backward_step (GsStepState.rows_clean): the chain kernel zeroes every row it has consumed
   const uint32_t* tiles_touched;  // [P] instances each Gaussian emitted in this forward (skip_uninstanced)
   const Splat* splat;
   GsGrads out;
 };
+// the float64 covariance chain of every Gaussian with sums: rows -> records (hdr != NULL: a forward that flagged overflow /
+// trunc_failed leaves nothing to compute - only the rows are cleaned)
+int launch_chain(const PreprocessBwdArgs& a, const GeomHeader* hdr, hipStream_t s);
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 // the same stage with the train step's tail fused in (gs_backward_step); bias corrections precomputed on the host
 struct StepArgs {

@@ -8,17 +8,61 @@
 // (cov2D part) + (projection part) + (SH view-direction part).
 // The kernel writes EVERY row of every output (zeros for culled Gaussians), which replaces the
 // reference's 304 B/Gaussian of cudaMemset (rasterize_points.cu:163-172).
-// Per visible Gaussian: reads 96 B gradient row (float64 sums) + 64 B splat + 24 B cov3D + 12+12+16+4 inputs
+// Per visible Gaussian: reads 80 B record (chain_kernel: 96 B float64 sums + 44 B parameters in, 80 B out) + 64 B splat + 24 B cov3D + 12+12+16+4 inputs
 // + 192 B SH; writes 12+12+192+12+4+12+16+24 B.
 #include "gs_common.h"
 #include "gs_math.h"
 #include "gs_backward_math.h"
 
-// waves per SIMD the per-Gaussian kernels are compiled for: the float64 covariance chain (gs_backward_math.h) wants ~170 VGPRs
-#ifndef GS_PBWD_OCC
-#define GS_PBWD_OCC 4
-#endif
-__global__ void __launch_bounds__(GS_BLOCK, GS_PBWD_OCC) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+// ------------------------------------------------------------------------------------------------------------------
+// chain_kernel: rows (float64 blend sums) -> records (fp32 results of the float64 covariance chain), one thread per
+// Gaussian, only those with sums do anything.  Registers are not an issue here (2 waves per SIMD allowed: the chain's
+// ~170 VGPRs), the launch is ~10 us at 1 M Gaussians.  With clean_rows it zeroes each row it has read, so the rows are
+// all-zero again for the next view's blend backward and no clear launch is needed (GsStepState.rows_clean).
+// ------------------------------------------------------------------------------------------------------------------
+// Only a fifth of the Gaussians have sums on depth-limited lists, scattered over the index range: one thread per Gaussian
+// would run the ~700 double-precision instructions of the chain in EVERY wave at 20 % lane occupancy (measured: 33 us).  So
+// ONE WAVE takes CHAIN_PER_WAVE consecutive Gaussians, loads their flags at once, compacts the indices of those with sums
+// into its LDS list (ballots, no barrier: a workgroup is one wave) and its lanes then take one list entry each: nearly full
+// waves, a fifth of the instruction issue, and 3 900 independent waves to hide the two dependent round trips behind.
+#define CHAIN_PER_WAVE 256
+__global__ void __launch_bounds__(64, 3) chain_kernel(PreprocessBwdArgs a, const GeomHeader* hdr) {
+  __shared__ int s_list[CHAIN_PER_WAVE];
+  const int lane = threadIdx.x;
+  const int base = blockIdx.x * CHAIN_PER_WAVE;
+  bool has[CHAIN_PER_WAVE / 64];
+#pragma unroll
+  for (int k = 0; k < CHAIN_PER_WAVE / 64; k++) {   // (all flag loads in flight before the first is used)
+    const int idx = base + k * 64 + lane;
+    has[k] = idx < a.P && a.radii[idx] > 0 && !(a.skip_uninstanced && a.tiles_touched[idx] == 0);
+  }
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < CHAIN_PER_WAVE / 64; k++) {
+    const unsigned long long m = __ballot(has[k]);
+    if (has[k]) s_list[n + __popcll(m & ((1ull << lane) - 1ull))] = base + k * 64 + lane;
+    n += __popcll(m);
+  }
+  __syncthreads();  // (one wave: orders the LDS writes before the reads below)
+  // the forward ran out of binning capacity or its depth limits proved too tight (possible only when the caller did not
+  // re-run it: deferred verdict, replayed graph): the step kernels do nothing - only leave the rows clean
+  const bool failed = hdr && (hdr->overflow | hdr->trunc_failed) != 0u;
+  for (int j = lane; j < n; j += 64) {
+    const int idx = s_list[j];
+    gs_row_t* row = const_cast<gs_row_t*>(a.grad_rows) + (size_t)idx * GR_STRIDE;
+    if (!failed) chain_from_row(a, idx, row, a.grad_recs + (size_t)idx * GC_STRIDE);
+    if (a.clean_rows) {
+      float4* w = reinterpret_cast<float4*>(row);
+      w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = make_float4(0.f, 0.f, 0.f, 0.f);  // the twelve slots in use
+    }
+  }
+}
+int launch_chain(const PreprocessBwdArgs& a, const GeomHeader* hdr, hipStream_t s) {
+  hipLaunchKernelGGL(chain_kernel, dim3((a.P + CHAIN_PER_WAVE - 1) / CHAIN_PER_WAVE), dim3(64), 0, s, a, hdr);
+  return 0;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_kernel(PreprocessBwdArgs a) {
   // dL_dsh rows (192 B per Gaussian) leave through LDS so that every store instruction of a wave covers 1 KiB of
   // consecutive addresses; written per lane (12 x 16 B at a 192-B stride) the same bytes cost 2.3x the HBM write
   // traffic (rocprofv3 WRITE_SIZE, profiles/).  Row stride 19 words (odd): conflict-free per-lane writes.
@@ -243,7 +287,7 @@ __device__ __forceinline__ void grad_block(float* __restrict__ out, int first, i
 // blend: a pure HBM stream (parameters and moments of four fifths of the Gaussians with depth-limited lists) beside a
 // kernel that is bound by vector issue.  Same arithmetic per element in every phase.
 template <int PHASE>
-__global__ void __launch_bounds__(GS_BLOCK, GS_PBWD_OCC) preprocess_bwd_step_kernel(PreprocessBwdArgs a, StepArgs sa) {
+__global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(PreprocessBwdArgs a, StepArgs sa) {
   __shared__ float s_sh[GS_BLOCK * SH_LDS_ROW];
   __shared__ float s_g[SG_TOTAL];
   __shared__ unsigned char s_sel[PHASE == 0 ? 1 : GS_BLOCK];
@@ -254,13 +298,7 @@ __global__ void __launch_bounds__(GS_BLOCK, GS_PBWD_OCC) preprocess_bwd_step_ker
   const bool failed = (sa.hdr->overflow | sa.hdr->trunc_failed) != 0u;
   if (grads_out && st.fail_flag && blockIdx.x == 0 && threadIdx.x == 0) *st.fail_flag = failed ? 1.0f : 0.0f;
   if (failed) {
-    if (a.clean_rows) {  // the blend backward may have accumulated into the rows of this invalid view: leave them zero
-      const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
-      if (i < a.P && a.radii[i] > 0 && !(a.skip_uninstanced && a.tiles_touched[i] == 0)) {
-        float4* w = reinterpret_cast<float4*>(const_cast<gs_row_t*>(a.grad_rows) + (size_t)i * GR_STRIDE);
-        w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = make_float4(0.f, 0.f, 0.f, 0.f);  // the twelve slots in use
-      }
-    }
+    // (the rows the blend backward accumulated into for this invalid view were cleaned by chain_kernel)
     if (grads_out && st.max_radii2D) {  // this view contributes no statistics (the sum over ranks must stay finite)
       const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
       if (i < a.P) {
@@ -295,13 +333,7 @@ __global__ void __launch_bounds__(GS_BLOCK, GS_PBWD_OCC) preprocess_bwd_step_ker
   ShSink dsh{s_sh + tid * SH_LDS_ROW, true};
 #pragma unroll
   for (int k = 0; k < SH_LDS_ROW; k++) dsh.p[k] = 0.f;
-  if (active) {
-    geometry_backward(a, idx, gb);
-    if (a.clean_rows && in_range) {  // the row is consumed: zero again for the next view's blend backward (no clear launch then)
-      float4* w = reinterpret_cast<float4*>(const_cast<gs_row_t*>(a.grad_rows) + (size_t)idx * GR_STRIDE);
-      w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = make_float4(0.f, 0.f, 0.f, 0.f);  // the twelve slots in use
-    }
-  }
+  if (active) geometry_backward(a, idx, gb);
 
   // ---- view statistics (train.py:266-268, gaussian_model.py:471-473)
   if (in_range && st.max_radii2D && mine) {

@@ -29,6 +29,7 @@ enum GsStage {
   ST_BWD_STEP,
   ST_TILE_ORDER,
   ST_STEP_UNINST,
+  ST_CHAIN,
   ST_COUNT
 };
 

@@ -66,7 +66,7 @@ void gs_prof_end(int stage, hipStream_t s) {
 static const char* kNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate", "sort_depth", "sort", "tile_ranges", "render_fwd",
                                        "bwd_memset", "render_bwd", "preprocess_bwd", "knn", "l1", "dwt2_l1_fwd",
                                        "dwt2_l1_bwd", "ssim_fwd", "ssim_bwd", "patch_dwt", "elf_map", "dwt_haar", "adam", "model_ops", "preprocess_bwd_step",
-                                       "tile_order", "step_uninstanced"};
+                                       "tile_order", "step_uninstanced", "chain"};
 
 extern "C" {
 int gs_profile_enable(int32_t on) {

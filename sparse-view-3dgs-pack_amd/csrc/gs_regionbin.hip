@@ -220,16 +220,21 @@ int launch_region_bin(const GeomView& g, const uint32_t* region_count, const uin
   uint32_t n_pad = 1024;
   while (n_pad < region_cap && n_pad < RG_MAX_ENTRIES) n_pad <<= 1;
   const size_t lds = (size_t)n_pad * sizeof(unsigned long long);
-  static size_t lds_allowed = 0;  // (raised once per process; the attribute is sticky)
-  if (lds > lds_allowed) {
+  // the attribute is per DEVICE (and sticky): remember what each device of this process was raised to
+  static_assert(RG_MAX_ENTRIES * sizeof(unsigned long long) <= 160 * 1024, "a region's sort must fit gfx950's 160 KB of LDS");
+  static size_t lds_allowed[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev < 0 || lds > lds_allowed[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)region_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    lds_allowed = lds;
+    if (dev >= 0) lds_allowed[dev] = lds;
   }
   const uint32_t cap32 = capacity > 0xFFFFFFFFll ? 0xFFFFFFFFu : (capacity < 0 ? 0u : (uint32_t)capacity);
   hipLaunchKernelGGL(region_bin_kernel, dim3(rg_x * rg_y), dim3(RB_THREADS), lds, s, g.hdr, g.splat, region_count, region_bucket,
                      region_cap, rg_x, grid_x, grid_y, tile_depth_limit, ranges, point_list, cap32, n_pad);
-  return 0;
+  const hipError_t le = hipGetLastError();  // (a refused launch - too much dynamic LDS - must not pass for stale lists)
+  return le == hipSuccess ? 0 : (int)le;
 }
 
 int launch_export_keys_region(const uint2* ranges, const uint32_t* point_list, const Splat* splat, int T, uint64_t* keys_sorted,

@@ -129,7 +129,7 @@ PROTOTYPES = {
     "backward_step": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P,
                                 C.POINTER(GsStepState), _P, _SZ, _P]),
     "backward_from_rows": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _P, _I32,
-                                     C.POINTER(GsGrads), _P]),
+                                     C.POINTER(GsGrads), _P, _SZ, _P]),
     "mark_visible": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
     "export_geom": (C.c_int, [C.POINTER(GsScratch), _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "export_binning": (C.c_int, [C.POINTER(GsScratch), _I64, _P, _P, _P]),

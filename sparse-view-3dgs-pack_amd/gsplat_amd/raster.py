@@ -98,6 +98,8 @@ class RasterBackend:
         self.fused_step = None
         self._side_streams = {}
         self._rows_ws = {}        # (device, bytes) -> [persistent gradient-row workspace of the fused step, rows all zero?]
+        self.rows_epoch = 0       # bumped whenever a fused backward found (or may have left) that workspace dirty
+        self._early = None        # what launch_uninstanced_early needs of the last forward
         self.two_phase_launches = 0
         self._uninst_done = None
         # one-shot, set together with fused_step by the train step: the opacities / scales / rotations of the next forward
@@ -293,7 +295,9 @@ class RasterBackend:
         c = self._cam_cache.get(key)
         if c is None:
             self.camera_cache_stats["misses"] += 1
-            if len(self._cam_cache) >= 256:  # forget the oldest camera that nobody pinned (GraphedStep pins its static one)
+            if len(self._cam_cache) >= self.CAMERA_CACHE_MAX:
+                # forget the oldest camera nobody pinned (a captured hipGraph holds the ADDRESSES of its camera's buffers:
+                # GraphedStep pins the entry for as long as the graph lives)
                 for k in self._cam_cache:
                     if not self._cam_cache[k].get("pinned"):
                         self._cam_cache.pop(k)
@@ -311,6 +315,15 @@ class RasterBackend:
         else:
             self.camera_cache_stats["hits"] += 1
         return c
+
+    CAMERA_CACHE_MAX = 256
+
+    def drop_camera_entries(self, key_prefix):
+        """Forget the per-camera state filed under explicit keys that start with `key_prefix` (a trainer that is gone:
+        its keys are ("trainer", uid, camera index)); pinned entries too - their graphs died with the trainer."""
+        n = len(key_prefix)
+        for k in [k for k in self._cam_cache if k[3][0] == "key" and isinstance(k[3][1], tuple) and k[3][1][:n] == key_prefix]:
+            self._cam_cache.pop(k, None)
 
     def camera_entry(self, W, H, viewmatrix=None, camera_key=None, device_index=None):
         """The per-camera state kept for a camera (by explicit key, or by the contents of its view matrix), or None - a
@@ -368,9 +381,70 @@ class RasterBackend:
     TWO_PHASE = os.environ.get("GS_TWO_PHASE_STEP", "1") != "0"
     TWO_PHASE_MIN_P = 100_000
 
+    # Where the side launch of the two-phase step (gs_step_uninstanced) is issued:
+    #   "loss_backward"  by the train step, right before the criterion's backward kernels (Trainer calls
+    #                    launch_uninstanced_early): it then runs under ssim_bwd / dwt2_l1_bwd and the backward blend
+    #   "raster_backward" at the start of the rasterizer's backward, next to the blend only (round 3)
+    UNINST_AT = os.environ.get("GS_UNINST_AT", "loss_backward")
+
     def rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                              cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
                              sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False):
+        """The forward (see _rasterize_gaussians); with a fused train step armed it also remembers what an early side launch
+        of that step needs (launch_uninstanced_early)."""
+        raw = self.raw_activations
+        out = self._rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
+                                        cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
+                                        sh, degree, campos, prefiltered, antialiasing, debug, extra=extra, fsgs=fsgs)
+        self._early = None
+        step = self.fused_step
+        if step is not None and extra is None and not fsgs and means3D.device.type == "cuda" and self.UNINST_AT != "raster_backward":
+            P = int(means3D.shape[0])
+            if self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and self.tile_cull and not step.grad_out[0] and not step.rows_override:
+                self._early = dict(args=(bg, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                                         projmatrix, campos, tanfovx, tanfovy, int(image_height), int(image_width),
+                                         scale_modifier, degree, antialiasing, debug),
+                                   raw=raw, radii=out[2], geom=out[3], img=out[5], step=step, done=None)
+        return out
+
+    def launch_uninstanced_early(self):
+        """Issue the side launch of the two-phase step NOW (everything enqueued so far on the current stream - the forward,
+        the criterion's forward - is waited for by the side stream; what the caller enqueues next runs beside it).  No-op
+        unless the last forward armed it.  The rasterizer's backward then only waits for it."""
+        e = self._early
+        if e is None or e["done"] is not None:
+            return False
+        (bg, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx,
+         tanfovy, H, W, scale_modifier, degree, antialiasing, debug) = e["args"]
+        device = means3D.device
+        keep = []
+        self._region_key = (int(means3D.shape[0]), W, H)
+        view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier, degree,
+                          False, antialiasing, debug)
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, raw=e["raw"])
+        empty = torch.empty((0,), dtype=torch.uint8, device=device)
+        s = self._scratch(e["geom"], e["img"], empty, 0)
+        e["done"] = self._launch_uninstanced(device, view, g, e["radii"], s, e["step"])
+        e["keep"] = keep
+        return True
+
+    def _launch_uninstanced(self, device, view, g, radii, s, step):
+        main = torch.cuda.current_stream(device)
+        side = self._side_streams.get(device.index)
+        if side is None:
+            side = self._side_streams[device.index] = torch.cuda.Stream(device=device)
+        side.wait_stream(main)   # (the forward has decided overflow / trunc_failed)
+        with torch.cuda.stream(side):
+            self.api.call("step_uninstanced", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),
+                          C.byref(step), C.c_void_p(side.cuda_stream))
+            done = torch.cuda.Event()
+            done.record(side)
+        self.two_phase_launches += 1
+        return done
+
+    def _rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
+                              cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
+                              sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False):
         """= RasterizeGaussiansCUDA (rasterize_points.cu:35-124).
 
         Returns (num_rendered, color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
@@ -705,17 +779,15 @@ class RasterBackend:
             # (the backward clears only the rows of Gaussians that emitted instances; a probe that reads the rows gets zeros
             # for the others too)
             two_phase = self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and view.tile_cull != 0 and not step.grad_out[0]
-            if self.keep_workspace or step.rows_override or two_phase:
-                # (two-phase: the clear launch stays - it is the head start the side kernel needs.  Its few hundred four-wave
-                # workgroups must find their slots before the blend's 8 160 one-wave workgroups are dealt out; launched at
-                # the same moment they trickle in behind them, 0.50 instead of 0.36 ms, and phase 2 waits: measured, with
-                # and without a high-priority side stream)
+            if self.keep_workspace or step.rows_override:
                 ws = (torch.zeros if self.keep_workspace else torch.empty)((wsb,), dtype=torch.uint8, device=device)
                 if self.keep_workspace:
                     self.last_workspace = ws
+                step.rows_clean = 0
             else:
-                # one persistent workspace per size: the per-Gaussian kernel zeroes every row it consumes
-                # (GsStepState.rows_clean), so the rows are clean again after every step and no clear launch runs
+                # one persistent workspace per size: the chain kernel zeroes every row it consumes (GsStepState.rows_clean),
+                # so the rows are clean again after every step and no clear launch runs.  rows_clean = 1 - one clear launch,
+                # then clean again - whenever the host is not SURE of that state (first use, a call that raised)
                 key = (device.index, wsb)
                 ent = self._rows_ws.get(key)
                 if ent is None:
@@ -723,27 +795,30 @@ class RasterBackend:
                         self._rows_ws.clear()    #  a captured graph is keyed by the number of Gaussians)
                     ent = self._rows_ws[key] = [torch.zeros((wsb,), dtype=torch.uint8, device=device), True]
                 ws = ent[0]
+                # (a launch captured into a hipGraph is replayed with this flag frozen: `rows_epoch` counts the calls that may
+                #  have left rows dirty, GraphedStep keys its graphs by it and captures again - after an eager step that cleaned)
                 step.rows_clean = 2 if ent[1] else 1
+                if not ent[1]:
+                    self.rows_epoch += 1
                 ent[1] = False      # (until the call below has returned: a failed launch leaves them in an unknown state)
             s = self._scratch(geomBuffer, imgBuffer, binningBuffer, self._capacity_for(binningBuffer, P, W, H, R))
+            early, self._early = self._early, None
             if two_phase:
-                main = torch.cuda.current_stream(device)
-                side = self._side_streams.get(device.index)
-                if side is None:
-                    side = self._side_streams[device.index] = torch.cuda.Stream(device=device)
-                side.wait_stream(main)   # (the forward has decided overflow / trunc_failed; the criterion is through)
-                with torch.cuda.stream(side):
-                    self.api.call("step_uninstanced", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),
-                                  C.byref(step), C.c_void_p(side.cuda_stream))
-                    done = torch.cuda.Event()
-                    done.record(side)
-                self.two_phase_launches += 1
+                if early is not None and early["done"] is not None and early["geom"].data_ptr() == geomBuffer.data_ptr() \
+                        and early["step"] is step:
+                    done = early["done"]          # (issued by launch_uninstanced_early, under the criterion's backward)
+                else:
+                    done = self._launch_uninstanced(device, view, g, radii, s, step)
                 self._uninst_done = done          # (kept alive until the next step replaces it)
                 step.phase = 2                    # gs_backward_step: the Gaussians with instances only ...
                 step.phase1_done = done.cuda_event  # ... its per-Gaussian kernel behind the side launch
-            self.api.call("backward_step", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
-                          dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(step), _ptr(ws), ws.numel(),
-                          self._stream(device))
+            try:
+                self.api.call("backward_step", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
+                              dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(step), _ptr(ws), ws.numel(),
+                              self._stream(device))
+            except Exception:
+                self.rows_epoch += 1   # (the persistent rows may hold sums now: graphs that skip the clear are stale)
+                raise
             if step.rows_clean:
                 self._rows_ws[(device.index, wsb)][1] = True
             return (None,) * 8
@@ -849,8 +924,10 @@ class RasterBackend:
         assert rows.shape == (P, 16)
         s = self._scratch(geomBuffer, torch.empty(0, dtype=torch.uint8, device=device),
                           torch.empty(0, dtype=torch.uint8, device=device), 0)
+        _, _, _, wsb = self.scratch_bytes(P, W, H, 0)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=device)
         self.api.call("backward_from_rows", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),
-                      rows.data_ptr(), int(depth_mode), C.byref(grads), self._stream(device))
+                      rows.data_ptr(), int(depth_mode), C.byref(grads), ws.data_ptr(), ws.numel(), self._stream(device))
         return (out["means2D"], out["colors"], out["opacity"], out["means3D"], out["cov3D"], out["sh"], out["scales"],
                 out["rotations"])
 

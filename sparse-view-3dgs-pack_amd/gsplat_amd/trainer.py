@@ -769,6 +769,11 @@ class Trainer:
         # the address of a dead trainer is handed to the next one, which would then inherit its cameras' hints and limits
         Trainer._uids = getattr(Trainer, "_uids", 0) + 1
         self.uid = Trainer._uids
+        # the backend keeps per-camera state under ("trainer", uid, camera): it goes when this trainer does
+        be = getattr(getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None), "backend", None)
+        if be is not None and hasattr(be, "drop_camera_entries"):
+            import weakref
+            weakref.finalize(self, be.drop_camera_entries, ("trainer", self.uid))
         self._stack = []    # train.py:106-111: cameras are drawn without replacement
         self._rng = None
 
@@ -939,6 +944,10 @@ class Trainer:
             rm = None if rm is None else rm.clone()
         if fused:
             loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
+            # two-phase step: the Adam stream of the Gaussians without instances starts HERE, on its side stream - it needs
+            # nothing of the loss - and runs under the criterion's backward kernels and the backward blend
+            if fused_step and backend is not None:
+                backend.launch_uninstanced_early()
             # (seeded with the criterion's cached constant 1: no fill kernel for the implicit seed, no multiply by it)
             torch.autograd.backward(loss, self.criterion.ops.unit_grad(loss.device))
         else:
@@ -1209,6 +1218,13 @@ class TrainerNIR(Trainer):
 # ----------------------------------------------------------------------------------------------------------------
 # hipGraph replay of the steady-state single-GPU step
 # ----------------------------------------------------------------------------------------------------------------
+def _status_check(tag, num_rendered, overflow, trunc_failed):
+    """include/gsplat.h GS_STATUS_CHECK"""
+    m = 0xFFFFFFFF
+    return (((tag & m) * 2654435761) & m) ^ (((num_rendered & m) * 40503) & m) ^ ((overflow << 30) & m) ^ ((trunc_failed << 31) & m) \
+        ^ 0x5bd1e995
+
+
 class GraphedStep:
     """Captures the train step of a Trainer (forward, fused criterion, gs_backward_step) into hipGraphs - ONE PER CAMERA -
     and replays them: the kernel launches of a step, their Python glue and the forward's host wait become one graph launch.
@@ -1222,7 +1238,9 @@ class GraphedStep:
     Everything frozen at capture is checked before a replay (model buffers, image size, field of view, active SH degree,
     the camera's tensors, the binning capacity); when it no longer holds the camera is captured again.  A view that needs
     more binning capacity than was captured, or whose depth limits failed, did nothing on the device (gs_backward_step
-    skips on either flag): the step is then taken eagerly (settle).  Results are those of the eager fused step: same
+    skips on either flag): the step is then taken eagerly (settle).  SINGLE-THREADED by contract: while a capture is open
+    nothing else in the process may free device memory (the cyclic collector is fenced in _capture; a tensor another thread
+    drops by refcount is not).  Results are those of the eager fused step: same
     kernels, same arguments."""
 
     def __init__(self, trainer, capacity_margin=1.5, warmup=3, capacity=None):
@@ -1258,7 +1276,23 @@ class GraphedStep:
         return (m.P, m.generation, m.denom.data_ptr(), m.max_radii2D.data_ptr(), m.xyz_gradient_accum.data_ptr(),
                 m.active_sh_degree, int(cam.image_height), int(cam.image_width), float(cam.FoVx), float(cam.FoVy),
                 cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr(), cam.camera_center.data_ptr(),
-                tr.gts[ci].data_ptr(), None if mask is None else mask.data_ptr(), self.capacity, bool(tr.depth_limit))
+                tr.gts[ci].data_ptr(), None if mask is None else mask.data_ptr(), self.capacity, bool(tr.depth_limit),
+                self._entry_ptrs(ci), self._backend().rows_epoch)
+
+    def _entry_ptrs(self, ci):
+        """The addresses a capture of camera `ci` bakes in from the backend's per-camera entry (tile order, depth limits,
+        slack): the entry the backend holds NOW - should it ever be replaced, the key changes and the camera is captured again."""
+        ent = self.camera_entry(ci)
+        return None if ent is None else (ent["order"].data_ptr(), ent["limit"].data_ptr(), ent["slack"].data_ptr())
+
+    def _drop_graph(self, ci):
+        g = self.graphs.pop(ci, None)
+        if g is not None and g.get("entry") is not None:
+            g["entry"]["pinned"] = max(0, g["entry"].get("pinned", 0) - 1)
+
+    def _drop_all_graphs(self):
+        for ci in list(self.graphs):
+            self._drop_graph(ci)
 
     def _backend(self):
         tr = self.tr
@@ -1341,7 +1375,7 @@ class GraphedStep:
             # A cyclic-garbage sweep INSIDE the capture may free tensors of an earlier capture's pool (autograd contexts are
             # cycles) - a device free while the stream is capturing aborts the process.  So: this camera's old graph goes
             # first, garbage is collected now, and the collector stays off until the capture has ended.
-            self.graphs.pop(ci, None)
+            self._drop_graph(ci)
             gc.collect()
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
@@ -1373,7 +1407,12 @@ class GraphedStep:
             self.eager_steps += 1
             self.s_loss = tr._step_camera(ci, True, ())
             return self.s_loss
-        self.graphs[ci] = dict(graph=graph, key=self._key(ci), loss=loss, rm_before=rm_before)
+        # the graph holds the addresses of this camera's entry: the entry is pinned (never evicted from the backend's cache)
+        # and referenced from here for as long as the graph lives
+        ent = self.camera_entry(ci)
+        if ent is not None:
+            ent["pinned"] = ent.get("pinned", 0) + 1
+        self.graphs[ci] = dict(graph=graph, key=self._key(ci), loss=loss, rm_before=rm_before, entry=ent)
         self.captures += 1
         self.s_loss = loss
         return loss
@@ -1392,7 +1431,7 @@ class GraphedStep:
             be.depth_limit_stats["failed"] += 1
             be.limits_failed(ent)     # (this camera's exported bounds get more slack: RasterBackend.SLACK)
         if overflow or num_rendered > self.capacity:
-            self.graphs.clear()
+            self._drop_all_graphs()
             self.capacity = None   # (the eager step that follows grows the backend's hint; the next capture reads it)
 
     def _view_ok(self, be):
@@ -1439,8 +1478,25 @@ class GraphedStep:
             spins += 1
             if spins > 2000:  # (not there after ~2 ms of polling: wait for the stream the ordinary way)
                 torch.cuda.current_stream(self.s_tag.device).synchronize()
+                if int(st[8]) != p["tag"]:
+                    raise RuntimeError("replay %d never delivered its status (block holds tag %d)" % (p["tag"], int(st[8])))
                 break
-        num_rendered, overflow, trunc_failed = int(st[0]), int(st[1]), int(st[2])
+        # The tag and the status words arrive with ONE 48-byte device-to-host copy, but nothing promises a host poller that
+        # the bytes of a copy land in address order: the block is accepted when its check word (written by the same kernel
+        # that wrote the tag, include/gsplat.h GS_STATUS_CHECK) matches the words read
+        def read():
+            w = (int(st[0]), int(st[1]), int(st[2]), int(st[8]), int(st[9]) & 0xFFFFFFFF)
+            return w, w[3] == p["tag"] and w[4] == _status_check(w[3], w[0], w[1], w[2])
+        seen, ok = read()
+        spins = 0
+        while not ok:
+            spins += 1
+            if spins == 2000:
+                torch.cuda.current_stream(self.s_tag.device).synchronize()
+            if spins > 2001:
+                raise RuntimeError("replay %d delivered an inconsistent status block %r" % (p["tag"], seen))
+            seen, ok = read()
+        num_rendered, overflow, trunc_failed = seen[0], seen[1], seen[2]
         if num_rendered <= p["capacity"] and not overflow and not trunc_failed:
             if tr.depth_limit:
                 ent = self.camera_entry(p["ci"])

@@ -39,6 +39,8 @@ extern "C" int bm_backward_from_rows(const GsView* v, const GsGaussians* g, cons
   a.antialiasing = v->antialiasing;
   a.has_invdepth = depth_mode;
   a.grad_rows = rows;
+  std::vector<float> recs((size_t)P * GC_STRIDE, 0.f);  // chain_kernel's output, read by the streaming kernels
+  a.grad_recs = recs.data();
   a.splat = splat.data();
   a.out = *out;
   for (int i = 0; i < P; i++) {
@@ -46,7 +48,8 @@ extern "C" int bm_backward_from_rows(const GsView* v, const GsGaussians* g, cons
     float* sh_row = (g->shs && out->dL_dsh) ? out->dL_dsh + (size_t)i * g->M * 3 : nullptr;
     if (sh_row) memset(sh_row, 0, sizeof(float) * g->M * 3);
     if (radii[i] > 0) {
-      geometry_backward(a, i, gb);
+      chain_from_row(a, i, rows + (size_t)i * GR_STRIDE, recs.data() + (size_t)i * GC_STRIDE);  // what chain_kernel runs
+      geometry_backward(a, i, gb);                                                                  // what the streaming kernels run
       if (g->shs) {
         float dummy[48 * 4];
         ShSink sink{sh_row ? sh_row : dummy, false};
