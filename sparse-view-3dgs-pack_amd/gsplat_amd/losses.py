@@ -320,6 +320,9 @@ class FusedLGDWTLoss(torch.autograd.Function):
         if params.patch_enable and not ctx.patch_folded:
             api.call("patch_dwt_bwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
                      coef[10:].data_ptr(), grad.data_ptr(), 1, st)
+        hook = getattr(ctx.ops, "before_last_backward_kernel", None)
+        if hook is not None:   # (the train step's side launch, RasterBackend.UNINST_AT = "ssim_backward")
+            hook()
         api.call("ssim_bwd_uniform", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, coef[1:].data_ptr(), d1.data_ptr(),
                  d2.data_ptr(), d3.data_ptr(), grad.data_ptr(), 1, raw.data_ptr(), st)
         return None, grad, None, None, None, None, None

@@ -384,8 +384,13 @@ class RasterBackend:
     # Where the side launch of the two-phase step (gs_step_uninstanced) is issued:
     #   "loss_backward"  by the train step, right before the criterion's backward kernels (Trainer calls
     #                    launch_uninstanced_early): it then runs under ssim_bwd / dwt2_l1_bwd and the backward blend
+    #   "ssim_backward"  from inside the criterion's backward, before its last kernel (ssim_bwd)
     #   "raster_backward" at the start of the rasterizer's backward, next to the blend only (round 3)
-    UNINST_AT = os.environ.get("GS_UNINST_AT", "loss_backward")
+    # Same box, C3 (gpurun_out/r04/ab4.log): ssim_backward 0.983 ms/step (ssim_bwd 43 -> 52 us beside the stream, blend 0.40),
+    # loss_backward 1.024 (the stream starts 20 us earlier, under dwt2_l1_bwd too, and ssim_bwd takes 103 us beside it),
+    # raster_backward 1.012 replayed / 1.15 eager (no head start: the blend's 8 160 one-wave workgroups are dealt out first
+    # and the stream's workgroups trickle in behind them, phase 2 waits 0.17 ms for it).
+    UNINST_AT = os.environ.get("GS_UNINST_AT", "ssim_backward")
 
     def rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                              cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
@@ -432,6 +437,8 @@ class RasterBackend:
         main = torch.cuda.current_stream(device)
         side = self._side_streams.get(device.index)
         if side is None:
+            # (a CU-masked side stream - hipExtStreamCreateWithCUMask, 64 / 96 / 128 CUs - was tried in round 4: the two
+            #  queues then did not overlap at all, every kernel of the step ran ~10 % slower, step 0.98 -> 1.18-1.20 ms)
             side = self._side_streams[device.index] = torch.cuda.Stream(device=device)
         side.wait_stream(main)   # (the forward has decided overflow / trunc_failed)
         with torch.cuda.stream(side):

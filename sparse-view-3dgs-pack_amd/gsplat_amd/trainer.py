@@ -947,7 +947,11 @@ class Trainer:
             # two-phase step: the Adam stream of the Gaussians without instances starts HERE, on its side stream - it needs
             # nothing of the loss - and runs under the criterion's backward kernels and the backward blend
             if fused_step and backend is not None:
-                backend.launch_uninstanced_early()
+                if backend.UNINST_AT == "ssim_backward":   # ... or between the criterion's two backward kernels
+                    self.criterion.ops.before_last_backward_kernel = backend.launch_uninstanced_early
+                else:
+                    self.criterion.ops.before_last_backward_kernel = None
+                    backend.launch_uninstanced_early()
             # (seeded with the criterion's cached constant 1: no fill kernel for the implicit seed, no multiply by it)
             torch.autograd.backward(loss, self.criterion.ops.unit_grad(loss.device))
         else:
