@@ -113,12 +113,14 @@ def build_workload(cfg, device, rank, world, seed=0, scene_kind="trained_like", 
         g = torch.Generator().manual_seed(seed + 2)
         nirs = [None if x is None else (torch.round(torch.rand((1, H, W), generator=g) * 255.0) / 255.0).to(device) for x in gts]
         model = GaussianModelLite(scene, device, api=hip_api_(), with_nir=True)
+        # the multispectral step on the fused machinery (GS_BENCH_NIR_FUSED=0: round-3 form - un-fused criterion and optimizer tail)
+        nir_fused = os.environ.get("GS_BENCH_NIR_FUSED", "1") != "0"
         rgb_crit, masks = None, None
         if dwt or patch:
-            rgb_crit = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch, fused=False)
+            rgb_crit = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch, fused=nir_fused)
             if patch:
                 masks = [None if x is None else rgb_crit.elf_mask(x) for x in gts]
-        tr = TrainerNIR(model, cams, gts, nirs, NirCriterion(LossOps(hip_api_()), rgb_criterion=rgb_crit),
+        tr = TrainerNIR(model, cams, gts, nirs, NirCriterion(LossOps(hip_api_()), rgb_criterion=rgb_crit, fused=nir_fused),
                         dgr.GaussianRasterizationSettings, bg, rank=rank, world_size=world, masks=masks)
         return tr, scene, cams, gts
     model = GaussianModelLite(scene, device, api=hip_api_())
@@ -303,7 +305,8 @@ def main():
     # region (a replay saves the launches and their Python glue but waits for the device once per step, which costs
     # more than it saves once a step is longer than ~1 ms: C1 0.75 -> 0.50 ms, C3 1.57 -> 1.63 ms); 0 / 1 force a form.
     graph_mode = os.environ.get("GS_BENCH_GRAPH", "auto")
-    use_graph = world == 1 and args.config not in NIR_CONFIGS and graph_mode != "0"
+    nir_unfused = args.config in NIR_CONFIGS and os.environ.get("GS_BENCH_NIR_FUSED", "1") == "0"
+    use_graph = world == 1 and not nir_unfused and graph_mode != "0"
     graphed, graph_choice = None, None
     if use_graph:
         from gsplat_amd.trainer import GraphedStep
@@ -312,7 +315,7 @@ def main():
     # depth-limited instance lists (csrc/gs_tilecull.h; exact, verified by the forward, verdict collected one step later -
     # gsplat_amd.trainer.Trainer.depth_limit): GS_BENCH_DEPTH_LIMIT=0 switches them off
     # (default: on from 100 k Gaussians - on the 10 k scene of c1 there is nothing to cut and the two extra launches cost 3 %)
-    depth_limit = args.config not in NIR_CONFIGS and \
+    depth_limit = not nir_unfused and \
         os.environ.get("GS_BENCH_DEPTH_LIMIT", "1" if P >= 100_000 else "0") != "0"
     if depth_limit:
         tr.depth_limit = "deferred"

@@ -102,6 +102,10 @@ typedef struct GsGaussians {
                                   bit - so the activated copies are never written nor read.  Honoured by
                                   gs_forward_geometry and gs_backward_step only (the plain backward returns gradients
                                   with respect to the activated values: GS_E_UNSUPPORTED with this flag) */
+  const float* extra_gain;     /* with raw_activations and extra_channel: device scalar; the blended 4th channel is then
+                                  sigmoid(extra_channel[i]) * clamp(*extra_gain, 0.1, 10) - the multispectral model's raw NIR
+                                  albedo and global gain (mult-dwtgs/gaussian_renderer/__init__.py:166-169), activated in
+                                  the kernel like the other raw rows.  NULL: extra_channel holds the values to blend */
 } GsGaussians;
 
 /* Caller-owned scratch.  geom and img sizes depend on (P, W, H); binning on the capacity in
@@ -279,7 +283,8 @@ typedef struct GsStepState {
   float* max_radii2D;        /* [P] densification statistics of train.py:266-268 (all three or none) */
   float* xyz_gradient_accum; /* [P] */
   float* denom;              /* [P] */
-  const float* coef_dev;      /* optional, device, 11 floats: lr[c] / (1 - beta1^t) for the six learning-rate classes, then
+  const float* coef_dev;      /* optional, device, 11 floats (15 with st->extra: + the same two constants of the sixth row and
+                                of the gain): lr[c] / (1 - beta1^t) for the six learning-rate classes, then
                                 1 / sqrt(1 - beta2^t) for the five rows.  NULL: computed from lr[] / step[] on the host and
                                 passed as kernel arguments.  A caller that REPLAYS a captured graph of the step must use
                                 this form (kernel arguments are frozen at capture) and refresh the buffer before each
@@ -311,11 +316,34 @@ typedef struct GsStepState {
   void* phase1_done; /* with phase = 2: a hipEvent_t recorded behind gs_step_uninstanced on its stream, or NULL.  gs_backward_step
                         makes its stream wait for it AFTER the backward blend has been launched - the two then run side by
                         side - and before the per-Gaussian kernel.  NULL: the caller has ordered the two calls itself. */
+  /* ---- 4th blended channel (gs_backward_step_x; multispectral train step, mult-dwtgs/train_nir.py): g->extra_channel must
+   * BE st->extra (the raw per-Gaussian parameter, e.g. the NIR albedo before its sigmoid) and g->extra_gain st->gain.  The
+   * raw row is stepped like the five rows above (sixth row: lr_extra, step_extra, coef_dev[11..12]); the global gain - one
+   * scalar, dL/dgain = sum_i dL/dextra_i sigmoid(raw_i) inside the clamp, 0 outside - by the first workgroup of the
+   * per-Gaussian kernel, from one partial sum per 256 Gaussians that the float64 chain kernel left behind the records in
+   * the workspace, added in index order (deterministic; lr_gain, step_gain, coef_dev[13..14]).  Data-parallel form:
+   * grad_out_extra [P] / grad_out_gain [1] receive the gradients instead. */
+  float* extra;    /* [P] or NULL (then none of the fields below is read) */
+  float* extra_m;
+  float* extra_v;
+  float* gain;     /* device scalar */
+  float* gain_m;
+  float* gain_v;
+  float lr_extra, lr_gain;
+  int32_t step_extra, step_gain;
+  float* grad_out_extra;
+  float* grad_out_gain;
 } GsStepState;
 int gs_backward_step(const GsView* view, const GsGaussians* g, const int32_t* radii,
                      const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
                      const float* dL_dinvdepth, const GsStepState* st, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* gs_backward_step behind gs_forward_render_x: dL_dextra_img [H,W] is the image gradient of the 4th channel; st->extra et
+ * al. describe its parameters (see GsStepState). */
+int gs_backward_step_x(const GsView* view, const GsGaussians* g, const int32_t* radii,
+                       const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
+                       const float* dL_dinvdepth, const float* dL_dextra_img, const GsStepState* st,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* The part of gs_backward_step that does not wait for the loss: a Gaussian that emitted no instance in this view
  * (tiles_touched == 0: off screen, culled, or cut by the depth limits - four fifths of them on depth-limited lists) has
@@ -508,7 +536,10 @@ typedef struct GsLgdwtParams {
   int32_t dwt_enable, patch_enable;
   int32_t reset_sums;        /* 1: the call zeroes sums[0..12] after it has read them (the accumulators of the next view:
                                 a caller that keeps ONE sums buffer per camera, word 13 preset, then needs no fill kernel) */
-  int32_t _pad;
+  int32_t custom_base;       /* 1: base = w_l1 * L1 + w_ssim * (1 - SSIM) instead of (1 - lambda) L1 + lambda (1 - SSIM): the NIR
+                                term of mult-dwtgs/train_nir.py:96-104 (nir_weight * (L1 + 0.2 (1 - SSIM)),
+                                mult-dwtgs/utils/loss_utils.py:93-144) through the same kernels */
+  float w_l1, w_ssim;
 } GsLgdwtParams;
 /* sums[16]: 0 l1 | 1 ssim | 2..9 bands | 10..12 patch | 13 selected patches.  running_mean: device scalar,
  * updated in place (train.py:193-195).  out[24]: 0 loss 1 base 2 dwt 3 patch 4 dwt_scale 5 l1 6 ssim 7 the running mean

@@ -564,7 +564,9 @@ int gso_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParam
   const GsLgdwtParams& p = *pp;
   const float l1 = sums[0] / p.n_pix;
   const float ssim = sums[1] / p.n_pix;
-  const float base = (1.0f - p.lambda_dssim) * l1 + p.lambda_dssim * (1.0f - ssim);
+  /* custom_base: the NIR term of mult-dwtgs/train_nir.py:96-104 (w_l1 L1 + w_ssim (1 - SSIM)) */
+  const float w_l1 = p.custom_base ? p.w_l1 : 1.0f - p.lambda_dssim, w_ssim = p.custom_base ? p.w_ssim : p.lambda_dssim;
+  const float base = w_l1 * l1 + w_ssim * (1.0f - ssim);
   float loss = base, dwt = 0.f, scale = 0.f, patch = 0.f;
   for (int k = 0; k < 24; k++) out[k] = 0.f;
   out[7] = running_mean[0];
@@ -586,8 +588,8 @@ int gso_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParam
     loss = loss + p.patch_weight * patch;
   }
   out[0] = loss; out[1] = base; out[2] = dwt; out[3] = patch; out[4] = scale; out[5] = l1; out[6] = ssim;
-  out[8] = (1.0f - p.lambda_dssim) / p.n_pix;
-  out[9] = -p.lambda_dssim / p.n_pix;
+  out[8] = w_l1 / p.n_pix;
+  out[9] = -w_ssim / p.n_pix;
   if (p.reset_sums)
     for (int k = 0; k < 13; k++) const_cast<float*>(sums)[k] = 0.f;
   return GS_OK;

@@ -121,6 +121,7 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   tile_grid(v, a.grid_x, a.grid_y);
   a.antialiasing = v->antialiasing;
   a.extra_channel = g->extra_channel;
+  a.extra_gain = g->extra_gain;
   a.tile_cull = v->tile_cull;
   a.tile_depth_limit = v->tile_cull ? sc->tile_depth_limit : nullptr;
   a.region_count = nullptr;
@@ -356,6 +357,9 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
   a.tan_fovy = v->tanfovy;
   a.antialiasing = v->antialiasing;
   a.has_invdepth = depth_mode;
+  a.has_extra = g->extra_channel != nullptr;
+  a.extra_raw = a.extra_gain = nullptr;
+  a.gain_partials = nullptr;
   a.grad_rows = rows;
   a.grad_recs = recs;
   a.clean_rows = 0;
@@ -374,11 +378,26 @@ static int step_args(const GsGaussians* g, const GsStepState* st, StepArgs& sa) 
   const bool any_stat = st->max_radii2D || st->xyz_gradient_accum || st->denom;
   if (any_stat && !(st->max_radii2D && st->xyz_gradient_accum && st->denom)) return GS_E_NULL;
   if (g->means3D != st->xyz || g->shs != st->features) return GS_E_SHAPE;  // no activation between them
-  if (g->M != 16 || g->colors_precomp || g->cov3D_precomp || !g->scales || !g->rotations || g->extra_channel)
-    return GS_E_UNSUPPORTED;
+  if (g->M != 16 || g->colors_precomp || g->cov3D_precomp || !g->scales || !g->rotations) return GS_E_UNSUPPORTED;
+  // the 4th channel: its raw row and the gain are this step's parameters, or there is no 4th channel at all
+  if ((g->extra_channel != nullptr) != (st->extra != nullptr)) return GS_E_UNSUPPORTED;
+  if (st->extra) {
+    if (g->extra_channel != st->extra || g->extra_gain != st->gain || !st->gain || !g->raw_activations) return GS_E_SHAPE;
+    if (grads_out ? (!st->grad_out_extra || !st->grad_out_gain) : (!st->extra_m || !st->extra_v || !st->gain_m || !st->gain_v))
+      return GS_E_NULL;
+    if (st->step_extra < 0 || st->step_gain < 0) return GS_E_SHAPE;
+  }
   sa.st = *st;
   sa.phase = 0;
   sa.phase1_workgroups = 0;
+  sa.gain_partials = nullptr;
+  {
+    const int tx = st->step_extra > 0 ? st->step_extra : 1, tg = st->step_gain > 0 ? st->step_gain : 1;
+    sa.x_inv_sqrt_bc2[0] = (float)(1.0 / sqrt(1.0 - pow((double)st->beta2, (double)tx)));
+    sa.x_inv_sqrt_bc2[1] = (float)(1.0 / sqrt(1.0 - pow((double)st->beta2, (double)tg)));
+    sa.x_lr_bc1[0] = st->lr_extra * (float)(1.0 / (1.0 - pow((double)st->beta1, (double)tx)));
+    sa.x_lr_bc1[1] = st->lr_gain * (float)(1.0 / (1.0 - pow((double)st->beta1, (double)tg)));
+  }
   static const int row_of_lr[6] = {0, 1, 1, 2, 3, 4};
   for (int k = 0; k < 5; k++) {
     if (st->step[k] < 0) return GS_E_SHAPE;
@@ -440,6 +459,13 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, recs, grads);
   a.skip_uninstanced = v->tile_cull ? 1 : 0;  // (with the reference's lists every visible Gaussian has instances)
   a.clean_rows = rows_clean != 0;
+  if (step && step->extra) {  // per-wave partial sums of dL/dgain: behind the records
+    float* gp = reinterpret_cast<float*>((char*)workspace + gs_align((size_t)P * GR_ROW_BYTES) + gs_align((size_t)P * GC_REC_BYTES));
+    a.extra_raw = step->extra;
+    a.extra_gain = step->gain;
+    a.gain_partials = gp;
+    sa.gain_partials = gp;
+  }
   {  // float64 sums -> fp32 records (the covariance chain in double); cleans the rows it read when asked to
     GS_PROF(ST_CHAIN, s);
     launch_chain(a, step ? gv.hdr : nullptr, s);
@@ -447,6 +473,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   if (step) {
     GS_PROF(ST_BWD_STEP, s);
     sa.hdr = gv.hdr;
+
     if (step->phase == 2) {  // the Gaussians without instances are stepped by gs_step_uninstanced (maybe still running)
       if (!v->tile_cull || step->grad_out[0]) return GS_E_UNSUPPORTED;
       sa.phase = 2;
@@ -472,6 +499,16 @@ int gs_backward_step(const GsView* v, const GsGaussians* g, const int32_t* radii
   if (!st) return GS_E_NULL;
   const GsGrads none = {};
   return backward_impl(v, g, radii, sc, num_rendered, dL_dcolor, dL_dinvdepth, nullptr, 0, &none, workspace, workspace_bytes,
+                       stream, st);
+}
+
+int gs_backward_step_x(const GsView* v, const GsGaussians* g, const int32_t* radii, const GsScratch* sc, int64_t num_rendered,
+                       const float* dL_dcolor, const float* dL_dinvdepth, const float* dL_dextra_img, const GsStepState* st,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!st) return GS_E_NULL;
+  if (g && ((dL_dextra_img != nullptr) != (g->extra_channel != nullptr))) return GS_E_NULL;
+  const GsGrads none = {};
+  return backward_impl(v, g, radii, sc, num_rendered, dL_dcolor, dL_dinvdepth, dL_dextra_img, 0, &none, workspace, workspace_bytes,
                        stream, st);
 }
 

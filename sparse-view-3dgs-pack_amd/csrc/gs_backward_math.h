@@ -382,7 +382,7 @@ GS_DEV void geometry_backward(const PreprocessBwdArgs& a, int idx, GeomBack& o) 
   o.dmean2D_y = r0.y;
   o.dop = r1.y;
   o.dcolor = {r3.y, r3.z, r3.w};
-  o.dextra = a.out.dL_dextra ? a.grad_recs[(size_t)idx * GC_STRIDE + GC_EXTRA] : 0.f;
+  o.dextra = a.has_extra ? a.grad_recs[(size_t)idx * GC_STRIDE + GC_EXTRA] : 0.f;
   const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
   o.dmean = V3{r0.z, r0.w, r1.x} + projection_backward(mean, a.projmatrix, o.dmean2D_x, o.dmean2D_y);
   o.dscale = {0.f, 0.f, 0.f};

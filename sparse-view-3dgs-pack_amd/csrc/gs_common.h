@@ -169,7 +169,10 @@ typedef double gs_row_t;
 enum { GC_MX = 0, GC_MY, GC_DMX, GC_DMY, GC_DMZ, GC_DOP, GC_C0, GC_R = GC_C0 + 7, GC_G, GC_B, GC_EXTRA, GC_STRIDE = 20 };
 #define GC_REC_BYTES (GC_STRIDE * sizeof(float))
 // backward workspace = rows [P][GR_STRIDE] float64, then records [P][GC_STRIDE] fp32
-static inline __host__ __device__ size_t bwd_workspace_bytes(size_t P) { return gs_align(P * GR_ROW_BYTES) + gs_align(P * GC_REC_BYTES); }
+// ... then the per-wave partial sums of dL/dgain (fused multispectral step)
+static inline __host__ __device__ size_t bwd_workspace_bytes(size_t P) {
+  return gs_align(P * GR_ROW_BYTES) + gs_align(P * GC_REC_BYTES) + gs_align(4 * ((P + GS_BLOCK - 1) / GS_BLOCK + 4));
+}
 
 // rasterizer_impl.cu:35-50 (host)
 static inline uint32_t gs_higher_msb(uint32_t n) {
@@ -228,6 +231,7 @@ struct PreprocessArgs {
   int grid_x, grid_y;
   int antialiasing;
   const float* extra_channel;  // [P] or NULL
+  const float* extra_gain;     // GsGaussians.extra_gain
   int tile_cull;  // GsView.tile_cull: 1 = emit only tiles the alpha >= 1/255 ellipse can reach (gs_tilecull.h); 2 = region binning
   const float* tile_depth_limit;  // [T] or NULL: depth-limited emission (gs_tilecull.h); only with tile_cull
   int raw_activations;            // GsGaussians.raw_activations
@@ -301,6 +305,14 @@ struct PreprocessBwdArgs {
   float focal_x, focal_y, tan_fovx, tan_fovy;
   int antialiasing;
   int has_invdepth;  // 0: none, 1: inverse-depth image gradient (dr_aa), 2: depth image gradient (FSGS generation)
+  int has_extra;     // a 4th channel was blended: slot GC_EXTRA of the records carries its per-Gaussian gradient
+  // fused multispectral step (GsStepState.extra): the channel is sigmoid(extra_raw[i]) * clamp(*extra_gain, 0.1, 10).  The chain
+  // kernel then stores dL/dextra_i * clamp(gain) in GC_EXTRA (what the raw row's activation backward needs) and wave w's share
+  // of dL/dgain = sum_i dL/dextra_i sigmoid(raw_i) [gain inside the clamp] in gain_partials[w] - so that the streaming
+  // kernel never reads the gain and its first workgroup can step it from the partials, added in index order
+  const float* extra_raw;
+  const float* extra_gain;
+  float* gain_partials;  // [ceil(P / 256)]
   int raw_activations;  // GsGaussians.raw_activations
   int skip_uninstanced;  // rows come from the blend backward of THIS forward: a Gaussian that emitted no instance (culled spans,
                          // depth limits) has all-zero sums and so all-zero gradients - its geometry / SH backward is skipped
@@ -320,6 +332,8 @@ struct StepArgs {
   GsStepState st;
   float lr_bc1[6];        // lr / (1 - beta1^t) per learning-rate class   (st.coef_dev, when given, replaces both arrays)
   float inv_sqrt_bc2[5];  // 1 / sqrt(1 - beta2^t) per row
+  float x_lr_bc1[2], x_inv_sqrt_bc2[2];  // the same for the 4th channel's raw row [0] and its global gain [1]
+  const float* gain_partials;  // [workgroups] written by the chain kernel: per-wave sums of dL/dgain
   const GeomHeader* hdr;  // overflow (binning capacity exceeded, nothing blended) or trunc_failed set -> the step is a no-op
   int phase;              // 0 every Gaussian | 1 only those without instances | 2 only those with (gs_step_uninstanced)
   int phase1_workgroups;  // grid of the throttled phase-1 kernel (0 = default)

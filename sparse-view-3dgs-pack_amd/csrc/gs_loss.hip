@@ -1099,7 +1099,8 @@ __global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __rest
   float ptot = 0.f;
   for (int w = 0; w < 16; w++) ptot += red[w];
   const float ssim = (sums[1] + ptot) / p.n_pix;
-  const float base = (1.0f - p.lambda_dssim) * l1 + p.lambda_dssim * (1.0f - ssim);
+  const float w_l1 = p.custom_base ? p.w_l1 : 1.0f - p.lambda_dssim, w_ssim = p.custom_base ? p.w_ssim : p.lambda_dssim;
+  const float base = w_l1 * l1 + w_ssim * (1.0f - ssim);
   float loss = base;
   float dwt = 0.f, scale = 0.f, patch = 0.f;
   for (int k = 0; k < 24; k++) out[k] = 0.f;
@@ -1125,8 +1126,8 @@ __global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __rest
     loss = loss + p.patch_weight * patch;
   }
   out[0] = loss; out[1] = base; out[2] = dwt; out[3] = patch; out[4] = scale; out[5] = l1; out[6] = ssim;
-  out[8] = (1.0f - p.lambda_dssim) / p.n_pix;
-  out[9] = -p.lambda_dssim / p.n_pix;
+  out[8] = w_l1 / p.n_pix;
+  out[9] = -w_ssim / p.n_pix;
   if (p.reset_sums) {  // every sum has been read (this thread read them all): ready for the next view's accumulation
     float* z = const_cast<float*>(sums);
     for (int k = 0; k < 13; k++) z[k] = 0.f;

@@ -165,6 +165,14 @@ GS_DEV V4 load_rotation(const float* p, int idx, int raw) {
   const float n = fmaxf(sqrtf(x * x + y * y + z * z + w * w), 1e-12f);
   return {x / n, y / n, z / n, w / n};
 }
+// the 4th blended channel of the multispectral model: sigmoid(raw albedo) * clamp(gain, 0.1, 10)
+// (mult-dwtgs/gaussian_renderer/__init__.py:166-169; torch.clamp keeps the gradient on [min, max])
+GS_DEV float clamp_gain(float g) { return fminf(10.0f, fmaxf(0.1f, g)); }
+GS_DEV float load_extra(const float* p, const float* gain, int idx, int raw) {
+  const float x = p[idx];
+  if (!raw || !gain) return x;
+  return (1.0f / (1.0f + expf(-x))) * clamp_gain(*gain);
+}
 GS_DEV float load_opacity(const float* p, int idx, int raw) {
   const float o = p[idx];
   return raw ? 1.0f / (1.0f + expf(-o)) : o;

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       sp.depth = p_view.z;
       sp.invdepth = 1 / p_view.z;
       radius_out = radius_i;
-      sp.extra = a.extra_channel ? a.extra_channel[idx] : 0.f;
+      sp.extra = a.extra_channel ? load_extra(a.extra_channel, a.extra_gain, idx, a.raw_activations) : 0.f;
       sp.x = pix_x;
       sp.y = pix_y;
       sp.cxx = conic.x; sp.cxy = conic.y; sp.cyy = conic.z;

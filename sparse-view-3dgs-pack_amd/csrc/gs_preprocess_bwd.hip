@@ -47,14 +47,36 @@ __global__ void __launch_bounds__(64, 3) chain_kernel(PreprocessBwdArgs a, const
   // the forward ran out of binning capacity or its depth limits proved too tight (possible only when the caller did not
   // re-run it: deferred verdict, replayed graph): the step kernels do nothing - only leave the rows clean
   const bool failed = hdr && (hdr->overflow | hdr->trunc_failed) != 0u;
+  // fused multispectral step: the 4th channel is sigmoid(raw) * clamp(gain) - fold clamp(gain) into the record's gradient
+  // and collect this wave's share of dL/dgain (see PreprocessBwdArgs)
+  float gc = 1.0f, dgain = 0.f;
+  bool gain_free = false;
+  if (a.gain_partials) {
+    const float gain = *a.extra_gain;
+    gc = clamp_gain(gain);
+    gain_free = gain >= 0.1f && gain <= 10.0f;
+  }
   for (int j = lane; j < n; j += 64) {
     const int idx = s_list[j];
     gs_row_t* row = const_cast<gs_row_t*>(a.grad_rows) + (size_t)idx * GR_STRIDE;
-    if (!failed) chain_from_row(a, idx, row, a.grad_recs + (size_t)idx * GC_STRIDE);
+    float* rec = a.grad_recs + (size_t)idx * GC_STRIDE;
+    if (!failed) {
+      chain_from_row(a, idx, row, rec);
+      if (a.gain_partials) {
+        const float dextra = rec[GC_EXTRA];
+        if (gain_free) dgain += dextra * (1.0f / (1.0f + expf(-a.extra_raw[idx])));
+        rec[GC_EXTRA] = dextra * gc;
+      }
+    }
     if (a.clean_rows) {
       float4* w = reinterpret_cast<float4*>(row);
       w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = make_float4(0.f, 0.f, 0.f, 0.f);  // the twelve slots in use
     }
+  }
+  if (a.gain_partials) {  // (a fixed tree over the 64 lanes: the same bits whenever the wave runs)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dgain += __shfl_down(dgain, off, 64);
+    if (lane == 0) a.gain_partials[blockIdx.x] = dgain;
   }
 }
 int launch_chain(const PreprocessBwdArgs& a, const GeomHeader* hdr, hipStream_t s) {
@@ -279,7 +301,36 @@ __device__ __forceinline__ void grad_block(float* __restrict__ out, int first, i
 #define SG_OPAC (3 * GS_BLOCK)
 #define SG_SCALE (4 * GS_BLOCK)
 #define SG_ROT (7 * GS_BLOCK)
-#define SG_TOTAL (11 * GS_BLOCK)
+#define SG_EXTRA (11 * GS_BLOCK)
+#define SG_TOTAL (12 * GS_BLOCK)
+
+// dL/dgain of the fused multispectral step: chain_kernel left one partial sum per wave of 256 Gaussians; the FIRST workgroup
+// of the per-Gaussian kernel adds them in index order (fixed shape: the same bits every run) and steps the gain - or stores
+// the gradient (data-parallel form).  No other workgroup reads the gain (its clamp is folded into the records).
+static_assert(CHAIN_PER_WAVE == GS_BLOCK, "one partial per workgroup of the streaming kernels");
+__device__ __forceinline__ void gain_step(const StepArgs& sa, bool grads_out, float b1, float b2, float eps) {
+  __shared__ float s_red[GS_BLOCK];
+  const GsStepState& st = sa.st;
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  for (unsigned j = tid; j < gridDim.x; j += GS_BLOCK) acc += sa.gain_partials[j];
+  s_red[tid] = acc;
+  __syncthreads();
+  for (int w = GS_BLOCK / 2; w > 0; w >>= 1) {
+    if (tid < w) s_red[tid] += s_red[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float g = s_red[0];
+    if (grads_out) {
+      *st.grad_out_gain = g;
+    } else if (st.step_gain > 0) {
+      float p = *st.gain, m = *st.gain_m, v = *st.gain_v;
+      adam_update(p, g, m, v, sa.x_lr_bc1[1], sa.x_inv_sqrt_bc2[1], b1, b2, eps);
+      *st.gain = p; *st.gain_m = m; *st.gain_v = v;
+    }
+  }
+}
 
 // PHASE (StepArgs.phase; the two-phase step, gs_step_uninstanced): 0 = every Gaussian.  2 = the Gaussians WITH instances
 // (statistics; Adam on every float4 that holds one of their elements) - the others are stepped by step_uninstanced_kernel
@@ -314,6 +365,10 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
     for (int k = 0; k < 6; k++) sa.lr_bc1[k] = st.coef_dev[k];
 #pragma unroll
     for (int k = 0; k < 5; k++) sa.inv_sqrt_bc2[k] = st.coef_dev[6 + k];
+    if (st.extra) {
+      sa.x_lr_bc1[0] = st.coef_dev[11]; sa.x_inv_sqrt_bc2[0] = st.coef_dev[12];
+      sa.x_lr_bc1[1] = st.coef_dev[13]; sa.x_inv_sqrt_bc2[1] = st.coef_dev[14];
+    }
   }
   const int tid = threadIdx.x;
   const int idx_raw = blockIdx.x * GS_BLOCK + tid;
@@ -356,6 +411,7 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
 #pragma unroll
       for (int k = 0; k < 4; k++) s_g[SG_ROT + 4 * tid + k] = 0.f;
       s_g[SG_OPAC + tid] = 0.f;
+      s_g[SG_EXTRA + tid] = 0.f;
     } else {
       // opacity = sigmoid(raw): grad * s * (1 - s)
       const float sg = 1.0f / (1.0f + expf(-st.opacity[idx]));
@@ -382,6 +438,11 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) s_g[SG_ROT + 4 * tid + k] = g[k];
+      // 4th channel = sigmoid(raw) * clamp(gain): gradient of the raw row (the record holds dL/dextra * clamp(gain))
+      if (st.extra) {
+        const float sx = 1.0f / (1.0f + expf(-st.extra[idx]));
+        s_g[SG_EXTRA + tid] = (gb.dextra * (1.0f - sx)) * sx;
+      }
       // ---- SH half: basis values and colour gradient to the LDS row; the view-direction part completes dL_dmean
       if (active) gb.dmean = gb.dmean + sh_backward_row(a, idx, gb.dcolor, dsh);
       s_g[SG_XYZ + 3 * tid] = gb.dmean.x;
@@ -406,9 +467,11 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
       return src[k] * src[16 + ch];
     }
   };
+  if (st.extra && blockIdx.x == 0) gain_step(sa, grads_out, b1, b2, eps);
   if (grads_out) {
     // the workgroup's contiguous piece of each gradient row array, straight from the LDS image
     if (PHASE == 0) {
+      if (st.extra) grad_block<1>(st.grad_out_extra, first, cnt, Lds{s_g + SG_EXTRA});
       grad_block<3>(st.grad_out[0], first, cnt, Lds{s_g + SG_XYZ});
       grad_block<1>(st.grad_out[2], first, cnt, Lds{s_g + SG_OPAC});
       grad_block<3>(st.grad_out[3], first, cnt, Lds{s_g + SG_SCALE});
@@ -426,6 +489,9 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
     adam_block<3, 0, SEL>(st.scaling, st.m[3], st.v[3], first, cnt, Lds{s_g + SG_SCALE}, sa.lr_bc1[4], 0.f, sa.inv_sqrt_bc2[3], b1, b2, eps, s_sel);
   if (st.step[4] > 0)
     adam_block<4, 0, SEL>(st.rotation, st.m[4], st.v[4], first, cnt, Lds{s_g + SG_ROT}, sa.lr_bc1[5], 0.f, sa.inv_sqrt_bc2[4], b1, b2, eps, s_sel);
+  if (st.extra && st.step_extra > 0)
+    adam_block<1, 0, SEL>(st.extra, st.extra_m, st.extra_v, first, cnt, Lds{s_g + SG_EXTRA}, sa.x_lr_bc1[0], 0.f, sa.x_inv_sqrt_bc2[0], b1, b2,
+                          eps, s_sel);
   if (st.step[1] > 0)
     adam_block<48, 3, SEL>(st.features, st.m[1], st.v[1], first, cnt, ShGrad{s_sh}, sa.lr_bc1[1], sa.lr_bc1[2], sa.inv_sqrt_bc2[1], b1,
                            b2, eps, s_sel);
@@ -445,6 +511,10 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) step_uninstanced_kernel(Preproces
 #pragma unroll
     for (int k = 0; k < 5; k++)
       sa.inv_sqrt_bc2[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st.coef_dev[6 + k])));
+    if (st.extra) {
+      sa.x_lr_bc1[0] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st.coef_dev[11])));
+      sa.x_inv_sqrt_bc2[0] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st.coef_dev[12])));
+    }
   }
   const float b1 = st.beta1, b2 = st.beta2, eps = st.eps;
   const int tid = threadIdx.x;
@@ -474,6 +544,8 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) step_uninstanced_kernel(Preproces
       adam_block<3, 0, 1>(st.scaling, st.m[3], st.v[3], first, cnt, Zero{}, sa.lr_bc1[4], 0.f, sa.inv_sqrt_bc2[3], b1, b2, eps, s_sel);
     if (st.step[4] > 0)
       adam_block<4, 0, 1>(st.rotation, st.m[4], st.v[4], first, cnt, Zero{}, sa.lr_bc1[5], 0.f, sa.inv_sqrt_bc2[4], b1, b2, eps, s_sel);
+    if (st.extra && st.step_extra > 0)
+      adam_block<1, 0, 1>(st.extra, st.extra_m, st.extra_v, first, cnt, Zero{}, sa.x_lr_bc1[0], 0.f, sa.x_inv_sqrt_bc2[0], b1, b2, eps, s_sel);
     if (st.step[1] > 0)
       adam_block<48, 3, 1>(st.features, st.m[1], st.v[1], first, cnt, Zero{}, sa.lr_bc1[1], sa.lr_bc1[2], sa.inv_sqrt_bc2[1], b1,
                            b2, eps, s_sel);

@@ -43,6 +43,7 @@ class GsGaussians(C.Structure):
         ("cov3D_precomp", C.c_void_p),
         ("extra_channel", C.c_void_p),
         ("raw_activations", C.c_int32),
+        ("extra_gain", C.c_void_p),
     ]
 
 
@@ -84,7 +85,7 @@ class GsLgdwtParams(C.Structure):
     _fields_ = [("lambda_dssim", C.c_float), ("n_pix", C.c_float), ("n_band1", C.c_float), ("n_band2", C.c_float),
                 ("dwt_w", C.c_float * 8), ("patch_w", C.c_float * 3), ("patch_weight", C.c_float),
                 ("patch_elems_per_sel", C.c_float), ("dwt_enable", C.c_int32), ("patch_enable", C.c_int32),
-                ("reset_sums", C.c_int32), ("_pad", C.c_int32)]
+                ("reset_sums", C.c_int32), ("custom_base", C.c_int32), ("w_l1", C.c_float), ("w_ssim", C.c_float)]
 
 
 class GsAdamSeg(C.Structure):
@@ -99,7 +100,12 @@ class GsStepState(C.Structure):
                 ("max_radii2D", C.c_void_p), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
                 ("coef_dev", C.c_void_p), ("rows_override", C.c_void_p), ("grad_out", C.c_void_p * 5),
                 ("fail_flag", C.c_void_p), ("phase", C.c_int32), ("rows_clean", C.c_int32),
-                ("phase1_done", C.c_void_p)]
+                ("phase1_done", C.c_void_p),
+                # 4th blended channel (gs_backward_step_x): its raw row, the global gain, their moments and rates
+                ("extra", C.c_void_p), ("extra_m", C.c_void_p), ("extra_v", C.c_void_p), ("gain", C.c_void_p),
+                ("gain_m", C.c_void_p), ("gain_v", C.c_void_p), ("lr_extra", C.c_float), ("lr_gain", C.c_float),
+                ("step_extra", C.c_int32), ("step_gain", C.c_int32), ("grad_out_extra", C.c_void_p),
+                ("grad_out_gain", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -128,6 +134,8 @@ PROTOTYPES = {
                                    C.POINTER(GsStepState), _P]),
     "backward_step": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P,
                                 C.POINTER(GsStepState), _P, _SZ, _P]),
+    "backward_step_x": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _I64, _P, _P, _P,
+                                  C.POINTER(GsStepState), _P, _SZ, _P]),
     "backward_from_rows": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), _P, C.POINTER(GsScratch), _P, _I32,
                                      C.POINTER(GsGrads), _P, _SZ, _P]),
     "mark_visible": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
@@ -184,7 +192,7 @@ PROTOTYPES = {
 # entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
 # (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
 # reference's two 3-channel passes, so the checker does not need it)
-DEVICE_ONLY = ("backward_step", "step_uninstanced", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "adam_step_gated", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
+DEVICE_ONLY = ("backward_step", "backward_step_x", "step_uninstanced", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "adam_step_gated", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
                "forward_render_x", "backward_x")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}

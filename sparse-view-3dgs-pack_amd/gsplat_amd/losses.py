@@ -278,7 +278,7 @@ class FusedLGDWTLoss(torch.autograd.Function):
             img = raw.clamp(0, 1)
             api.call("l1_dwt2_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, sums.data_ptr(), sums[2:].data_ptr(), st)
         else:
-            img = raw.clamp(0, 1)
+            img = raw.clamp(0, 1) if params.clamp else raw
             api.call("l1_fwd", img.data_ptr(), gt.data_ptr(), img.numel(), sums.data_ptr(), st)
         # SSIM sum as per-workgroup partials (no atomics; lgdwt_combine_p adds them up in a fixed order)
         partials = torch.empty((params.n_ssim_partials,), dtype=torch.float32, device=raw.device)
@@ -324,7 +324,7 @@ class FusedLGDWTLoss(torch.autograd.Function):
         if hook is not None:   # (the train step's side launch, RasterBackend.UNINST_AT = "ssim_backward")
             hook()
         api.call("ssim_bwd_uniform", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, coef[1:].data_ptr(), d1.data_ptr(),
-                 d2.data_ptr(), d3.data_ptr(), grad.data_ptr(), 1, raw.data_ptr(), st)
+                 d2.data_ptr(), d3.data_ptr(), grad.data_ptr(), 1, raw.data_ptr() if params.clamp else None, st)
         return None, grad, None, None, None, None, None
 
 
@@ -354,6 +354,10 @@ class _FusedParams:
         self.dwt_enable = bool(crit.dwt_enable)
         c.dwt_enable, c.patch_enable = int(self.dwt_enable), int(self.patch_enable)
         c.reset_sums = 1
+        cb = getattr(crit, "custom_base", None)   # (w_l1, w_ssim): the NIR term of the multispectral criterion
+        if cb is not None:
+            c.custom_base, c.w_l1, c.w_ssim = 1, float(cb[0]), float(cb[1])
+        self.clamp = bool(getattr(crit, "clamp", True))   # False: the image is not a clamped render (NIR channel)
         self.c = c
         self.patch_size = crit.patch_size
         self.n_ssim_partials = int(crit.ops.api.raw("ssim_partials_count")(1, Cc, H, W))

@@ -34,13 +34,15 @@ class _RasterizeGaussiansX(torch.autograd.Function):
 
     @classmethod
     def forward(cls, ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, extra,
-                raster_settings):
+                extra_gain, raster_settings):
         rs = raster_settings
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.antialiasing, rs.debug)
+        kw = {} if extra_gain is None else {"extra_gain": extra_gain}
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths, extra_img = \
-            cls._impl.rasterize_gaussians(*args, extra=extra)
+            cls._impl.rasterize_gaussians(*args, extra=extra, **kw)
+        ctx.extra_gain = extra_gain
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
@@ -60,23 +62,29 @@ class _RasterizeGaussiansX(torch.autograd.Function):
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer,
                 rs.antialiasing, rs.debug)
+        kw = {} if ctx.extra_gain is None else {"extra_gain": ctx.extra_gain}
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations, grad_extra) = cls._impl.rasterize_gaussians_backward(
-            *args, extra=extra, dL_dout_extra=grad_out_extra)
+            *args, extra=extra, dL_dout_extra=grad_out_extra, **kw)
+        # (the fused train step - RasterBackend.fused_step - has applied every gradient itself and returns none)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
-                grad_rotations, grad_cov3Ds_precomp, grad_extra.reshape(extra.shape), None)
+                grad_rotations, grad_cov3Ds_precomp, None if grad_extra is None else grad_extra.reshape(extra.shape), None,
+                None)
 
 
 class GaussianRasterizerX(nn.Module):
     """`GaussianRasterizer` + `extra` [P]: returns (color, radii, invdepth, extra_img[1,H,W])."""
     _fn = _RasterizeGaussiansX
+    camera_key = None   # as GaussianRasterizer.camera_key: the caller's name for this camera (per-camera tile order / depth limits)
 
     def __init__(self, raster_settings):
         super().__init__()
         self.raster_settings = raster_settings
 
     def forward(self, means3D, means2D, opacities, extra, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, extra_gain=None):
+        """extra_gain (with the backend's raw activations only): `extra` is then the RAW per-Gaussian row and the kernels
+        blend sigmoid(extra) * clamp(extra_gain, 0.1, 10) - the fused multispectral train step's form."""
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -85,6 +93,11 @@ class GaussianRasterizerX(nn.Module):
         if extra is None or extra.numel() != means3D.shape[0]:
             raise Exception('extra must hold one value per Gaussian')
         e = torch.Tensor([])
+        if self.camera_key is not None:
+            backend = getattr(self._fn._impl, "backend", None)
+            if backend is not None:
+                backend.camera_key = self.camera_key   # one-shot: consumed by the forward below
         return self._fn.apply(means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp,
                               opacities, e if scales is None else scales, e if rotations is None else rotations,
-                              e if cov3D_precomp is None else cov3D_precomp, extra.reshape(-1), self.raster_settings)
+                              e if cov3D_precomp is None else cov3D_precomp, extra.reshape(-1), extra_gain,
+                              self.raster_settings)

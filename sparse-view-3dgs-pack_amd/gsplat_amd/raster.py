@@ -140,12 +140,17 @@ class RasterBackend:
         v.bg, v.viewmatrix, v.projmatrix, v.campos = _ptr(bg), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos)
         return v
 
-    def _gauss(self, keep, device, means3D, sh, colors, opacities, scales, rotations, cov3D, extra=None, raw=False):
+    def _gauss(self, keep, device, means3D, sh, colors, opacities, scales, rotations, cov3D, extra=None, raw=False,
+               extra_gain=None):
         g = GsGaussians()
         g.raw_activations = int(bool(raw))
         extra = _prep(extra, device)
         keep.append(extra)
         g.extra_channel = _ptr(extra)
+        if extra_gain is not None:  # raw mode: extra holds the RAW row, activated in the kernels with this device scalar
+            extra_gain = _prep(extra_gain, device)
+            keep.append(extra_gain)
+            g.extra_gain = _ptr(extra_gain)
         means3D, sh, colors, opacities, scales, rotations, cov3D = (
             _prep(x, device) for x in (means3D, sh, colors, opacities, scales, rotations, cov3D))
         keep += [means3D, sh, colors, opacities, scales, rotations, cov3D]
@@ -394,21 +399,23 @@ class RasterBackend:
 
     def rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                              cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
-                             sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False):
+                             sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False, extra_gain=None):
         """The forward (see _rasterize_gaussians); with a fused train step armed it also remembers what an early side launch
         of that step needs (launch_uninstanced_early)."""
         raw = self.raw_activations
         out = self._rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                                         cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
-                                        sh, degree, campos, prefiltered, antialiasing, debug, extra=extra, fsgs=fsgs)
+                                        sh, degree, campos, prefiltered, antialiasing, debug, extra=extra, fsgs=fsgs,
+                                        extra_gain=extra_gain)
         self._early = None
         step = self.fused_step
-        if step is not None and extra is None and not fsgs and means3D.device.type == "cuda" and self.UNINST_AT != "raster_backward":
+        if step is not None and not fsgs and means3D.device.type == "cuda" and self.UNINST_AT != "raster_backward":
             P = int(means3D.shape[0])
             if self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and self.tile_cull and not step.grad_out[0] and not step.rows_override:
                 self._early = dict(args=(bg, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
                                          projmatrix, campos, tanfovx, tanfovy, int(image_height), int(image_width),
                                          scale_modifier, degree, antialiasing, debug),
+                                   extra=extra, extra_gain=extra_gain,
                                    raw=raw, radii=out[2], geom=out[3], img=out[5], step=step, done=None)
         return out
 
@@ -426,7 +433,8 @@ class RasterBackend:
         self._region_key = (int(means3D.shape[0]), W, H)
         view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier, degree,
                           False, antialiasing, debug)
-        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, raw=e["raw"])
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, e["extra"],
+                        raw=e["raw"], extra_gain=e["extra_gain"])
         empty = torch.empty((0,), dtype=torch.uint8, device=device)
         s = self._scratch(e["geom"], e["img"], empty, 0)
         e["done"] = self._launch_uninstanced(device, view, g, e["radii"], s, e["step"])
@@ -451,7 +459,7 @@ class RasterBackend:
 
     def _rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                               cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
-                              sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False):
+                              sh, degree, campos, prefiltered, antialiasing, debug, extra=None, fsgs=False, extra_gain=None):
         """= RasterizeGaussiansCUDA (rasterize_points.cu:35-124).
 
         Returns (num_rendered, color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
@@ -484,8 +492,10 @@ class RasterBackend:
 
         raw, self.raw_activations = self.raw_activations, False
         self._raw_backward = raw
-        if raw and (fsgs or extra is not None):
-            raise RuntimeError("raw activations serve the plain RGB rasterizer only")
+        if raw and fsgs:
+            raise RuntimeError("raw activations do not serve the FSGS rasterizer generation")
+        if (extra_gain is not None) != (raw and extra is not None):
+            raise RuntimeError("extra_gain goes with a RAW 4th channel (raw activations), and only with it")
         cache = self._camera_cache(device, W, H, viewmatrix)
         static = self.static_capacity is not None
         use_order = cache is not None and self.order_hint_on
@@ -525,7 +535,8 @@ class RasterBackend:
         keep = []
         view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
                           degree, prefiltered, antialiasing, debug)
-        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra, raw=raw)
+        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra, raw=raw,
+                        extra_gain=extra_gain)
         stream = self._stream(device)
 
         gb, ib, _, _ = self.scratch_bytes(P, W, H, 0)
@@ -753,7 +764,7 @@ class RasterBackend:
                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy,
                                      dL_dout_color, dL_dout_invdepth, sh, degree, campos, geomBuffer, R,
                                      binningBuffer, imgBuffer, antialiasing, debug, extra=None, dL_dout_extra=None,
-                                     fsgs=False):
+                                     fsgs=False, extra_gain=None):
         """= RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-223).
 
         Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
@@ -774,12 +785,15 @@ class RasterBackend:
         if raw and (step is None or P == 0):
             raise RuntimeError("a forward on raw activations must be followed by the fused train-step backward")
         if step is not None and P != 0:
-            if fsgs or extra is not None:
-                raise RuntimeError("the fused train-step backward serves the plain RGB rasterizer only")
+            if fsgs:
+                raise RuntimeError("the fused train-step backward does not serve the FSGS rasterizer generation")
             keep = []
             view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
                               degree, False, antialiasing, debug)
-            g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, raw=raw)
+            g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra, raw=raw,
+                            extra_gain=extra_gain)
+            if extra is not None:
+                dL_dout_extra = torch.zeros((1, H, W), **f32) if dL_dout_extra is None else _prep(dL_dout_extra, device)
             dL_dout_color = _prep(dL_dout_color, device)
             dL_dout_invdepth = _prep(dL_dout_invdepth, device)
             _, _, _, wsb = self.scratch_bytes(P, W, H, R)
@@ -820,15 +834,20 @@ class RasterBackend:
                 step.phase = 2                    # gs_backward_step: the Gaussians with instances only ...
                 step.phase1_done = done.cuda_event  # ... its per-Gaussian kernel behind the side launch
             try:
-                self.api.call("backward_step", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
-                              dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(step), _ptr(ws), ws.numel(),
-                              self._stream(device))
+                if extra is not None:
+                    self.api.call("backward_step_x", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
+                                  dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), dL_dout_extra.data_ptr(), C.byref(step),
+                                  _ptr(ws), ws.numel(), self._stream(device))
+                else:
+                    self.api.call("backward_step", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s), int(R),
+                                  dL_dout_color.data_ptr(), _ptr(dL_dout_invdepth), C.byref(step), _ptr(ws), ws.numel(),
+                                  self._stream(device))
             except Exception:
                 self.rows_epoch += 1   # (the persistent rows may hold sums now: graphs that skip the clear are stale)
                 raise
             if step.rows_clean:
                 self._rows_ws[(device.index, wsb)][1] = True
-            return (None,) * 8
+            return (None,) * (8 if extra is None else 9)
 
         def out(name, shape):
             t = None if arena is None else arena.get(name)

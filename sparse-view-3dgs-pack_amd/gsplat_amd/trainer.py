@@ -61,6 +61,8 @@ class FlatAdam:
         # torch keeps Adam's step count per parameter; a group that is skipped (no gradient after its tensor
         # was replaced) falls behind the others
         self.seg_steps = {name: 0 for name, _ in model.fields}
+        if getattr(model, "with_nir", False):
+            self.seg_steps["nir_gain"] = 0   # the global gain (not a per-Gaussian field): stepped with every optimizer step
         self.lr = dict(LRS)
         self.lr["xyz"] = LRS["xyz"] * model.spatial_lr_scale
         self._Seg = GsAdamSeg
@@ -102,6 +104,28 @@ class FlatAdam:
         for name, _ in self.model.fields:
             if name not in skip:
                 self.seg_steps[name] += 1
+        if "nir_gain" in self.seg_steps:
+            self.seg_steps["nir_gain"] += 1
+
+    def _nir_into(self, st, grads_out):
+        """The 4th channel's part of a GsStepState (multispectral model): raw albedo row, global gain, moments, rates."""
+        m = self.model
+        if not m.with_nir:
+            return
+        st.extra = m.params["nir_albedo"].data_ptr()
+        st.gain = m.nir_gain.data_ptr()
+        st.lr_extra, st.lr_gain = self.lr["nir_albedo"], self.lr["nir_gain"]
+        if grads_out:
+            st.grad_out_extra = m.grad_views()["nir_albedo"].data_ptr()
+            st.grad_out_gain = m.gain_grad_word.data_ptr()
+            st.step_extra = st.step_gain = 1
+            return
+        ea, eas = self.field_views(self.exp_avg), self.field_views(self.exp_avg_sq)
+        st.extra_m, st.extra_v = ea["nir_albedo"].data_ptr(), eas["nir_albedo"].data_ptr()
+        gs = m.nir_gain_optimizer.state[m.nir_gain]
+        st.gain_m, st.gain_v = gs["exp_avg"].data_ptr(), gs["exp_avg_sq"].data_ptr()
+        st.step_extra = self.seg_steps["nir_albedo"] if self.seg_steps["nir_albedo"] > 0 else self.t
+        st.step_gain = self.seg_steps["nir_gain"]
 
     def grads_out_request(self):
         """The GsStepState of the data-parallel form of gs_backward_step: raw rows in, gradients OUT into the flat gradient
@@ -119,6 +143,7 @@ class FlatAdam:
         st.max_radii2D = m.max_radii2D.data_ptr()
         st.xyz_gradient_accum, st.denom = m.stat_delta[0].data_ptr(), m.stat_delta[1].data_ptr()
         st.fail_flag = m.fail_flag.data_ptr()
+        self._nir_into(st, True)
         return st
 
     def step_range(self, lo, hi, skip=(), grads=None, gate=None):
@@ -152,16 +177,22 @@ class FlatAdam:
     def step_coefficients(self, skip=()):
         """The 11 step-dependent constants of gs_backward_step for the CURRENT counters (call after begin_step):
         lr / (1 - beta1^t) per learning-rate class, 1 / sqrt(1 - beta2^t) per row - in the float arithmetic of
-        gs_adam_step (double, rounded once; the product lr * 1/(1 - beta1^t) in float)."""
+        gs_adam_step (double, rounded once; the product lr * 1/(1 - beta1^t) in float).  Always 15 floats: words 11..14 are
+        the same two constants of the multispectral model's 4th-channel row and of its gain (zero without them)."""
         import numpy as np
         t = [self.seg_steps[name] if self.seg_steps[name] > 0 else self.t for name in self.ROWS]
         t = [max(x, 1) for x in t]
         b1, b2 = (float(np.float32(b)) for b in self.betas)  # the C ABI takes the betas as float
-        out = np.zeros(11, dtype=np.float32)
+        out = np.zeros(15, dtype=np.float32)
         for c, (name, row) in enumerate(self.LR_CLASSES):
             out[c] = np.float32(self.lr[name]) * np.float32(1.0 / (1.0 - b1 ** t[row]))
         for k in range(5):
             out[6 + k] = np.float32(1.0 / math.sqrt(1.0 - b2 ** t[k]))
+        if getattr(self.model, "with_nir", False):
+            for k, name in enumerate(("nir_albedo", "nir_gain")):
+                tk = max(self.seg_steps[name] if self.seg_steps[name] > 0 else self.t, 1)
+                out[11 + 2 * k] = np.float32(self.lr[name]) * np.float32(1.0 / (1.0 - b1 ** tk))
+                out[12 + 2 * k] = np.float32(1.0 / math.sqrt(1.0 - b2 ** tk))
         return out
 
     def fused_request(self, skip=(), coef_dev=None):
@@ -185,6 +216,9 @@ class FlatAdam:
         st.beta1, st.beta2, st.eps = self.betas[0], self.betas[1], self.eps
         st.max_radii2D, st.xyz_gradient_accum, st.denom = (m.max_radii2D.data_ptr(), m.xyz_gradient_accum.data_ptr(),
                                                            m.denom.data_ptr())
+        self._nir_into(st, False)
+        if m.with_nir and "nir_albedo" in skip:
+            st.step_extra = 0
         return st
 
     def field_views(self, buf):
@@ -272,6 +306,12 @@ class GaussianModelLite:
         if self.with_nir:
             self.nir_gain = torch.nn.Parameter(torch.tensor(1.0, dtype=torch.float32, device=device))
             self.nir_gain_optimizer = torch.optim.Adam([self.nir_gain], lr=LRS["nir_gain"], eps=1e-15)
+            # the moments exist from the start: the fused multispectral step (gs_backward_step_x) updates them in place, the
+            # un-fused one goes through torch's optimizer - ONE state for both.  The step count lives with the main
+            # optimizer's (FlatAdam.seg_steps["nir_gain"]): the gain steps whenever that one does.
+            self.nir_gain_optimizer.state[self.nir_gain] = {
+                "step": torch.tensor(0.0, dtype=torch.float32), "exp_avg": torch.zeros_like(self.nir_gain.data),
+                "exp_avg_sq": torch.zeros_like(self.nir_gain.data)}
         if api is not None:
             self.optimizer = FlatAdam(api, self)
         else:
@@ -326,6 +366,7 @@ class GaussianModelLite:
         self.stat_delta = self.exchange[n_pad:n_pad + 2 * P].view(2, P)
         self.stat_tail = self.exchange[n_pad:]            # statistics + flag: what travels beside the gradients
         self.fail_flag = self.exchange[n_pad + 2 * P:n_pad + 2 * P + 1]
+        self.gain_grad_word = self.exchange[n_pad + 2 * P + 1:n_pad + 2 * P + 2]   # multispectral model: dL/dgain of this view
         self.params = {}
         off = 0
         shapes = self._shapes(P)
@@ -845,8 +886,10 @@ class Trainer:
     def _fused_step_ok(self, backend, optimizer_step):
         m = self.model
         return (self.FUSED_STEP and optimizer_step and self.world_size == 1 and backend is not None
-                and isinstance(m.optimizer, FlatAdam) and not m.with_nir and m.flat.is_cuda
+                and isinstance(m.optimizer, FlatAdam) and (not m.with_nir or self.RENDERS_NIR) and m.flat.is_cuda
                 and hasattr(backend.api, "_backward_step") and hasattr(backend, "fused_step"))
+
+    RENDERS_NIR = False   # (TrainerNIR: the step renders and steps the model's 4th channel)
 
     def _fused_dp_ok(self, backend, optimizer_step):
         """N > 1: the data-parallel form of the fused backward (GsStepState.grad_out): raw rows in, the 59 gradient floats per
@@ -854,7 +897,7 @@ class Trainer:
         flag - no activation kernels, no activated copies, no packing; the optimizer then runs gated by the reduced flag."""
         m = self.model
         return (self.FUSED_STEP and optimizer_step and self.world_size > 1 and backend is not None
-                and isinstance(m.optimizer, FlatAdam) and not m.with_nir and m.flat.is_cuda
+                and isinstance(m.optimizer, FlatAdam) and (not m.with_nir or self.RENDERS_NIR) and m.flat.is_cuda
                 and hasattr(backend.api, "_backward_step") and hasattr(backend.api, "_adam_step_gated")
                 and hasattr(backend, "fused_step"))
 
@@ -901,14 +944,56 @@ class Trainer:
         self.gather_optimizer_state()
         return self.model.capture()
 
+    def _backend(self):
+        be = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
+        return getattr(be, "backend", None)
+
+    # -- what differs between the RGB step and the multispectral one (TrainerNIR)
+    def _render_view(self, ci, fused, raw):
+        m = self.model
+        return render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
+                      clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci,
+                      raw_activations=raw, camera_key=("trainer", self.uid, ci))
+
+    def _criterion_backward(self, pkg, ci, mask, fused, side_launch):
+        """-> (loss, parts); runs the backward.  side_launch: callable that issues the two-phase step's side launch (or None)"""
+        if fused:
+            loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
+            # two-phase step: the Adam stream of the Gaussians without instances starts on its side stream from inside the
+            # criterion's backward (RasterBackend.UNINST_AT) - it needs nothing of the loss - and runs beside the blend
+            self._arm_side_launch(side_launch)
+            # (seeded with the criterion's cached constant 1: no fill kernel for the implicit seed, no multiply by it)
+            torch.autograd.backward(loss, self.criterion.ops.unit_grad(loss.device))
+        else:
+            loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
+            loss.backward()
+        return loss, parts
+
+    def _arm_side_launch(self, side_launch):
+        ops = self.criterion.ops
+        ops.before_last_backward_kernel = None
+        if side_launch is None:
+            return
+        backend = self._backend()
+        if backend.UNINST_AT == "ssim_backward":      # ... between the criterion's two backward kernels
+            ops.before_last_backward_kernel = side_launch
+        else:
+            side_launch()
+
+    def _unfused_tail(self, pkg, radii, optimizer_step, skip):
+        m = self.model
+        with torch.no_grad():
+            m.collect_grads()
+            m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
+            self.exchange_and_step(optimizer_step, skip)
+
     def _step_camera(self, ci, optimizer_step, skip, exposure_step=None):
         self.sync()
         m = self.model
         if exposure_step is None:
             exposure_step = optimizer_step
         m.zero_grad()
-        backend = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
-        backend = getattr(backend, "backend", None)
+        backend = self._backend()
         fused_step = self._fused_step_ok(backend, optimizer_step)
         fused_dp = self._fused_dp_ok(backend, optimizer_step)
         # (not with a trainable exposure: its torch optimizer has stepped on the invalid image by the time the verdict
@@ -929,34 +1014,18 @@ class Trainer:
             rows = getattr(self, "rows_override", None)  # parity tests: blend sums to use instead of stage 1
             if rows is not None:
                 backend.fused_step.rows_override = rows.data_ptr()
-        elif backend is not None:
+        elif backend is not None and hasattr(backend, "grad_arena") and not m.with_nir:
             m.arm_grad_arena(backend)
         fused = getattr(self.criterion, "fused", False)
-        pkg = render(self.cameras[ci], m, self.Rasterizer, self.Settings, self.bg, filter_as_indices=None,
-                     clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci,
-                     raw_activations=(fused_step or fused_dp) and self.RAW_ACTIVATIONS,
-                     camera_key=("trainer", self.uid, ci))
+        pkg = self._render_view(ci, fused, (fused_step or fused_dp) and self.RAW_ACTIVATIONS)
         mask = None if self.masks is None else self.masks[ci]
         verdict = backend.take_deferred() if deferred else None
         rm = None
         if verdict is not None and not fused:
             rm = getattr(self.criterion, "dwt_running_mean", None)
             rm = None if rm is None else rm.clone()
-        if fused:
-            loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
-            # two-phase step: the Adam stream of the Gaussians without instances starts HERE, on its side stream - it needs
-            # nothing of the loss - and runs under the criterion's backward kernels and the backward blend
-            if fused_step and backend is not None:
-                if backend.UNINST_AT == "ssim_backward":   # ... or between the criterion's two backward kernels
-                    self.criterion.ops.before_last_backward_kernel = backend.launch_uninstanced_early
-                else:
-                    self.criterion.ops.before_last_backward_kernel = None
-                    backend.launch_uninstanced_early()
-            # (seeded with the criterion's cached constant 1: no fill kernel for the implicit seed, no multiply by it)
-            torch.autograd.backward(loss, self.criterion.ops.unit_grad(loss.device))
-        else:
-            loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
-            loss.backward()
+        loss, parts = self._criterion_backward(pkg, ci, mask, fused,
+                                               backend.launch_uninstanced_early if (fused_step and fused) else None)
         radii = pkg["radii"]
         if fused_dp:
             # gradients, statistic increments and the validity flag are in the exchange buffer: reduce, then the gated
@@ -992,10 +1061,7 @@ class Trainer:
                 backend.fused_step = None
                 raise RuntimeError("fused train step armed but the rasterizer backward did not run")
         else:
-            with torch.no_grad():
-                m.collect_grads()
-                m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
-                self.exchange_and_step(optimizer_step, skip)
+            self._unfused_tail(pkg, radii, optimizer_step, skip)
         if m.exposure_optimizer is not None:
             # train.py:280-281: the exposure optimizer steps with the main one; a camera's row is only touched by the
             # rank that rendered it, the others hold a zero gradient for it (N > 1: summed like every other gradient)
@@ -1123,11 +1189,14 @@ class Trainer:
 # multispectral (RGB + NIR) step: counterpart of LGDWT-GS/mult-dwtgs/train_nir.py:81-125 on the fused 4-channel pass
 # ----------------------------------------------------------------------------------------------------------------
 def render_rgb_nir(viewpoint_camera, pc, Settings, bg_color, scaling_modifier=1.0, antialiasing=False, debug=False,
-                   two_pass_rasterizer=None):
+                   two_pass_rasterizer=None, clamp=True, raw_activations=False, camera_key=None):
     """= render() + render_nir() of mult-dwtgs/gaussian_renderer/__init__.py:18-258: {render (clamped to [0,1] as
     :119 does), nir (channel 0 of the NIR pass, not clamped), viewspace_points, visibility_filter, radii, depth}.
     Default: ONE pass with the NIR albedo as a 4th blended channel (gsplat_amd.nir).  two_pass_rasterizer = a
-    `GaussianRasterizer` class: the reference's two 3-channel passes through it (used as the parity target)."""
+    `GaussianRasterizer` class: the reference's two 3-channel passes through it (used as the parity target).
+    raw_activations (the fused train step's form; the caller has told the backend, RasterBackend.raw_activations): the
+    rasterizer gets the RAW scaling / rotation / opacity / albedo rows and the gain and activates them in its kernels.
+    clamp=False: the fused criterion clamps (and differentiates the clamp of) the render itself."""
     from .nir import GaussianRasterizerX, nir_colors
     rs = Settings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
@@ -1135,6 +1204,18 @@ def render_rgb_nir(viewpoint_camera, pc, Settings, bg_color, scaling_modifier=1.
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=debug, antialiasing=antialiasing)
+    if raw_activations:
+        if two_pass_rasterizer is not None:
+            raise RuntimeError("raw activations serve the fused 4-channel pass only")
+        ssp = torch.empty_like(pc.get_xyz).requires_grad_(True)
+        rast = GaussianRasterizerX(rs)
+        if camera_key is not None:
+            rast.camera_key = camera_key
+        color, radii, depth, nir_img = rast(
+            means3D=pc.get_xyz, means2D=ssp, opacities=pc.params["opacity"], extra=pc.params["nir_albedo"],
+            shs=pc.get_features, scales=pc.params["scaling"], rotations=pc.params["rotation"], extra_gain=pc.nir_gain)
+        return {"render": color.clamp(0, 1) if clamp else color, "nir": nir_img, "viewspace_points": ssp,
+                "viewspace_points_nir": None, "visibility_filter": None, "radii": radii, "depth": depth}
     act = pc.fused_activations()
     if act is None:
         act = (pc.get_scaling, pc.get_rotation, pc.get_opacity)
@@ -1142,7 +1223,10 @@ def render_rgb_nir(viewpoint_camera, pc, Settings, bg_color, scaling_modifier=1.
     nir = nir_colors(torch.sigmoid(pc.params["nir_albedo"]), pc.nir_gain)  # get_nir_albedo * clamp(gain), render_nir:166-169
     ssp = torch.zeros_like(pc.get_xyz, requires_grad=True)
     if two_pass_rasterizer is None:
-        color, radii, depth, nir_img = GaussianRasterizerX(rs)(
+        rast = GaussianRasterizerX(rs)
+        if camera_key is not None:
+            rast.camera_key = camera_key
+        color, radii, depth, nir_img = rast(
             means3D=pc.get_xyz, means2D=ssp, opacities=opacities, extra=nir, shs=pc.get_features, scales=scales,
             rotations=rotations)
         ssp2 = None
@@ -1154,22 +1238,55 @@ def render_rgb_nir(viewpoint_camera, pc, Settings, bg_color, scaling_modifier=1.
         img3, _, _ = rast(means3D=pc.get_xyz, means2D=ssp2, shs=None, colors_precomp=nir[:, None].repeat(1, 3),
                           opacities=opacities, scales=scales, rotations=rotations)
         nir_img = img3[0:1]
-    return {"render": color.clamp(0, 1), "nir": nir_img, "viewspace_points": ssp, "viewspace_points_nir": ssp2,
-            "visibility_filter": radii > 0, "radii": radii, "depth": depth}
+    return {"render": color.clamp(0, 1) if clamp else color, "nir": nir_img, "viewspace_points": ssp,
+            "viewspace_points_nir": ssp2, "visibility_filter": radii > 0, "radii": radii, "depth": depth}
 
 
 class NirCriterion:
     """train_nir.py:88-104: (1 - l) L1 + l (1 - SSIM) on RGB, plus nir_weight * (L1 + 0.2 (1 - SSIM)) on the NIR image
     (mult-dwtgs/utils/loss_utils.py:93-144; the reference evaluates the single-channel SSIM on three identical
-    copies, whose mean is the single-channel value)."""
+    copies, whose mean is the single-channel value).
+    fused=True (device kernels available): both terms as FusedLGDWTLoss nodes - the RGB one on the un-clamped render
+    (with the global / patch DWT terms when rgb_criterion asks for them), the NIR one through the same kernels on one
+    channel with its own two weights (GsLgdwtParams.custom_base), no clamp; no torch pass over an image."""
 
-    def __init__(self, ops, lambda_dssim=0.2, nir_weight=1.0, nir_l1_weight=1.0, nir_ssim_weight=0.2, rgb_criterion=None):
-        """rgb_criterion: an LGDWTCriterion (fused=False) to use for the RGB term instead of train_nir.py's plain
-        L1 + SSIM - the multispectral step WITH the global / patch DWT terms of LGDWT-GS/train.py:128-202 (BASELINE
-        configs[4] names a patch-DWT loss; the reference's train_nir.py itself has none)."""
+    def __init__(self, ops, lambda_dssim=0.2, nir_weight=1.0, nir_l1_weight=1.0, nir_ssim_weight=0.2, rgb_criterion=None,
+                 fused=False):
+        """rgb_criterion: an LGDWTCriterion to use for the RGB term instead of train_nir.py's plain L1 + SSIM - the
+        multispectral step WITH the global / patch DWT terms of LGDWT-GS/train.py:128-202 (BASELINE configs[4] names a
+        patch-DWT loss; the reference's train_nir.py itself has none)."""
+        from .losses import LGDWTCriterion
         self.ops, self.lambda_dssim, self.nir_weight = ops, lambda_dssim, nir_weight
         self.nir_l1_weight, self.nir_ssim_weight = nir_l1_weight, nir_ssim_weight
         self.rgb_criterion = rgb_criterion
+        self.fused = bool(fused)
+        if self.fused:
+            if rgb_criterion is None:
+                self.rgb_criterion = LGDWTCriterion(ops, lambda_dssim=lambda_dssim, dwt_enable=False, patch_dwt_enable=False)
+            self._nir = LGDWTCriterion(ops, dwt_enable=False, patch_dwt_enable=False)
+            self._nir.custom_base = (nir_weight * nir_l1_weight, nir_weight * nir_ssim_weight)
+            self._nir.clamp = False
+
+    # (the running mean of the RGB criterion's DWT scale: what a step that has to be taken back restores)
+    @property
+    def dwt_running_mean(self):
+        return None if self.rgb_criterion is None else self.rgb_criterion.dwt_running_mean
+
+    @dwt_running_mean.setter
+    def dwt_running_mean(self, v):
+        if self.rgb_criterion is not None:
+            self.rgb_criterion.dwt_running_mean = v
+
+    def elf_mask(self, gt_image):
+        return self.rgb_criterion.elf_mask(gt_image)
+
+    def fused_call(self, raw_image, gt_image, nir_pred, nir_gt, mask=None):
+        """-> ((rgb_loss, nir_loss), parts): two scalars to seed the backward with (their sum is the step's loss)"""
+        rgb, parts = self.rgb_criterion.fused_call(raw_image, gt_image, mask=mask)
+        nir, nparts = self._nir.fused_call(nir_pred, nir_gt)
+        parts = dict(parts)
+        parts.update(rgb=rgb.detach(), nir=nir.detach(), nir_l1=nparts["l1"], nir_ssim=nparts["ssim"])
+        return (rgb, nir), parts
 
     def __call__(self, image, gt_image, nir_pred, nir_gt, mask=None):
         o = self.ops
@@ -1184,24 +1301,49 @@ class NirCriterion:
 
 class TrainerNIR(Trainer):
     """Trainer for a model created with with_nir=True: one fused 4-channel pass per view, RGB + NIR losses, Adam over
-    the 60-float rows (59 + raw NIR albedo) and the global gain."""
+    the 60-float rows (59 + raw NIR albedo) and the global gain.  With a fused NirCriterion on the GPU the step is the RGB
+    trainer's: raw parameter rows, region-binned depth-limited lists with the deferred verdict, the criterion as two fused
+    nodes, gs_backward_step_x (backward + activation backward + statistics + Adam over the six rows and the gain in the
+    per-Gaussian kernels, two-phase with the side stream), hipGraph replay, and the data-parallel form."""
+    RENDERS_NIR = True
 
     def __init__(self, model, cameras, gt_images, nir_images, criterion, Settings, bg, two_pass_rasterizer=None, **kw):
-        super().__init__(model, cameras, gt_images, criterion, None, Settings, bg, **kw)
+        from .nir import GaussianRasterizerX
+        super().__init__(model, cameras, gt_images, criterion, None if two_pass_rasterizer is not None else GaussianRasterizerX,
+                         Settings, bg, **kw)
         self.nirs = nir_images
         self.two_pass = two_pass_rasterizer
 
-    def _step_camera(self, ci, optimizer_step, skip, exposure_step=None):
+    def _fused_step_ok(self, backend, optimizer_step):
+        return self.two_pass is None and getattr(self.criterion, "fused", False) and super()._fused_step_ok(backend, optimizer_step)
+
+    def _fused_dp_ok(self, backend, optimizer_step):
+        return self.two_pass is None and getattr(self.criterion, "fused", False) and super()._fused_dp_ok(backend, optimizer_step)
+
+    def _render_view(self, ci, fused, raw):
         m = self.model
-        m.zero_grad()
         if m.nir_gain.grad is not None:
             m.nir_gain.grad = None
-        pkg = render_rgb_nir(self.cameras[ci], m, self.Settings, self.bg, two_pass_rasterizer=self.two_pass)
-        mask = None if self.masks is None else self.masks[ci]
-        loss, parts = self.criterion(pkg["render"], self.gts[ci], pkg["nir"], self.nirs[ci], **(
-            {} if mask is None else {"mask": mask}))
-        loss.backward()
-        radii = pkg["radii"]
+        return render_rgb_nir(self.cameras[ci], m, self.Settings, self.bg, two_pass_rasterizer=self.two_pass,
+                              clamp=not fused, raw_activations=raw,
+                              camera_key=None if self.two_pass is not None else ("trainer", self.uid, ci))
+
+    def _criterion_backward(self, pkg, ci, mask, fused, side_launch):
+        kw = {} if mask is None else {"mask": mask}
+        if fused:
+            (rgb, nir), parts = self.criterion.fused_call(pkg["render"], self.gts[ci], pkg["nir"], self.nirs[ci], **kw)
+            self._arm_side_launch(side_launch)
+            unit = self.criterion.ops.unit_grad(rgb.device)
+            torch.autograd.backward([rgb, nir], [unit, unit])
+            with torch.no_grad():
+                loss = rgb + nir
+        else:
+            loss, parts = self.criterion(pkg["render"], self.gts[ci], pkg["nir"], self.nirs[ci], **kw)
+            loss.backward()
+        return loss, parts
+
+    def _unfused_tail(self, pkg, radii, optimizer_step, skip):
+        m = self.model
         with torch.no_grad():
             m.collect_grads()
             vg = pkg["viewspace_points"].grad
@@ -1213,10 +1355,25 @@ class TrainerNIR(Trainer):
             self.exchange_and_step(optimizer_step, skip)
             if optimizer_step:
                 # the reference keeps the global gain in the main Adam (mult-dwtgs/scene/gaussian_model.py:266-280): it
-                # is stepped whenever optimizer.step() runs - and, like every group, not on a densification iteration
+                # is stepped whenever optimizer.step() runs - and, like every group, not on a densification iteration.
+                # Its step count is the main optimizer's (FlatAdam.seg_steps["nir_gain"], advanced by the step above)
+                opt = m.optimizer
+                if isinstance(opt, FlatAdam):
+                    m.nir_gain_optimizer.state[m.nir_gain]["step"].fill_(float(opt.seg_steps["nir_gain"] - 1))
                 m.nir_gain_optimizer.step()
-        self.last = dict(loss=loss.detach(), radii=radii, parts=parts)
-        return loss.detach()
+
+    def exchange_and_step(self, optimizer_step, skip=(), gate=None):
+        super().exchange_and_step(optimizer_step, skip, gate)
+        if gate is not None and optimizer_step and self.world_size > 1:
+            # fused data-parallel step: the gain's gradient travelled in the exchange tail (summed with the flag); its
+            # Adam step, gated like every other row's, on every rank
+            m, opt = self.model, self.model.optimizer
+            gs = m.nir_gain_optimizer.state[m.nir_gain]
+            segs = (opt._Seg * 1)()
+            segs[0].begin, segs[0].end, segs[0].lr_a, segs[0].step = 0, 1, opt.lr["nir_gain"], opt.seg_steps["nir_gain"]
+            opt.api.call("adam_step_gated", m.nir_gain.data_ptr(), m.gain_grad_word.data_ptr(), gs["exp_avg"].data_ptr(),
+                         gs["exp_avg_sq"].data_ptr(), 1, segs, 1, opt.betas[0], opt.betas[1], opt.eps, opt.t,
+                         gate.data_ptr(), _stream_of(m.flat))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -1312,8 +1469,8 @@ class GraphedStep:
 
     def _shared_init(self, dev):
         be = self._backend()
-        self.coef = torch.zeros((11,), dtype=torch.float32, device=dev)
-        self.coef_host = torch.zeros((11,), dtype=torch.float32).pin_memory()
+        self.coef = torch.zeros((15,), dtype=torch.float32, device=dev)
+        self.coef_host = torch.zeros((15,), dtype=torch.float32).pin_memory()
         be._pinned_by_device.setdefault((dev.index, "static"), torch.zeros((16,), dtype=torch.int32).pin_memory())
         # the replay's identity: uploaded before every replay, copied out with the status words by the captured
         # gs_forward_status (GsScratch.step_tag) - the host polls the pinned block for it instead of draining the stream
