@@ -480,6 +480,40 @@ def main():
             tr.step(k)
             k += 1
         barrier()
+    # The DROP-IN loop, untimed by the driver: the reference's own iteration (LGDWT-GS/train.py:97-288) written against the
+    # drop-in packages only - GaussianRasterizer, lgdwt_loss.l1_loss / get_dwt_subbands / compute_elf_map /
+    # compute_patch_dwt_loss, fused_ssim, torch.optim.Adam over six tensors, the reference's `.item()` syncs - with the
+    # product's defaults (no environment switches): what a maintainer who follows INTEGRATION.md section 1 gets
+    # (gsplat_amd/dropin.py).  Then the two one-line additions INTEGRATION.md section 4 offers: the optimizer as one
+    # kernel per tensor (gsplat_amd.optim.FusedAdam, same constructor) and a camera_key on the rasterizer (depth-limited
+    # lists on a camera's later visits, verified by the forward).
+    drop_in = None
+    if world == 1 and args.config not in NIR_CONFIGS and os.environ.get("GS_BENCH_DROP_IN", "1") != "0":
+        from gsplat_amd.dropin import DropInLoop
+        drop_in = {"what": "LGDWT-GS/train.py:97-288 against the drop-in packages only (gsplat_amd/dropin.py): "
+                           "GaussianRasterizer + lgdwt_loss functions + fused_ssim + Adam over six tensors, the reference's "
+                           "host syncs kept; product defaults, no environment switches; untimed by the driver"}
+        n_di = min(args.steps, 20)
+        for label, kw in (("torch.optim.Adam", dict(optimizer="torch")),
+                          ("FusedAdam", dict(optimizer="fused")),
+                          ("FusedAdam + camera_key", dict(optimizer="fused", use_camera_key=True))):
+            loop = DropInLoop(scene, cams, gts, device, dwt=dwt, patch=patch, **kw)
+            for j in range(len(cams) + 2):      # every camera once (a keyed camera's limits exist from its second visit on)
+                loop.iteration(j % len(cams))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for j in range(n_di):
+                loop.iteration((j + 2) % len(cams))
+            torch.cuda.synchronize()
+            drop_in[label] = {"ms_per_step": (time.perf_counter() - t1) / n_di * 1e3, "steps": n_di}
+            log("drop-in loop, %s: %.3f ms/step" % (label, drop_in[label]["ms_per_step"]))
+            del loop
+        drop_in["drop_in_api_ms_per_step"] = drop_in["torch.optim.Adam"]["ms_per_step"]
+        torch.cuda.empty_cache()
+        for _ in range(2):  # restore the capacity hint / last-view counter of the timed mode
+            tr.step(k)
+            k += 1
+        barrier()
     # The LONG run, untimed by the driver: the timed region is twenty steps early in a run; what a few hundred more steps cost
     # depends on how fast the model moves between two visits of a camera - the depth limits of a camera are the stop depths of
     # its last visit, and a view whose tiles now saturate deeper is rendered again with full lists (a fall-back).  Two runs of
@@ -717,6 +751,8 @@ def main():
                        "camera-sharded dp%d, one all-reduce of 61 f32/Gaussian (59 gradients + 2 statistic increments)" % world},
             "roofline": roofline,
             "reference_lists": ref_lists,
+            "drop_in_api": drop_in,
+            "drop_in_api_ms_per_step": None if drop_in is None else drop_in["drop_in_api_ms_per_step"],
             "other_scenes": other or None,
             "sustained": sustained,
             "data_parallel": dp_info,

@@ -333,6 +333,10 @@ typedef struct GsStepState {
   int32_t step_extra, step_gain;
   float* grad_out_extra;
   float* grad_out_gain;
+  /* data-parallel form, optional: [P] bytes, 1 where this view's gradients of the Gaussian may be non-zero (it emitted
+   * instances), 0 where every one of its gradient floats was written as zero.  The union of the ranks' masks is what a
+   * sparse exchange has to move (gsplat_amd.trainer: pack the union's rows, all-reduce, scatter back). */
+  uint8_t* grad_mask;
 } GsStepState;
 int gs_backward_step(const GsView* view, const GsGaussians* g, const int32_t* radii,
                      const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,

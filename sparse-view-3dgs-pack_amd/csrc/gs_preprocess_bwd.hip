@@ -357,6 +357,10 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
         st.denom[i] = 0.f;
       }
     }
+    if (grads_out && st.grad_mask) {  // ... and no gradients: an empty mask (the step is repeated; nothing is applied)
+      const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+      if (i < a.P) st.grad_mask[i] = 0;
+    }
     return;
   }
   // step-dependent constants from device memory when the launch is replayed from a captured graph
@@ -468,6 +472,7 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
     }
   };
   if (st.extra && blockIdx.x == 0) gain_step(sa, grads_out, b1, b2, eps);
+  if (grads_out && st.grad_mask && in_range) st.grad_mask[idx] = active ? 1 : 0;  // (what a sparse exchange has to move)
   if (grads_out) {
     // the workgroup's contiguous piece of each gradient row array, straight from the LDS image
     if (PHASE == 0) {

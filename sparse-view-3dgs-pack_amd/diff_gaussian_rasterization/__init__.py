@@ -90,6 +90,10 @@ class GaussianRasterizer(nn.Module):
     # limits: INTEGRATION.md section 4) and tells cameras apart by this key; without one it falls back to a hash of the view
     # matrix's contents (one small device-to-host copy per NEW tensor object).
     camera_key = None
+    # With a camera_key the backend may also render this camera's LATER visits from depth-limited instance lists (exact: the
+    # forward verifies every cut list and renders the view again when one proved too short - INTEGRATION.md section 4).
+    # False: the key only names the camera (tile-order hint); gsplat_amd.trainer manages the limits itself.
+    camera_limits = True
 
     def __init__(self, raster_settings):
         super().__init__()
@@ -127,5 +131,6 @@ class GaussianRasterizer(nn.Module):
             backend = getattr(self._fn._impl, "backend", None)
             if backend is not None:
                 backend.camera_key = self.camera_key   # one-shot: consumed by the forward below
+                backend.camera_key_limits = bool(self.camera_limits)
         return self._fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                               raster_settings)

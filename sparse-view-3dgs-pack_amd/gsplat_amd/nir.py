@@ -76,6 +76,7 @@ class GaussianRasterizerX(nn.Module):
     """`GaussianRasterizer` + `extra` [P]: returns (color, radii, invdepth, extra_img[1,H,W])."""
     _fn = _RasterizeGaussiansX
     camera_key = None   # as GaussianRasterizer.camera_key: the caller's name for this camera (per-camera tile order / depth limits)
+    camera_limits = True
 
     def __init__(self, raster_settings):
         super().__init__()
@@ -97,6 +98,7 @@ class GaussianRasterizerX(nn.Module):
             backend = getattr(self._fn._impl, "backend", None)
             if backend is not None:
                 backend.camera_key = self.camera_key   # one-shot: consumed by the forward below
+                backend.camera_key_limits = bool(self.camera_limits)
         return self._fn.apply(means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp,
                               opacities, e if scales is None else scales, e if rotations is None else rotations,
                               e if cov3D_precomp is None else cov3D_precomp, extra.reshape(-1), extra_gain,

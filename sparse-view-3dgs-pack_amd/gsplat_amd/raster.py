@@ -65,6 +65,9 @@ class RasterBackend:
         self._cam_cache = {}
         # one-shot identity of the camera of the NEXT forward (GaussianRasterizer.camera_key); None = hash the view matrix
         self.camera_key = None
+        # one-shot, set with camera_key by GaussianRasterizer: the caller named the camera and did not decline depth limits
+        # (GaussianRasterizer.camera_limits) - the forward may use this camera's verified limits as with GS_DEPTH_LIMIT=1
+        self.camera_key_limits = False
         self._region_key = None    # (P, W, H) of the call being served (see _region_off)
         self._vm_ids = {}
         self.camera_cache_stats = dict(hits=0, misses=0, hashed=0)
@@ -293,7 +296,7 @@ class RasterBackend:
         leave them alone when a forward overflowed, so whatever is read from them is safe.
         -> dict(order, order_ok, limit, limit_ok) or None"""
         if device.type != "cuda" or not (self.order_hint_on or self.depth_limit_on or self.depth_limit_request is not None
-                                         or self.static_capacity is not None):
+                                         or self.static_capacity is not None or self.camera_key_limits):
             self.camera_key = None
             return None
         key = (device.index, W, H, self._camera_identity(viewmatrix))
@@ -383,6 +386,8 @@ class RasterBackend:
     # is launched on a side stream right before the fused backward and runs NEXT TO the backward blend; the per-Gaussian
     # kernel of gs_backward_step (phase 2) waits for it.  From TWO_PHASE_MIN_P Gaussians on (below, the extra launch and
     # the stream hand-offs cost more than the hidden stream saves); GS_TWO_PHASE_STEP=0 switches it off.
+    # depth-limited lists for callers that name their cameras (GaussianRasterizer.camera_key); GS_KEYED_LIMITS=0: never
+    KEYED_LIMITS = os.environ.get("GS_KEYED_LIMITS", "1") != "0"
     TWO_PHASE = os.environ.get("GS_TWO_PHASE_STEP", "1") != "0"
     TWO_PHASE_MIN_P = 100_000
 
@@ -500,8 +505,9 @@ class RasterBackend:
         static = self.static_capacity is not None
         use_order = cache is not None and self.order_hint_on
         request, self.depth_limit_request = self.depth_limit_request, None
+        keyed_limits, self.camera_key_limits = self.camera_key_limits and self.KEYED_LIMITS, False
         self.deferred = None
-        use_limit = cache is not None and (self.depth_limit_on or request is not None) and self.tile_cull
+        use_limit = cache is not None and (self.depth_limit_on or request is not None or keyed_limits) and self.tile_cull
         defer = request == "defer"
         # capture-safe mode always passes the limit buffer (+inf = no limit): the pointer is frozen into the graph
         limit = cache["limit"] if use_limit and (static or cache["limit_ok"]) else None

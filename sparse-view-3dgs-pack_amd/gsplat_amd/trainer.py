@@ -143,6 +143,7 @@ class FlatAdam:
         st.max_radii2D = m.max_radii2D.data_ptr()
         st.xyz_gradient_accum, st.denom = m.stat_delta[0].data_ptr(), m.stat_delta[1].data_ptr()
         st.fail_flag = m.fail_flag.data_ptr()
+        st.grad_mask = m.grad_mask.data_ptr()
         self._nir_into(st, True)
         return st
 
@@ -367,6 +368,8 @@ class GaussianModelLite:
         self.stat_tail = self.exchange[n_pad:]            # statistics + flag: what travels beside the gradients
         self.fail_flag = self.exchange[n_pad + 2 * P:n_pad + 2 * P + 1]
         self.gain_grad_word = self.exchange[n_pad + 2 * P + 1:n_pad + 2 * P + 2]   # multispectral model: dL/dgain of this view
+        # data-parallel step: 1 where this view's gradient row of the Gaussian may be non-zero (sparse exchange)
+        self.grad_mask = torch.zeros((P,), dtype=torch.uint8, device=self.device)
         self.params = {}
         off = 0
         shapes = self._shapes(P)
@@ -730,6 +733,7 @@ def render(viewpoint_camera, pc, Rasterizer, Settings, bg_color, scaling_modifie
     rasterizer = Rasterizer(raster_settings=rs)
     if camera_key is not None:  # stable camera identity for the backend's per-camera state (GaussianRasterizer.camera_key)
         rasterizer.camera_key = camera_key
+        rasterizer.camera_limits = False   # (the train step asks for depth limits itself: Trainer.depth_limit)
     rendered_image, radii, depth_image = rasterizer(
         means3D=pc.get_xyz, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None,
         opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=None)
@@ -790,7 +794,7 @@ class Trainer:
     `train_iteration(it, opt)` is one iteration of the reference's loop with its schedule."""
 
     def __init__(self, model, cameras, gt_images, criterion, Rasterizer, Settings, bg, rank=0, world_size=1,
-                 optimizer_step=True, masks=None, sharded_optimizer=None):
+                 optimizer_step=True, masks=None, sharded_optimizer=None, sparse_exchange=None):
         # sharded_optimizer (default: env GS_SHARDED_ADAM=1): reduce-scatter the gradients, Adam on this rank's 1/N of
         # the rows, all-gather the parameters - instead of all-reduce + the full Adam pass on every replica
         import os
@@ -800,6 +804,11 @@ class Trainer:
         # the moments only before a densification or a checkpoint.
         self.sharded_optimizer = (os.environ.get("GS_SHARDED_ADAM", "1") == "1") if sharded_optimizer is None \
             else bool(sharded_optimizer)
+        # N > 1: move only the gradient rows of the Gaussians some rank's view reached (_exchange_and_step_sparse; replaces
+        # the sharded / all-reduce forms when on).  GS_SPARSE_EXCHANGE=1 / sparse_exchange=True
+        self.sparse_exchange = (os.environ.get("GS_SPARSE_EXCHANGE", "0") == "1") if sparse_exchange is None \
+            else bool(sparse_exchange)
+        self.last_exchange = None
         self.model, self.cameras, self.gts, self.criterion = model, cameras, gt_images, criterion
         self.Rasterizer, self.Settings, self.bg = Rasterizer, Settings, bg
         self.rank, self.world_size = rank, world_size
@@ -985,6 +994,8 @@ class Trainer:
         with torch.no_grad():
             m.collect_grads()
             m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
+            if self.world_size > 1:   # (a culled Gaussian's gradient row is all zero, rasterize_points.cu:163-172)
+                torch.gt(radii, 0, out=m.grad_mask.view(torch.bool))
             self.exchange_and_step(optimizer_step, skip)
 
     def _step_camera(self, ci, optimizer_step, skip, exposure_step=None):
@@ -1107,6 +1118,8 @@ class Trainer:
         m = self.model
         opt = m.optimizer
         chunked = isinstance(opt, FlatAdam)
+        if self.sparse_exchange and chunked:
+            return self._exchange_and_step_sparse(optimizer_step, skip, gate)
         if self.sharded_optimizer and chunked:
             return self._exchange_and_step_sharded(optimizer_step, skip, gate)
         n_grad = m.flat_grad.numel()
@@ -1144,12 +1157,57 @@ class Trainer:
             m.xyz_gradient_accum += (m.stat_delta[0] * ok).unsqueeze(1)
             m.denom += (m.stat_delta[1] * ok).unsqueeze(1)
 
+    def _exchange_and_step_sparse(self, optimizer_step, skip=(), gate=None):
+        """The visibility-sparse exchange.  Only Gaussians that emitted instances in SOME rank's view of this step
+        have a non-zero gradient row - with depth-limited lists a fifth of them per view, and never more than the ~40 % any
+        camera reaches - so: all-reduce (MAX) the per-rank row masks (1 byte per Gaussian), pack the union's rows of the
+        field-major gradient buffer into one contiguous buffer, all-reduce THAT, scatter the sums back, and run the dense
+        gated Adam on every replica (rows outside the union hold the exact sum already: zero on every rank - their update
+        is the zero-gradient one, identical everywhere, no traffic).  Statistics + flag (8 B/Gaussian) and max_radii2D
+        travel dense as in the other forms.  With two ranks the sums are the dense all-reduce's bit for bit (a + b
+        commutes); with more the reduction order is the library's choice in either form.  One host read per step (the
+        union's size, which the collective's message length needs)."""
+        m, opt = self.model, self.model.optimizer
+        P, W = m.P, m.width
+        n_grad = m.flat_grad.numel()
+        ws = dist.all_reduce(m.stat_tail, op=dist.ReduceOp.SUM, async_op=True)   # statistic increments + validity flag
+        wmax = dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)
+        dist.all_reduce(m.grad_mask, op=dist.ReduceOp.MAX)
+        idx = m.grad_mask.nonzero().squeeze(1)        # (host sync: K)
+        K = int(idx.numel())
+        if K:
+            need = (K * W + 3) // 4 * 4
+            buf = getattr(self, "_packed", None)
+            if buf is None or buf.numel() < need or buf.device != m.flat.device:
+                buf = self._packed = torch.empty((int(need * 1.25) + 1024,), dtype=torch.float32, device=m.flat.device)
+            views, off, poff = [], 0, 0
+            for name, n in m.fields:
+                src = m.flat_grad[off:off + P * n].view(P, n)
+                dst = buf[poff:poff + K * n].view(K, n)
+                torch.index_select(src, 0, idx, out=dst)
+                views.append((src, dst))
+                off += P * n
+                poff += K * n
+            dist.all_reduce(buf[:K * W], op=dist.ReduceOp.SUM)
+            for src, dst in views:
+                src.index_copy_(0, idx, dst)
+        self.last_exchange = dict(union_rows=K, rows=P, sparse_bytes=4 * K * W + P + 4 * int(m.stat_tail.numel()),
+                                  dense_bytes=4 * (n_grad + int(m.stat_tail.numel())))
+        if gate is not None:
+            ws.wait()  # the gate is the reduced flag
+        if optimizer_step:
+            opt.begin_step(skip)
+            opt.step_range(0, n_grad, skip, gate=gate)
+        ws.wait()
+        wmax.wait()
+        self._add_statistics(gate)
+
     def gather_optimizer_state(self):
         """Sharded optimizer only: every rank holds current Adam moments for ITS shard; before anything that needs them
         all (densification re-layout, checkpoint) they are all-gathered in place.  No-op otherwise."""
         m, opt = self.model, self.model.optimizer
-        if not (self.sharded_optimizer and self.world_size > 1 and isinstance(opt, FlatAdam)):
-            return
+        if not (self.sharded_optimizer and self.world_size > 1 and isinstance(opt, FlatAdam)) or self.sparse_exchange:
+            return   # (all-reduce and sparse forms: every replica holds all moments)
         S = m.flat_padded.numel() // self.world_size
         for buf in (opt.exp_avg_padded, opt.exp_avg_sq_padded):
             dist.all_gather_into_tensor(buf, buf[self.rank * S:(self.rank + 1) * S])
@@ -1210,7 +1268,7 @@ def render_rgb_nir(viewpoint_camera, pc, Settings, bg_color, scaling_modifier=1.
         ssp = torch.empty_like(pc.get_xyz).requires_grad_(True)
         rast = GaussianRasterizerX(rs)
         if camera_key is not None:
-            rast.camera_key = camera_key
+            rast.camera_key, rast.camera_limits = camera_key, False
         color, radii, depth, nir_img = rast(
             means3D=pc.get_xyz, means2D=ssp, opacities=pc.params["opacity"], extra=pc.params["nir_albedo"],
             shs=pc.get_features, scales=pc.params["scaling"], rotations=pc.params["rotation"], extra_gain=pc.nir_gain)
@@ -1225,7 +1283,7 @@ def render_rgb_nir(viewpoint_camera, pc, Settings, bg_color, scaling_modifier=1.
     if two_pass_rasterizer is None:
         rast = GaussianRasterizerX(rs)
         if camera_key is not None:
-            rast.camera_key = camera_key
+            rast.camera_key, rast.camera_limits = camera_key, False
         color, radii, depth, nir_img = rast(
             means3D=pc.get_xyz, means2D=ssp, opacities=opacities, extra=nir, shs=pc.get_features, scales=scales,
             rotations=rotations)
@@ -1352,6 +1410,7 @@ class TrainerNIR(Trainer):
             m.update_view_statistics(radii, vg.contiguous(), into_delta=self.world_size > 1)
             if self.world_size > 1:
                 dist.all_reduce(m.nir_gain.grad, op=dist.ReduceOp.SUM)
+                torch.gt(radii, 0, out=m.grad_mask.view(torch.bool))
             self.exchange_and_step(optimizer_step, skip)
             if optimizer_step:
                 # the reference keeps the global gain in the main Adam (mult-dwtgs/scene/gaussian_model.py:266-280): it
@@ -1371,7 +1430,11 @@ class TrainerNIR(Trainer):
             gs = m.nir_gain_optimizer.state[m.nir_gain]
             segs = (opt._Seg * 1)()
             segs[0].begin, segs[0].end, segs[0].lr_a, segs[0].step = 0, 1, opt.lr["nir_gain"], opt.seg_steps["nir_gain"]
-            opt.api.call("adam_step_gated", m.nir_gain.data_ptr(), m.gain_grad_word.data_ptr(), gs["exp_avg"].data_ptr(),
+            gbuf = getattr(self, "_gain_grad_buf", None)   # (the kernel wants 16-byte aligned pointers: the word is not)
+            if gbuf is None:
+                gbuf = self._gain_grad_buf = torch.zeros((4,), dtype=torch.float32, device=m.flat.device)
+            gbuf[:1].copy_(m.gain_grad_word)
+            opt.api.call("adam_step_gated", m.nir_gain.data_ptr(), gbuf.data_ptr(), gs["exp_avg"].data_ptr(),
                          gs["exp_avg_sq"].data_ptr(), 1, segs, 1, opt.betas[0], opt.betas[1], opt.eps, opt.t,
                          gate.data_ptr(), _stream_of(m.flat))
 

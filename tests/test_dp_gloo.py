@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, outdir, sharded=False):
+def _worker(rank, world, port, outdir, sharded=False, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
@@ -28,13 +28,14 @@ def _worker(rank, world, port, outdir, sharded=False):
     from test_trainer_cpu import make_trainer
     orc = oracle_lib.get()
     tr = make_trainer(orc, P=400, W=96, H=64, world_size=world, rank=rank)
-    tr.sharded_optimizer = sharded
+    tr.sharded_optimizer, tr.sparse_exchange = sharded, sparse
     for k in range(2):
         tr.step(k)
     m = tr.model
     torch.save(dict(flat=m.flat.clone(), grad=m.flat_grad.clone(), m1=m.optimizer.exp_avg.clone(),
                     m2=m.optimizer.exp_avg_sq.clone(), accum=m.xyz_gradient_accum.clone(),
-                    denom=m.denom.clone(), maxr=m.max_radii2D.clone(), cams=[tr.camera_index(k) for k in range(2)]),
+                    denom=m.denom.clone(), maxr=m.max_radii2D.clone(), cams=[tr.camera_index(k) for k in range(2)],
+                    exchange=tr.last_exchange),
                os.path.join(outdir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -108,7 +109,7 @@ def test_sharded_optimizer_equals_the_all_reduce_path_bit_for_bit():
     assert 0 < S < n  # both ranks own a non-empty shard
 
 
-def _worker_schedule(rank, world, port, outdir, sharded=False):
+def _worker_schedule(rank, world, port, outdir, sharded=False, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
@@ -119,7 +120,7 @@ def _worker_schedule(rank, world, port, outdir, sharded=False):
     from test_trainer_cpu import make_trainer
     orc = oracle_lib.get()
     tr = make_trainer(orc, P=300, W=96, H=64, world_size=world, rank=rank, dwt=False)
-    tr.sharded_optimizer = sharded
+    tr.sharded_optimizer, tr.sparse_exchange = sharded, sparse
     opt = TrainOptions(iterations=20, densify_from_iter=2, densification_interval=3, opacity_reset_interval=5,
                        densify_until_iter=12, cameras_extent=4.4, densify_grad_threshold=1e-7, seed=1)
     cams, sizes = [], []
@@ -175,3 +176,57 @@ def test_schedule_with_densification_keeps_replicas_identical(world):
     flat = [c for cams in per_step for c in cams]
     for k in range(0, len(flat), 4):  # 4 cameras in the scene: every 4 draws are a permutation of them
         assert sorted(flat[k:k + 4]) == [0, 1, 2, 3]
+
+
+@pytest.mark.timeout(600)
+def test_sparse_exchange_equals_the_dense_all_reduce_bit_for_bit():
+    """The visibility-sparse exchange (Trainer._exchange_and_step_sparse: union of the ranks' row masks, pack, all-reduce,
+    scatter, dense Adam) against the dense all-reduce on two ranks: gradients, parameters, both moments and the statistics
+    are the same bits on every rank (a + b commutes; rows outside the union are 0 + 0), and fewer bytes moved."""
+    world = 2
+    runs = {}
+    for sparse in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker, args=(world, _free_port(), d, False, sparse), nprocs=world, join=True)
+            runs[sparse] = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(world)]
+    ref = runs[False][0]
+    for r in range(world):
+        got = runs[True][r]
+        for k in ("flat", "grad", "m1", "m2", "accum", "denom", "maxr"):
+            assert torch.equal(got[k], ref[k]), (r, k)
+        ex = got["exchange"]
+        # (this small scene lies inside every camera's frustum: the union is all of it; tests/test_gpu_dp_fused.py runs the
+        #  depth-limited GPU form, where a view reaches a fifth of the Gaussians)
+        assert 0 < ex["union_rows"] <= ex["rows"] and ex["sparse_bytes"] <= ex["dense_bytes"] + ex["rows"]
+    assert runs[False][0]["exchange"] is None
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sparse_exchange_through_densification(world):
+    """8 iterations of the schedule (densify / prune / opacity reset: P changes, the masks and the packed buffer follow) with
+    the sparse exchange: replicas bit-identical; against the dense all-reduce run - the same bits on two ranks, and on
+    four (where the library adds the four contributions in an order of its own choosing in either form) the same sizes
+    and parameters to rounding."""
+    out = {}
+    for sparse in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker_schedule, args=(world, _free_port(), d, False, sparse), nprocs=world, join=True)
+            out[sparse] = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(world)]
+    a = out[False][0]
+    assert a["sizes"][-1] != a["sizes"][0]
+    for r in range(world):
+        b = out[True][r]
+        assert b["sizes"] == out[True][0]["sizes"]
+        for k in ("flat", "m1", "m2"):
+            assert torch.equal(out[True][0][k], b[k]), (r, k)      # replicas
+    b = out[True][0]
+    if world == 2:
+        assert b["sizes"] == a["sizes"]
+        for k in ("flat", "m1", "m2"):
+            assert torch.equal(a[k], b[k]), k
+    else:
+        assert b["sizes"][:3] == a["sizes"][:3]
+        if b["sizes"] == a["sizes"]:
+            d = (a["flat"] - b["flat"]).double()
+            assert float(d.pow(2).mean().sqrt()) <= 1e-3 * float(a["flat"].double().pow(2).mean().sqrt())

@@ -28,11 +28,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make(rank, world, fused):
+def _make(rank, world, fused, nir=False):
     import diff_gaussian_rasterization as dgr
     import lgdwt_loss
     from gsplat_amd import hip_backend, synthetic
-    from gsplat_amd.trainer import GaussianModelLite, Trainer, camera_to, render
+    from gsplat_amd.losses import LossOps
+    from gsplat_amd.trainer import GaussianModelLite, NirCriterion, Trainer, TrainerNIR, camera_to, render
     from simple_knn._C import distCUDA2
     dev = torch.device("cuda", 0)
     hip = hip_backend()
@@ -45,6 +46,14 @@ def _make(rank, world, fused):
     tm = GaussianModelLite(target, dev, api=hip.api)
     with torch.no_grad():
         gts = [render(c, tm, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg)["render"].clone() for c in cams]
+    if nir:  # the multispectral step (TrainerNIR): 60-float rows + the global gain, RGB criterion with the DWT terms
+        nirs = [torch.rand((1, H, W), generator=g).to(dev) for _ in cams]
+        model = GaussianModelLite(sc, dev, api=hip.api, with_nir=True)
+        rgb = lgdwt_loss.criterion(dwt_enable=True, patch_dwt_enable=True, fused=fused)
+        tr = TrainerNIR(model, cams, gts, nirs, NirCriterion(LossOps(hip.api), rgb_criterion=rgb, fused=fused),
+                        dgr.GaussianRasterizationSettings, bg, rank=rank, world_size=world, optimizer_step=True)
+        tr.FUSED_STEP = fused
+        return tr, hip
     model = GaussianModelLite(sc, dev, api=hip.api)
     crit = lgdwt_loss.criterion(dwt_enable=True, patch_dwt_enable=True)
     tr = Trainer(model, cams, gts, crit, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, bg, rank, world,
@@ -53,13 +62,13 @@ def _make(rank, world, fused):
     return tr, hip
 
 
-def _worker(rank, world, port, outdir, mode, sharded):
+def _worker(rank, world, port, outdir, mode, sharded, nir=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tr, hip = _make(rank, world, fused=(mode != "plain"))
-    tr.sharded_optimizer = sharded
+    tr, hip = _make(rank, world, fused=(mode != "plain"), nir=nir)
+    tr.sharded_optimizer, tr.sparse_exchange = sharded is True, sharded == "sparse"
     hip.tile_cull = True
     info = {}
     if mode == "plain":
@@ -91,17 +100,19 @@ def _worker(rank, world, port, outdir, mode, sharded):
     m = tr.model
     tr.gather_optimizer_state()
     torch.cuda.synchronize()
+    gain = None if m.nir_gain is None else m.nir_gain.detach().cpu().reshape(1).clone()
     torch.save(dict(flat=m.flat.detach().cpu(), accum=m.xyz_gradient_accum.cpu(), denom=m.denom.cpu(),
-                    maxr=m.max_radii2D.cpu(), m1=m.optimizer.exp_avg.cpu(), t=m.optimizer.t, info=info),
+                    maxr=m.max_radii2D.cpu(), m1=m.optimizer.exp_avg.cpu(), t=m.optimizer.t, info=info, gain=gain,
+                    seg_steps=dict(m.optimizer.seg_steps), exchange=tr.last_exchange),
                os.path.join(outdir, "%s_rank%d.pt" % (mode, rank)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(mode, sharded):
+def _run(mode, sharded, nir=False):
     world = 2
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d, mode, sharded), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, mode, sharded, nir), nprocs=world, join=True)
         return [torch.load(os.path.join(d, "%s_rank%d.pt" % (mode, r))) for r in range(world)]
 
 
@@ -123,7 +134,7 @@ def _same_run(a, b):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("sharded", [False, True], ids=["allreduce", "sharded"])
+@pytest.mark.parametrize("sharded", [False, True, "sparse"], ids=["allreduce", "sharded", "sparse"])
 def test_fused_data_parallel_step_is_the_plain_one_and_a_bad_view_repeats_on_every_rank(sharded):
     plain = _run("plain", sharded)
     fused = _run("fused", sharded)
@@ -142,3 +153,32 @@ def test_fused_data_parallel_step_is_the_plain_one_and_a_bad_view_repeats_on_eve
     for r in (0, 1):
         assert bad[r]["info"]["unchanged_after_bad_step"], "rank %d stepped on an invalid view" % r
         assert bad[r]["info"]["t_after_bad_step"] == 1   # (counter advanced optimistically; put back and redone by sync)
+    if sharded == "sparse":
+        # the visibility-sparse exchange: with depth-limited lists the union of the two views' instanced Gaussians is a
+        # fraction of the model, and only those rows travelled
+        ex = fused[0]["exchange"]
+        print("sparse exchange:", ex)
+        assert 0 < ex["union_rows"] < 0.8 * ex["rows"] and ex["sparse_bytes"] < 0.85 * ex["dense_bytes"]
+
+
+@pytest.mark.timeout(900)
+def test_fused_data_parallel_multispectral_step():
+    """TrainerNIR with N = 2: the fused form (gs_backward_step_x writes the 60 gradient floats per Gaussian and dL/dgain into
+    the exchange buffer; gated Adam on the rows and on the gain after the reduction) against the un-fused data-parallel
+    multispectral step, and with one rank's view sabotaged: replicas bit-identical, trajectories equal, the gain stepped
+    once per step on every rank."""
+    plain = _run("plain", True, nir=True)
+    fused = _run("fused", True, nir=True)
+    bad = _run("sabotage", True, nir=True)
+    for run in (plain, fused, bad):
+        for k in ("flat", "accum", "denom", "maxr", "m1", "gain"):
+            assert torch.equal(run[0][k], run[1][k]), "replicas differ in " + k
+        assert run[0]["t"] == run[1]["t"] == 8 and run[0]["seg_steps"]["nir_gain"] == 8
+        assert run[0]["flat"].numel() == 30000 * 60 and float(run[0]["gain"]) != 1.0
+    _same_run(plain[0], fused[0])
+    _same_run(plain[0], bad[0])
+    assert abs(float(plain[0]["gain"]) - float(fused[0]["gain"])) <= 1e-5
+    assert abs(float(plain[0]["gain"]) - float(bad[0]["gain"])) <= 1e-5
+    assert bad[1]["info"]["failed"] >= 1
+    for r in (0, 1):
+        assert bad[r]["info"]["unchanged_after_bad_step"], "rank %d stepped on an invalid view" % r
