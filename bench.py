@@ -496,16 +496,23 @@ def main():
         n_di = min(args.steps, 20)
         for label, kw in (("torch.optim.Adam", dict(optimizer="torch")),
                           ("FusedAdam", dict(optimizer="fused")),
-                          ("FusedAdam + camera_key", dict(optimizer="fused", use_camera_key=True))):
+                          ("FusedAdam + camera_key", dict(optimizer="fused", use_camera_key=True)),
+                          ("FusedAdam + camera_key + lgdwt_loss.criterion()", dict(optimizer="fused", use_camera_key=True,
+                                                                                 fused_criterion=True))):
+            from gsplat_amd import hip_backend as _hbd
+            bed = _hbd()
             loop = DropInLoop(scene, cams, gts, device, dwt=dwt, patch=patch, **kw)
             for j in range(len(cams) + 2):      # every camera once (a keyed camera's limits exist from its second visit on)
                 loop.iteration(j % len(cams))
             torch.cuda.synchronize()
+            dd0 = dict(bed.depth_limit_stats)
             t1 = time.perf_counter()
             for j in range(n_di):
                 loop.iteration((j + 2) % len(cams))
             torch.cuda.synchronize()
-            drop_in[label] = {"ms_per_step": (time.perf_counter() - t1) / n_di * 1e3, "steps": n_di}
+            drop_in[label] = {"ms_per_step": (time.perf_counter() - t1) / n_di * 1e3, "steps": n_di,
+                              "depth_limited_views": bed.depth_limit_stats["used"] - dd0["used"],
+                              "fallbacks": bed.depth_limit_stats["failed"] - dd0["failed"]}
             log("drop-in loop, %s: %.3f ms/step" % (label, drop_in[label]["ms_per_step"]))
             del loop
         drop_in["drop_in_api_ms_per_step"] = drop_in["torch.optim.Adam"]["ms_per_step"]

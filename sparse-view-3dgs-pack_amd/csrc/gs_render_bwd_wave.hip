@@ -318,19 +318,22 @@ int launch_blend_stats(const uint2* ranges, const uint32_t* point_list, int W, i
   return 0;
 }
 
-// zero fill of the gradient rows (GR_STRIDE = 16 doubles = eight float4 per row).  With tiles_touched given only the rows of
-// Gaussians that emitted instances are cleared: no atomic lands anywhere else and the per-Gaussian stage does not read the
-// others (PreprocessBwdArgs.skip_uninstanced) - a fifth of the rows with depth-limited lists.
-__global__ void __launch_bounds__(GS_BLOCK) zero_rows_kernel(float4* __restrict__ p, size_t n4,
+// zero fill of the gradient rows (GR_STRIDE = 16 float64 slots, twelve in use = six float4 per row): one thread per
+// Gaussian.  With tiles_touched given only the rows of Gaussians that emitted instances are cleared: no atomic lands
+// anywhere else and the chain kernel does not read the others (PreprocessBwdArgs.skip_uninstanced) - a fifth of the rows
+// with depth-limited lists.  (One thread per float4 - 8 M threads at 1 M Gaussians, seven eighths of them leaving after
+// the flag load - took 26 us; this takes 7.)
+__global__ void __launch_bounds__(GS_BLOCK) zero_rows_kernel(float4* __restrict__ p, size_t P,
                                                              const uint32_t* __restrict__ tiles_touched) {
   const size_t i = (size_t)blockIdx.x * GS_BLOCK + threadIdx.x;
-  if (i < n4 && (!tiles_touched || tiles_touched[i >> 3] != 0)) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i >= P || (tiles_touched && tiles_touched[i] == 0)) return;
+  float4* w = p + i * (GR_ROW_BYTES / 16);
+  w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 int launch_zero_rows(gs_row_t* rows, size_t P, const uint32_t* tiles_touched, hipStream_t s) {
-  static_assert(GR_ROW_BYTES == 128, "eight float4 per row");
-  const size_t n4 = P * (GR_ROW_BYTES / 16);
-  if (n4) hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n4 + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, s,
-                             reinterpret_cast<float4*>(rows), n4, tiles_touched);
+  static_assert(GR_ROW_BYTES == 128, "eight float4 per row, six in use");
+  if (P) hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((P + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), 0, s,
+                            reinterpret_cast<float4*>(rows), P, tiles_touched);
   return 0;
 }
 

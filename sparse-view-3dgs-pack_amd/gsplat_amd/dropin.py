@@ -79,7 +79,8 @@ def render(cam, pc, bg_color, camera_key=None):
 class DropInLoop:
     """One object = one training run's state (model, optimizer, the running mean of train.py:75)."""
 
-    def __init__(self, scene, cameras, gt_images, device, dwt=True, patch=True, optimizer="torch", use_camera_key=False):
+    def __init__(self, scene, cameras, gt_images, device, dwt=True, patch=True, optimizer="torch", use_camera_key=False,
+                 fused_criterion=False):
         self.pc = DropInModel(scene, device)
         self.cameras, self.gts = cameras, gt_images
         self.bg = torch.zeros(3, device=device)
@@ -88,6 +89,12 @@ class DropInLoop:
         self.lambda_dssim, self.patch_dwt_weight = 0.2, 0.1
         self.dwt_weights = {"LL1": 1.0, "LH1": 1.0, "HL1": 1.0, "HH1": 0.0, "LL2": 0.0, "LH2": 0.0, "HL2": 0.0, "HH2": 0.0}
         self.use_camera_key = use_camera_key
+        # INTEGRATION.md section 1, "optional, faster": the loss calls of train.py:128-202 replaced by ONE call of
+        # lgdwt_loss.criterion() (same terms, the running mean kept on the device: no `.item()`), ELF masks cached per camera
+        self.criterion, self.masks = None, {}
+        if fused_criterion:
+            import lgdwt_loss
+            self.criterion = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch)
         if optimizer == "torch":
             self.optimizer = torch.optim.Adam(self.pc.groups(), lr=0.0, eps=1e-15)
         else:
@@ -103,6 +110,11 @@ class DropInLoop:
         pkg = render(self.cameras[ci], pc, self.bg, camera_key=("dropin", ci) if self.use_camera_key else None)
         image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
         gt = self.gts[ci]
+        if self.criterion is not None:
+            if self.patch and ci not in self.masks:
+                self.masks[ci] = self.criterion.elf_mask(gt)
+            loss, _ = self.criterion(image, gt, mask=self.masks.get(ci))
+            return self._finish(loss, vsp, vis, radii)
         Ll1 = l1_loss(image, gt)
         dwt_loss = torch.tensor(0.0, device=image.device)
         if self.dwt:
@@ -127,6 +139,10 @@ class DropInLoop:
             loss = base
         if self.patch:
             loss = loss + self.patch_dwt_weight * patch_loss
+        return self._finish(loss, vsp, vis, radii)
+
+    def _finish(self, loss, vsp, vis, radii):
+        pc = self.pc
         loss.backward()
         with torch.no_grad():
             # train.py:266-268

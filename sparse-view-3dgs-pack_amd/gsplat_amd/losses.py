@@ -44,10 +44,14 @@ class LossOps:
             @staticmethod
             def backward(ctx, g):
                 a, b = ctx.saved_tensors
-                # coef is applied on the device so no host sync is needed: grad = sign * (g / n)
-                sign = torch.empty_like(a)
-                ops.api.call("l1_bwd", a.data_ptr(), b.data_ptr(), a.numel(), 1.0, sign.data_ptr(), 0, _stream(a))
-                ga = sign * (g / a.numel())
+                # grad = sign(a - b) * (g / n), the coefficient read on the device (no host sync, one pass over the image)
+                coef = (g / a.numel()).reshape(1).contiguous()
+                ga = torch.empty_like(a)
+                if hasattr(ops.api, "_l1_bwd_dev"):
+                    ops.api.call("l1_bwd_dev", a.data_ptr(), b.data_ptr(), a.numel(), coef.data_ptr(), ga.data_ptr(), 0, _stream(a))
+                else:
+                    ops.api.call("l1_bwd", a.data_ptr(), b.data_ptr(), a.numel(), 1.0, ga.data_ptr(), 0, _stream(a))
+                    ga = ga * coef
                 return ga, (-ga if ctx.needs_input_grad[1] else None)
 
         class _Haar(torch.autograd.Function):

@@ -27,11 +27,11 @@ def one_binning_path(hip):
     hip._cam_cache.clear()
 
 
-def make(hip, fused, P=30000, W=480, H=320, seed=3, sh_degree=3, skip_rows=None):
+def make(hip, fused, P=30000, W=480, H=320, seed=3, sh_degree=3, skip_rows=None, n_cams=4):
     from simple_knn._C import distCUDA2
     dev = torch.device("cuda")
     sc = synthetic.trained_like(P, seed=seed, sh_degree=sh_degree, knn=lambda x: distCUDA2(x.to(dev)).cpu())
-    cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(W, H)[:4]]
+    cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(W, H)[:n_cams]]
     g = torch.Generator().manual_seed(5)
     gts = [torch.rand((3, H, W), generator=g).to(dev) for _ in cams]
     model = GaussianModelLite(sc, dev, api=hip.api)
@@ -245,3 +245,53 @@ def test_graphed_step_recaptures_after_a_restore_of_the_same_size(hip):
         assert torch.equal(sa[k], sb[k]), (k, float((sa[k] - sb[k]).abs().max()))
     assert a.model.optimizer.t == b.model.optimizer.t
     assert max(abs(x - y) for x, y in zip(la[1::2], lb)) <= 1e-6 * max(la)
+
+
+def test_captured_graphs_pin_their_camera_entries_against_eviction(hip):
+    """A captured graph holds the ADDRESSES of its camera's tile-order / depth-limit / slack buffers.  The backend's
+    per-camera cache evicts its oldest entry when full - never one a graph points into (GraphedStep pins it and keeps a
+    reference), and entries of a trainer that is gone are dropped.  Six cameras under GraphedStep with room for four
+    entries: every camera keeps the entry it was captured with, replays stay the eager run bit for bit."""
+    import gc
+    from gsplat_amd.trainer import GraphedStep
+    _prime(hip)
+    hip._cam_cache.clear()
+    hip.CAMERA_CACHE_MAX = 4
+    try:
+        a = make(hip, True, P=12000, W=320, H=192, n_cams=6)
+        b = make(hip, True, P=12000, W=320, H=192, n_cams=6)
+        P = a.model.P
+        g = torch.Generator().manual_seed(17)
+        rows = torch.zeros((P, 16), dtype=torch.float64)
+        rows[:, :9] = (torch.randn((P, 9), generator=g) * 1e-3).double()
+        rows = rows.cuda()
+        a.rows_override = b.rows_override = rows
+        a.depth_limit = b.depth_limit = "deferred"
+        gs = GraphedStep(b, warmup=1)
+        for k in range(18):          # every camera: capture, then two replays - while four other cameras come and go
+            gs.step(k)
+        gs.sync()
+        assert gs.captures == 6 and gs.eager_steps == 0 and gs.replays == 12
+        ents = {ci: gs.graphs[ci]["entry"] for ci in range(6)}
+        for ci, e in ents.items():
+            assert e is gs.camera_entry(ci) and e.get("pinned", 0) >= 1          # still THE entry of that camera
+            assert gs.graphs[ci]["key"] == gs._key(ci)
+        assert len(hip._cam_cache) >= 6                                           # (over the limit: nothing evictable)
+        # the eager reference on the same camera sequence creates its own six entries: those are evictable again
+        for c in _camera_sequence(18, warmup=1, n_cams=6):
+            a._step_camera(c, True, ())
+        a.sync()
+        torch.cuda.synchronize()
+        sa, sb = state(a), state(b)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (k, float((sa[k] - sb[k]).abs().max()))
+        for ci, e in ents.items():
+            assert e is gs.camera_entry(ci)
+        # a trainer that goes takes its entries (and pins) with it
+        uid = b.uid
+        del gs, b, ents, e
+        gc.collect()
+        assert not any(k[3][0] == "key" and k[3][1][:2] == ("trainer", uid) for k in hip._cam_cache)
+    finally:
+        del hip.CAMERA_CACHE_MAX
+        hip._cam_cache.clear()
