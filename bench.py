@@ -226,7 +226,27 @@ def measured_valu_ceilings():
     return out
 
 
-def valu_roofline(kernel, ms_per_launch):
+def counters_match(d, P, R):
+    """May the static counter file `d` (profiles/pmc_traffic.json / sq_insts.json) be combined with THIS run's durations?
+    -> None when yes, else the reason: other kernel sources (profiles/source_id.py), another P, or an instance count R
+    that differs by more than 5 % from the profiled run's."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    try:
+        from source_id import source_id
+        sid = source_id(ROOT)
+    except Exception as e:   # noqa: BLE001
+        return "source id unavailable (%r)" % (e,)
+    if d.get("source_id") != sid:
+        return "counters were collected from other kernel sources (file: %s, this build: %s)" % (d.get("source_id"), sid)
+    if P is not None and d.get("P") not in (None, P):
+        return "counters were collected with %s Gaussians, this run has %s" % (d.get("P"), P)
+    if R is not None and d.get("R"):
+        if abs(float(R) - float(d["R"])) > 0.05 * float(d["R"]):
+            return "counters were collected at R = %s instances per view, this run has %s" % (d["R"], R)
+    return None
+
+
+def valu_roofline(kernel, ms_per_launch, P=None, R=None):
     """VALU-issue fraction of a blend kernel: wave-instructions per launch (SQ_INSTS_VALU of the committed SQ-counter
     profile, profiles/sq_insts.json: {"tag": ..., "<kernel>": insts per launch}) / this run's launch duration / the
     MEASURED plain-f32 issue ceiling."""
@@ -236,6 +256,9 @@ def valu_roofline(kernel, ms_per_launch):
         insts = float(d[kernel])
     except Exception:
         return None
+    why = counters_match(d, P, R)
+    if why is not None:
+        return {"bound": "valu", "achieved": None, "frac": None, "dropped": why}
     ceil = measured_valu_ceilings()
     ach = insts / (ms_per_launch * 1e-3) / 1e9
     return {"bound": "valu", "achieved": ach, "peak": ceil["fma"], "unit": "G wave-instructions/s",
@@ -693,19 +716,24 @@ def main():
             if os.path.exists(tf) and args.config == "c3":  # counters were collected on the C3 workload
                 try:
                     t = json.load(open(tf))
-                    roofline["traffic"] = t.get(dom)
-                    roofline["traffic_from"] = "profiles/pmc_traffic.json (tag %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
-                                               "passes of this bench, not measured in this run" % t.get("tag", "r01")
+                    why = counters_match(t, P, R_last)
+                    if why is None:
+                        roofline["traffic"] = t.get(dom)
+                        roofline["traffic_from"] = "profiles/pmc_traffic.json (tag %s, same kernel sources, R within 5 %%): " \
+                                                   "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, not " \
+                                                   "measured in this run" % t.get("tag", "r01")
+                    else:
+                        roofline["traffic_dropped"] = why
                 except Exception:
                     pass
             # the blend kernels are bound by VALU issue, not by HBM: report that roof for them
             blend = {}
             for kname in ("render_bwd", "render_fwd"):
                 if kname in stages and args.config == "c3":  # (the instruction counts are those of the C3 workload)
-                    v = valu_roofline(kname, stages[kname]["ms_per_launch"])
+                    v = valu_roofline(kname, stages[kname]["ms_per_launch"], P, R_last)
                     if v:
-                        if prof_alone and kname in prof_alone:
-                            va = valu_roofline(kname, prof_alone[kname])
+                        if prof_alone and kname in prof_alone and v.get("frac") is not None:
+                            va = valu_roofline(kname, prof_alone[kname], P, R_last)
                             v["alone"] = {"ms_per_launch": prof_alone[kname], "achieved": va["achieved"], "frac": va["frac"],
                                           "what": "the kernel without the Adam stream of the two-phase step beside it "
                                                   "(GS_TWO_PHASE_STEP=0, untimed pass of this run)"}
@@ -721,7 +749,10 @@ def main():
                               "instructions; gs_backward_step's per-Gaussian kernel waits for both"}
                 try:
                     t = json.load(open(tf)) if args.config == "c3" else {}  # (the counters were collected on the C3 workload)
-                    if t.get("step_uninstanced"):
+                    why = counters_match(t, P, R_last) if t else "no counters for this configuration"
+                    if why is not None:
+                        co["traffic"], co["traffic_dropped"] = None, why
+                    elif t.get("step_uninstanced"):
                         co["traffic"] = t["step_uninstanced"]
                         co["achieved"] = t["step_uninstanced"] / 1e9 / (co["ms_per_launch"] / 1e3)
                         co["peak"], co["unit"] = HBM_PEAK_GBS, "GB/s"

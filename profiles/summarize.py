@@ -15,13 +15,30 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, here)
+from source_id import source_id  # noqa: E402
+
+
+def run_identity():
+    """What the counters belong to: the kernel sources (source_id.py) and the workload of the traced bench run (P, the
+    instance count R of its last view).  bench.py only combines these counters with a live duration when both match."""
+    ident = {"tag": tag, "source_id": source_id(os.path.dirname(here))}
+    try:
+        line = [x for x in open(os.path.join(src, "bench_trace.json")).read().splitlines() if x.startswith("{")][-1]
+        j = json.loads(line)
+        ident["P"] = j["config"]["gaussians"]
+        ident["R"] = j["config"]["num_rendered_last_view"]
+        ident["workload"] = j["config"]["workload"]
+    except Exception as e:   # noqa: BLE001
+        ident["identity_error"] = repr(e)
+    return ident
 OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs_scatter_kernel", "scan_reduce_kernel",
         "scan_sums_kernel", "scan_down_kernel", "rs_rowscan_kernel", "sorted_block_sums_kernel", "duplicate_kernel", "tile_ranges_kernel",
         "bin_prepare_kernel", "render_fwd_wave_kernel", "render_bwd_wave_kernel", "render_fwd_kernel", "render_bwd_kernel", "adam_kernel", "scan_small_kernel", "preprocess_bwd_kernel", "l1_fwd_kernel",
         "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
         "patch_dwt_kernel", "lgdwt_combine_kernel", "act_fwd_kernel", "act_bwd_kernel", "densify_stats_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel", "preprocess_bwd_step_kernel",
         "tile_order_kernel", "zero_rows_kernel", "stop_depth_bounds_kernel", "region_bin_kernel", "region_prepare_kernel",
-        "status_tag_kernel", "rs_small_sort_kernel", "step_uninstanced_kernel")
+        "status_tag_kernel", "rs_small_sort_kernel", "step_uninstanced_kernel", "chain_kernel")
 
 
 def short(name):
@@ -103,9 +120,10 @@ stage_of = {"render_bwd": "render_bwd_wave_kernel", "render_fwd": "render_fwd_wa
             "preprocess_bwd": "preprocess_bwd_kernel", "preprocess_bwd_step": "preprocess_bwd_step_kernel",
             "duplicate": "duplicate_kernel", "tile_ranges": "tile_ranges_kernel", "region_bin": "region_bin_kernel",
             "ssim_fwd": "ssim_fwd_kernel", "ssim_bwd": "ssim_bwd_kernel",
-            "step_uninstanced": "step_uninstanced_kernel"}
+            "step_uninstanced": "step_uninstanced_kernel", "chain": "chain_kernel"}
 out = {st: traffic[k] for st, k in stage_of.items() if k in traffic}
-out["tag"] = tag
+out.update(run_identity())
+out["launches_counted"] = {st: len(table[k]["FETCH_SIZE"]) for st, k in stage_of.items() if k in traffic}
 if "region_bin_kernel" in traffic:   # region binning: the whole binning stage is this one kernel (bench.py stage "sort")
     out["sort"] = traffic["region_bin_kernel"]
 elif "rs_scatter_kernel" in traffic:  # LSD path: all passes of hist + scatter (launch counts per step: 6 each)
@@ -128,7 +146,8 @@ if sq:
         w.writerow(["kernel", "waves", "VALU_insts_per_wave", "LDS_insts_per_wave", "SALU_insts_per_wave", "VMEM_rd_per_wave",
                     "VMEM_wr_per_wave", "VALU_issue_pct_of_peak", "VALU_active_x4_pct_of_SIMD_cycles", "wait_any_pct_of_wave_cycles",
                     "wait_inst_pct_of_wave_cycles", "waves_per_SIMD", "LDS_bank_conflict_pct_of_LDS_cycles"])
-        sq_insts = {"tag": tag}
+        sq_insts = run_identity()
+        sq_insts["launches_counted"] = {}
         for k, v in sorted(sq.items()):
             m = {c: sum(x) / len(x) for c, x in v.items()}
             if k not in OURS or "GRBM_GUI_ACTIVE" not in m or m.get("SQ_WAVES", 0) == 0:
@@ -146,6 +165,7 @@ if sq:
             for st, kn in (("render_bwd", "render_bwd_wave_kernel"), ("render_fwd", "render_fwd_wave_kernel")):
                 if k == kn:
                     sq_insts[st] = m.get("SQ_INSTS_VALU", 0)   # wave-instructions per launch (mean over the launches)
+                    sq_insts["launches_counted"][st] = len(v.get("SQ_INSTS_VALU", []))
                     # SIMD cycles the VALU spent issuing this kernel's instructions (SQ_ACTIVE_INST_VALU counts quad-cycles)
                     sq_insts[st + "_valu_active_cycles_per_simd"] = m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024
                     sq_insts[st + "_valu_active_share_under_profiler"] = m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles

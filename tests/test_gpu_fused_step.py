@@ -266,7 +266,8 @@ def test_captured_graphs_pin_their_camera_entries_against_eviction(hip):
         rows[:, :9] = (torch.randn((P, 9), generator=g) * 1e-3).double()
         rows = rows.cuda()
         a.rows_override = b.rows_override = rows
-        a.depth_limit = b.depth_limit = "deferred"
+        # (no depth limits here: a natural fall-back would be repeated on full lists, and with RANDOM pinned sums which
+        #  Gaussians read their row is a property of the lists; the entry's tile-order buffers are baked in either way)
         gs = GraphedStep(b, warmup=1)
         for k in range(18):          # every camera: capture, then two replays - while four other cameras come and go
             gs.step(k)
