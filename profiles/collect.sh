@@ -1,14 +1,18 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): kernel trace + stats, then HBM traffic counters in their own passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC has 4 slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
-# usage: bash profiles/collect.sh <tag>      -> gpurun_out/prof_<tag>/{trace,fetch,write}
+# usage: bash profiles/collect.sh <tag>      -> raw counters in /tmp/prof_<tag> (tens of MB: they stay on the box),
+#                                               their summary in gpurun_out/prof_<tag>_summary/ (what summarize.py writes:
+#                                               copy those files into profiles/)
 set -e
 TAG=${1:-r03}
 # kernel-level numbers: eager launches (a hipGraph replay shows the same kernels), no reference-lists leg
 export GS_BENCH_GRAPH=0 GS_BENCH_REFERENCE_LISTS=0 GS_BENCH_OTHER_SCENES=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT
+OUT=/tmp/prof_$TAG
+SUM=$R/gpurun_out/prof_${TAG}_summary
+rm -rf $OUT $SUM
+mkdir -p $OUT $SUM
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
@@ -20,4 +24,6 @@ for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY 
   i=$((i+1))
   rocprofv3 --pmc $c --output-format csv -d $OUT/sq$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > /dev/null 2> $OUT/bench_sq$i.err
 done
-find $OUT -name "*.csv" | head -30
+python3 $R/profiles/summarize.py $OUT $TAG $SUM > $SUM/summarize.log 2>&1 || tail -5 $SUM/summarize.log
+cp $OUT/bench_trace.json $SUM/${TAG}_bench_under_rocprof.json
+ls -la $SUM

@@ -5,7 +5,7 @@ the largest torch kernels), <tag>_step_timeline.txt (one steady-state step), <ta
 pmc_traffic.json (HBM bytes per launch of each kernel from FETCH_SIZE / WRITE_SIZE, corrected as
 MI355X_MICROARCH.md 'HBM' prescribes: both counters are in KiB... FETCH_SIZE under-reports wide coalesced
 reads by 2x on gfx950, WRITE_SIZE is exact for 16-B stores and float atomics).
-usage: python profiles/summarize.py gpurun_out/prof_r01b r01"""
+usage: python profiles/summarize.py <raw dir of collect.sh> <tag> [output dir, default profiles/]"""
 import collections
 import csv
 import glob
@@ -14,15 +14,16 @@ import os
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-here = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, here)
+script_dir = os.path.dirname(os.path.abspath(__file__))
+here = sys.argv[3] if len(sys.argv) > 3 else script_dir     # where the summary files go (default: profiles/)
+sys.path.insert(0, script_dir)
 from source_id import source_id  # noqa: E402
 
 
 def run_identity():
     """What the counters belong to: the kernel sources (source_id.py) and the workload of the traced bench run (P, the
     instance count R of its last view).  bench.py only combines these counters with a live duration when both match."""
-    ident = {"tag": tag, "source_id": source_id(os.path.dirname(here))}
+    ident = {"tag": tag, "source_id": source_id(os.path.dirname(script_dir))}
     try:
         line = [x for x in open(os.path.join(src, "bench_trace.json")).read().splitlines() if x.startswith("{")][-1]
         j = json.loads(line)
