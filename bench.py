@@ -666,12 +666,22 @@ def main():
         mine = torch.tensor([dt / args.steps * 1e3, ex_ms], dtype=torch.float64, device=device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        nbytes = tr.model.exchange.numel() * 4
+        dense_bytes = tr.model.exchange.numel() * 4
+        lx = getattr(tr, "last_exchange", None)      # visibility-sparse exchange (GS_SPARSE_EXCHANGE=1): what really moved
+        nbytes = int(lx["sparse_bytes"]) if lx else dense_bytes
         worst = max(float(x[1]) for x in allr)
         dp_info = {"per_rank_step_ms": [float(x[0]) for x in allr],
                    "per_rank_exchange_ms": [float(x[1]) for x in allr],
                    "per_rank_compute_ms": [float(x[0]) - float(x[1]) for x in allr],
+                   "exchange_form": ("sparse (union of the ranks' instanced Gaussians: mask all-reduce, pack, all-reduce, "
+                                     "scatter, dense gated Adam)" if lx else
+                                     ("sharded (reduce-scatter, Adam on 1/N, all-gather)" if tr.sharded_optimizer else
+                                      "chunked all-reduce, Adam behind the chunks")),
                    "exchange_bytes_per_gpu": nbytes,
+                   "exchange_bytes_per_gpu_dense": dense_bytes,
+                   "exchange_bytes_per_gpu_sparse": None if not lx else int(lx["sparse_bytes"]),
+                   "union_rows_last_step": None if not lx else int(lx["union_rows"]),
+                   "rows": int(tr.model.P),
                    # ring / RS+AG traffic per GPU = 2 (N-1)/N x bytes, over the time the slowest rank spent in the exchange
                    "bus_GBps": (2.0 * (world - 1) / world * nbytes / 1e9) / (worst * 1e-3) if worst > 0 else None,
                    "what": "exchange = reduce-scatter + Adam on 1/N + all-gather (sharded) or chunked all-reduce with Adam "

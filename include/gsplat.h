@@ -510,6 +510,18 @@ int gs_l1_dwt2_patch_bwd(const float* pred, const float* gt, int32_t C, int32_t 
 int gs_l1_dwt2_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W,
                    const float* l1_coef_dev /*[1]*/, const float* coef_dev /*[8]*/, float* grad_pred,
                    int32_t accumulate, void* stream);
+/* Order-independent sums (round 4).  The *_fwd kernels above add each workgroup's sums to their targets with float atomics:
+ * the totals then depend, in the last bits, on the order in which the workgroups finish.  These forms store the
+ * workgroups' sums instead - partials[12 w + k] for workgroup w of gs_l1_dwt2_patch_fwd_clamp_p (k: 0..7 the band sums,
+ * 8 the L1 sum, 9..11 the patch sums; gs_dwt_partials_count(C, H, W) rows; ps = 0 / mask = NULL: no patch term),
+ * partials[w] for gs_l1_fwd_p (gs_l1_partials_count(n) entries) - and gs_lgdwt_combine_pp adds them to sums[] in index
+ * order before it composes the loss: two runs of a train step give the same bits (tests/test_gpu_fused_step.py).
+ * H, W (and ps) multiples of 4, 16-byte aligned planes, else GS_E_UNSUPPORTED (use the atomic forms). */
+int64_t gs_dwt_partials_count(int32_t C, int32_t H, int32_t W);
+int gs_l1_dwt2_patch_fwd_clamp_p(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps,
+                                 const uint8_t* mask, float* partials, float* clamped_out, void* stream);
+int64_t gs_l1_partials_count(int64_t n);
+int gs_l1_fwd_p(const float* a, const float* b, int64_t n, float* partials, void* stream);
 /* like gs_ssim_fwd but returns sum(ssim_map) (+=, zero it first) instead of the map.  One atomic per workgroup on
  * sum_out: prefer gs_ssim_fwd_partials below for large images (the atomics serialise: 98 vs 59 us at 1080p). */
 int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1,
@@ -554,6 +566,11 @@ int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams
 /* the same with the SSIM sum given as sums[1] + sum(ssim_partials[0..n_partials)) */
 int gs_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_partials, float* running_mean,
                        const GsLgdwtParams* params /*host*/, float* out, void* stream);
+/* ... and with the DWT / L1 / patch sums given as sums[] + the per-workgroup partials of gs_l1_dwt2_patch_fwd_clamp_p
+ * (n_dwt rows of 12) and of gs_l1_fwd_p (n_l1 entries), added in index order */
+int gs_lgdwt_combine_pp(const float* sums, const float* ssim_partials, int64_t n_partials, const float* dwt_partials,
+                        int64_t n_dwt, const float* l1_partials, int64_t n_l1, float* running_mean,
+                        const GsLgdwtParams* params /*host*/, float* out, void* stream);
 
 /* ---- optimiser (caller side of the path): fused Adam over ONE flat fp32 parameter buffer.
  * Replaces torch.optim.Adam(lr=0, eps=1e-15) with per-group learning rates,

@@ -608,4 +608,47 @@ int gso_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n
     for (int k = 0; k < 13; k++) const_cast<float*>(sums)[k] = 0.f;
   return rc;
 }
+/* The order-independent forms (include/gsplat.h): on the CPU the sums are sequential anyway - ONE row of partials. */
+int64_t gso_dwt_partials_count(int32_t C, int32_t H, int32_t W) { return (C <= 0 || H <= 0 || W <= 0) ? 0 : 1; }
+int gso_l1_dwt2_patch_fwd_clamp_p(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps,
+                                  const uint8_t* mask, float* partials, float* clamped_out, void*) {
+  if (!raw || !gt || !partials || !clamped_out) return GS_E_NULL;
+  if ((ps > 0) != (mask != nullptr)) return GS_E_NULL;
+  float l1 = 0.f, bands[8] = {0, 0, 0, 0, 0, 0, 0, 0}, patch[3] = {0, 0, 0};
+  int rc;
+  if (ps > 0)
+    rc = gso_l1_dwt2_patch_fwd_clamp(raw, gt, C, H, W, ps, mask, &l1, bands, patch, clamped_out, nullptr);
+  else
+    rc = gso_l1_dwt2_fwd_clamp(raw, gt, C, H, W, &l1, bands, clamped_out, nullptr);
+  if (rc != GS_OK) return rc;
+  for (int k = 0; k < 8; k++) partials[k] = bands[k];
+  partials[8] = l1;
+  for (int k = 0; k < 3; k++) partials[9 + k] = patch[k];
+  return GS_OK;
+}
+int64_t gso_l1_partials_count(int64_t n) { return n <= 0 ? 0 : 1; }
+int gso_l1_fwd_p(const float* a, const float* b, int64_t n, float* partials, void*) {
+  if (!a || !b || !partials) return GS_E_NULL;
+  partials[0] = 0.f;
+  return gso_l1_fwd(a, b, n, partials, nullptr);
+}
+int gso_lgdwt_combine_pp(const float* sums, const float* ssim_partials, int64_t n_partials, const float* dwt_partials,
+                         int64_t n_dwt, const float* l1_partials, int64_t n_l1, float* running_mean, const GsLgdwtParams* pp,
+                         float* out, void*) {
+  if (!sums) return GS_E_NULL;
+  float s2[16];
+  for (int k = 0; k < 16; k++) s2[k] = sums[k];
+  for (int64_t w = 0; w < n_dwt; w++) {
+    for (int k = 0; k < 8; k++) s2[2 + k] += dwt_partials[12 * w + k];
+    s2[0] += dwt_partials[12 * w + 8];
+    for (int k = 0; k < 3; k++) s2[10 + k] += dwt_partials[12 * w + 9 + k];
+  }
+  for (int64_t w = 0; w < n_l1; w++) s2[0] += l1_partials[w];
+  GsLgdwtParams p2 = *pp;
+  p2.reset_sums = 0;
+  const int rc = gso_lgdwt_combine_p(s2, ssim_partials, n_partials, running_mean, &p2, out, nullptr);
+  if (rc == GS_OK && pp->reset_sums)
+    for (int k = 0; k < 13; k++) const_cast<float*>(sums)[k] = 0.f;
+  return rc;
+}
 }

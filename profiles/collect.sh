@@ -7,7 +7,7 @@
 set -e
 TAG=${1:-r03}
 # kernel-level numbers: eager launches (a hipGraph replay shows the same kernels), no reference-lists leg
-export GS_BENCH_GRAPH=0 GS_BENCH_REFERENCE_LISTS=0 GS_BENCH_OTHER_SCENES=0
+export GS_BENCH_GRAPH=0 GS_BENCH_REFERENCE_LISTS=0 GS_BENCH_OTHER_SCENES=0 GS_BENCH_DROP_IN=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=/tmp/prof_$TAG
 SUM=$R/gpurun_out/prof_${TAG}_summary

@@ -59,8 +59,10 @@ __device__ __forceinline__ void block_sum_atomic(float (&v)[N], float* out) {
 }
 
 // ------------------------------------------------------------------------------------------------ L1
+// partials != NULL: workgroup w stores its sum to partials[w] instead of adding it to *sum atomically (a caller that wants
+// the total independent of the order in which the workgroups finish adds the partials itself: gs_lgdwt_combine_pp)
 __global__ void __launch_bounds__(GS_BLOCK) l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          int64_t n, float* sum) {
+                                                          int64_t n, float* sum, float* __restrict__ partials) {
   float acc[1] = {0.f};
   const int64_t n4 = n >> 2;
   const float4* a4 = reinterpret_cast<const float4*>(a);
@@ -70,6 +72,20 @@ __global__ void __launch_bounds__(GS_BLOCK) l1_fwd_kernel(const float* __restric
     acc[0] += fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) acc[0] += fabsf(a[n4 * 4 + threadIdx.x] - b[n4 * 4 + threadIdx.x]);
+  if (partials) {
+    __shared__ float red[GS_BLOCK / 64];
+    float x = acc[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < GS_BLOCK / 64; w++) t += red[w];
+      partials[blockIdx.x] = t;
+    }
+    return;
+  }
   block_sum_atomic<1>(acc, sum);
 }
 __global__ void __launch_bounds__(GS_BLOCK) l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -189,7 +205,7 @@ __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __re
                                                                int C, int H, int W, float* band_sums, float* l1_sum,
                                                                float* __restrict__ clamped_out,
                                                                const uint8_t* __restrict__ patch_mask, int ps,
-                                                               float* patch_sums) {
+                                                               float* patch_sums, float* __restrict__ partials) {
   const int h1 = cdiv2(H), w1 = cdiv2(W), h2 = cdiv2(h1), w2 = cdiv2(w1);
   const int64_t total = (int64_t)C * h2 * w2;
   const int pnx = patch_mask ? W / ps : 0, pny = patch_mask ? H / ps : 0;
@@ -252,7 +268,9 @@ __global__ void __launch_bounds__(GS_BLOCK) dwt2_l1_fwd_kernel(const float* __re
     if (threadIdx.x < 12) {
       float t = 0.f;
       for (int w = 0; w < GS_BLOCK / 64; w++) t += red12[w][threadIdx.x];
-      if (t != 0.f)
+      if (partials)   // (deterministic form: the caller adds the workgroups' sums in index order, gs_lgdwt_combine_pp)
+        partials[(size_t)blockIdx.x * 12 + threadIdx.x] = t;
+      else if (t != 0.f)
         atomicAdd(threadIdx.x < 8 ? &band_sums[threadIdx.x] : (threadIdx.x == 8 ? l1_sum : &patch_sums[threadIdx.x - 9]), t);
     }
   } else {
@@ -814,7 +832,18 @@ int gs_l1_fwd(const float* a, const float* b, int64_t n, float* sum, void* strea
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_L1, s);
   if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return GS_E_UNSUPPORTED;  // torch allocations are 256-B aligned
-  hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblocks(n / 4 + 1, GS_BLOCK, 512)), dim3(GS_BLOCK), 0, s, a, b, n, sum);
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblocks(n / 4 + 1, GS_BLOCK, 512)), dim3(GS_BLOCK), 0, s, a, b, n, sum, (float*)nullptr);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int64_t gs_l1_partials_count(int64_t n) { return n <= 0 ? 0 : (int64_t)nblocks(n / 4 + 1, GS_BLOCK, 512); }
+int gs_l1_fwd_p(const float* a, const float* b, int64_t n, float* partials, void* stream) {
+  if (!a || !b || !partials) return GS_E_NULL;
+  if (n <= 0) return GS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_L1, s);
+  if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return GS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblocks(n / 4 + 1, GS_BLOCK, 512)), dim3(GS_BLOCK), 0, s, a, b, n, (float*)nullptr, partials);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -852,21 +881,25 @@ int gs_dwt_haar_bwd(const float* dll, const float* dlh, const float* dhl, const 
 static inline bool dwt2_fast(const void* a, const void* b, const void* g, int H, int W) {
   return (H % 4) == 0 && (W % 4) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)g) & 15) == 0);
 }
+static inline unsigned dwt2_fwd_workgroups(int32_t C, int32_t H, int32_t W) {
+  const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
+  return (unsigned)nblocks((int64_t)C * h2 * w2, GS_BLOCK, 512);
+}
 static int dwt2_l1_fwd_launch(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, float* band_sums,
                               float* l1_sum, hipStream_t s, float* clamped_out = nullptr, const uint8_t* patch_mask = nullptr,
-                              int ps = 0, float* patch_sums = nullptr) {
+                              int ps = 0, float* patch_sums = nullptr, float* partials = nullptr) {
   const int h2 = ((H + 1) / 2 + 1) / 2, w2 = ((W + 1) / 2 + 1) / 2;
   // few, long-running workgroups: every workgroup ends in nine atomics on one cache line, and at 1500 workgroups
   // (1080p) their serialisation was 40 % of the kernel (25.9 us at a 4096 cap, 15.1 us at 512)
   const dim3 grid(nblocks((int64_t)C * h2 * w2, GS_BLOCK, 512));
   if (dwt2_fast(pred, gt, clamped_out, H, W))
     hipLaunchKernelGGL(dwt2_l1_fwd_kernel<true>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum, clamped_out,
-                       patch_mask, ps, patch_sums);
-  else if (clamped_out || patch_mask)
+                       patch_mask, ps, patch_sums, partials);
+  else if (clamped_out || patch_mask || partials)
     return GS_E_UNSUPPORTED;  // (H, W multiples of 4 and 16-byte aligned planes only: clamp with torch otherwise)
   else
     hipLaunchKernelGGL(dwt2_l1_fwd_kernel<false>, grid, dim3(GS_BLOCK), 0, s, pred, gt, C, H, W, band_sums, l1_sum,
-                       (float*)nullptr, (const uint8_t*)nullptr, 0, (float*)nullptr);
+                       (float*)nullptr, (const uint8_t*)nullptr, 0, (float*)nullptr, (float*)nullptr);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }
@@ -925,6 +958,21 @@ int gs_l1_dwt2_patch_fwd_clamp(const float* raw, const float* gt, int32_t C, int
   hipStream_t s = (hipStream_t)stream;
   GS_PROF(ST_DWT2_FWD, s);
   return dwt2_l1_fwd_launch(raw, gt, C, H, W, band_sums, l1_sum, s, clamped_out, mask, ps, patch_sums);
+}
+int64_t gs_dwt_partials_count(int32_t C, int32_t H, int32_t W) {
+  return (C <= 0 || H <= 0 || W <= 0) ? 0 : (int64_t)dwt2_fwd_workgroups(C, H, W);
+}
+int gs_l1_dwt2_patch_fwd_clamp_p(const float* raw, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps, const uint8_t* mask,
+                                 float* partials, float* clamped_out, void* stream) {
+  if (!raw || !gt || !partials || !clamped_out) return GS_E_NULL;
+  if (C <= 0 || H <= 0 || W <= 0 || ps < 0) return GS_E_SHAPE;
+  if ((ps > 0) != (mask != nullptr)) return GS_E_NULL;
+  if (ps > 0 && (H < ps || W < ps)) return GS_E_SHAPE;
+  if (ps % 4 != 0) return GS_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_DWT2_FWD, s);
+  float dummy_target = 0.f;  // (never dereferenced with partials given; the kernel only tests l1_sum for NULL)
+  return dwt2_l1_fwd_launch(raw, gt, C, H, W, &dummy_target, &dummy_target, s, clamped_out, mask, ps, &dummy_target, partials);
 }
 int gs_l1_dwt2_patch_bwd(const float* pred, const float* gt, int32_t C, int32_t H, int32_t W, int32_t ps, const uint8_t* mask,
                          const float* l1_coef_dev, const float* coef_dev, const float* patch_coef_dev, float* grad_pred,
@@ -1083,9 +1131,36 @@ int gs_ssim_bwd_uniform(const float* img1, const float* img2, int32_t B, int32_t
 //   sums[16] : 0 l1_sum | 1 ssim_sum | 2..9 band_sums | 10..12 patch_sums | 13 n_selected_patches
 //   out[24]  : 0 loss | 1 base | 2 dwt | 3 patch | 4 dwt_scale | 5 l1 | 6 ssim | 7 running mean before the call |
 //              8 c_l1 | 9 c_ssim | 10..17 c_band[8] | 18..20 c_patch[3]      (dL/d term-sum, for upstream grad 1)
-__global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __restrict__ sums, float* running_mean,
+__global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __restrict__ sums_in, float* running_mean,
                                                              GsLgdwtParams p, float* __restrict__ out,
-                                                             const float* __restrict__ ssim_partials, int n_partials) {
+                                                             const float* __restrict__ ssim_partials, int n_partials,
+                                                             const float* __restrict__ dwt_partials, int n_dwt,
+                                                             const float* __restrict__ l1_partials, int n_l1) {
+  // the per-workgroup partial sums of gs_l1_dwt2_patch_fwd_clamp_p (rows of 12: 8 bands, L1, 3 patch) and of gs_l1_fwd_p,
+  // added in index order by one thread per slot: the same total whatever order the workgroups finished in
+  __shared__ float s_extra[13];
+  if (threadIdx.x < 13) {
+    float t = 0.f;
+    if (threadIdx.x < 12) {
+      for (int w = 0; w < n_dwt; w++) t += dwt_partials[(size_t)w * 12 + threadIdx.x];
+    } else {
+      for (int w = 0; w < n_l1; w++) t += l1_partials[w];
+    }
+    s_extra[threadIdx.x] = t;
+  }
+  __syncthreads();
+  float sums[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) sums[k] = 0.f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) sums[k] = sums_in[k];
+    sums[0] += s_extra[8] + s_extra[12];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sums[2 + k] += s_extra[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) sums[10 + k] += s_extra[9 + k];
+  }
   // SSIM sum = sums[1] + the per-workgroup partials of gs_ssim_fwd_partials, added in a fixed order
   __shared__ float red[16];
   float part = 0.f;
@@ -1129,21 +1204,28 @@ __global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __rest
   out[8] = w_l1 / p.n_pix;
   out[9] = -w_ssim / p.n_pix;
   if (p.reset_sums) {  // every sum has been read (this thread read them all): ready for the next view's accumulation
-    float* z = const_cast<float*>(sums);
+    float* z = const_cast<float*>(sums_in);
     for (int k = 0; k < 13; k++) z[k] = 0.f;
   }
 }
 
-int gs_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_partials, float* running_mean,
-                       const GsLgdwtParams* p, float* out, void* stream) {
+int gs_lgdwt_combine_pp(const float* sums, const float* ssim_partials, int64_t n_partials, const float* dwt_partials,
+                        int64_t n_dwt, const float* l1_partials, int64_t n_l1, float* running_mean, const GsLgdwtParams* p,
+                        float* out, void* stream) {
   if (!sums || !running_mean || !p || !out) return GS_E_NULL;
   if (n_partials < 0 || n_partials > 0x7FFFFFFF || (n_partials > 0 && !ssim_partials)) return GS_E_SHAPE;
+  if (n_dwt < 0 || n_dwt > 65536 || (n_dwt > 0 && !dwt_partials) || n_l1 < 0 || n_l1 > 65536 || (n_l1 > 0 && !l1_partials))
+    return GS_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   hipLaunchKernelGGL(lgdwt_combine_kernel, dim3(1), dim3(1024), 0, s, sums, running_mean, *p, out, ssim_partials,
-                     (int)n_partials);
+                     (int)n_partials, dwt_partials, (int)n_dwt, l1_partials, (int)n_l1);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
+}
+int gs_lgdwt_combine_p(const float* sums, const float* ssim_partials, int64_t n_partials, float* running_mean,
+                       const GsLgdwtParams* p, float* out, void* stream) {
+  return gs_lgdwt_combine_pp(sums, ssim_partials, n_partials, nullptr, 0, nullptr, 0, running_mean, p, out, stream);
 }
 int gs_lgdwt_combine(const float* sums, float* running_mean, const GsLgdwtParams* p, float* out, void* stream) {
   return gs_lgdwt_combine_p(sums, nullptr, 0, running_mean, p, out, stream);

@@ -12,7 +12,7 @@
 
 #define WB 64
 #ifndef GS_FWD_SELECT
-#define GS_FWD_SELECT 1
+#define GS_FWD_SELECT 0
 #endif
 
 // FSGS: the older rasterizer generation of FSGS / DNGaussian (-confidence fork, forward.cu:262-380): out_invdepth

@@ -164,6 +164,11 @@ PROTOTYPES = {
     "patch_dwt_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "ssim_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "ssim_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "dwt_partials_count": (C.c_int64, [_I32, _I32, _I32]),
+    "l1_dwt2_patch_fwd_clamp_p": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "l1_partials_count": (C.c_int64, [_I64]),
+    "l1_fwd_p": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "lgdwt_combine_pp": (C.c_int, [_P, _P, _I64, _P, _I64, _P, _I64, _P, C.POINTER(GsLgdwtParams), _P, _P]),
     "l1_bwd_dev": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P]),
     "l1_dwt2_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "l1_dwt2_fwd_clamp": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),

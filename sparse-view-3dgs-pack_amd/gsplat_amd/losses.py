@@ -268,22 +268,26 @@ class FusedLGDWTLoss(torch.autograd.Function):
         # same 2 x 2 blocks, restricted to the selected patches): two launches less per step
         patch_folded = bool(params.patch_enable and params.dwt_enable and H % 4 == 0 and W % 4 == 0
                             and ctx_ps(params) % 4 == 0)
-        if patch_folded:
+        # Order-independent sums: the kernels store their workgroups' sums (rows of 12 / single floats) and the combine kernel
+        # adds them in index order - with the float atomics of the plain forms the loss, the running-mean DWT scale and with it
+        # every gradient depended in the last bits on which workgroup finished first
+        dwt_part = l1_part = None
+        fast = H % 4 == 0 and W % 4 == 0
+        if patch_folded or (params.dwt_enable and fast and params.clamp):
             img = torch.empty_like(raw)
-            api.call("l1_dwt2_patch_fwd_clamp", raw.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
-                     sums.data_ptr(), sums[2:].data_ptr(), sums[10:].data_ptr(), img.data_ptr(), st)
-        elif params.dwt_enable and H % 4 == 0 and W % 4 == 0:
-            # L1 and the eight band sums from one read of the two images - and the clamp: the kernel clamps the render as it
-            # loads it and leaves the clamped image behind for the other terms (no torch.clamp pass: 9 us at 1080p)
-            img = torch.empty_like(raw)
-            api.call("l1_dwt2_fwd_clamp", raw.data_ptr(), gt.data_ptr(), Cc, H, W, sums.data_ptr(), sums[2:].data_ptr(),
-                     img.data_ptr(), st)
+            dwt_part = torch.empty((params.n_dwt_partials * 12,), dtype=torch.float32, device=raw.device)
+            api.call("l1_dwt2_patch_fwd_clamp_p", raw.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params) if patch_folded else 0,
+                     mask.data_ptr() if patch_folded else None, dwt_part.data_ptr(), img.data_ptr(), st)
         elif params.dwt_enable:
-            img = raw.clamp(0, 1)
+            img = raw.clamp(0, 1) if params.clamp else raw
             api.call("l1_dwt2_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, sums.data_ptr(), sums[2:].data_ptr(), st)
         else:
             img = raw.clamp(0, 1) if params.clamp else raw
-            api.call("l1_fwd", img.data_ptr(), gt.data_ptr(), img.numel(), sums.data_ptr(), st)
+            if img.numel() % 4 == 0:
+                l1_part = torch.empty((params.n_l1_partials,), dtype=torch.float32, device=raw.device)
+                api.call("l1_fwd_p", img.data_ptr(), gt.data_ptr(), img.numel(), l1_part.data_ptr(), st)
+            else:
+                api.call("l1_fwd", img.data_ptr(), gt.data_ptr(), img.numel(), sums.data_ptr(), st)
         # SSIM sum as per-workgroup partials (no atomics; lgdwt_combine_p adds them up in a fixed order)
         partials = torch.empty((params.n_ssim_partials,), dtype=torch.float32, device=raw.device)
         api.call("ssim_fwd_partials", img.data_ptr(), gt.data_ptr(), 1, Cc, H, W, 0.01 ** 2, 0.03 ** 2,
@@ -292,8 +296,10 @@ class FusedLGDWTLoss(torch.autograd.Function):
             api.call("patch_dwt_fwd", img.data_ptr(), gt.data_ptr(), Cc, H, W, ctx_ps(params), mask.data_ptr(),
                      sums[10:].data_ptr(), st)
         out = torch.empty((24,), dtype=torch.float32, device=raw.device)
-        api.call("lgdwt_combine_p", sums.data_ptr(), partials.data_ptr(), partials.numel(), running_mean.data_ptr(),
-                 C.byref(params.c), out.data_ptr(), st)
+        api.call("lgdwt_combine_pp", sums.data_ptr(), partials.data_ptr(), partials.numel(),
+                 None if dwt_part is None else dwt_part.data_ptr(), 0 if dwt_part is None else dwt_part.numel() // 12,
+                 None if l1_part is None else l1_part.data_ptr(), 0 if l1_part is None else l1_part.numel(),
+                 running_mean.data_ptr(), C.byref(params.c), out.data_ptr(), st)
         ctx.ops, ctx.params, ctx.patch_folded = ops, params, patch_folded
         ctx.save_for_backward(raw, img, gt, mask, d1, d2, d3, out)
         ctx.mark_non_differentiable(out)
@@ -365,6 +371,8 @@ class _FusedParams:
         self.c = c
         self.patch_size = crit.patch_size
         self.n_ssim_partials = int(crit.ops.api.raw("ssim_partials_count")(1, Cc, H, W))
+        self.n_dwt_partials = int(crit.ops.api.raw("dwt_partials_count")(Cc, H, W))
+        self.n_l1_partials = int(crit.ops.api.raw("l1_partials_count")(Cc * H * W))
 
 
 class LGDWTCriterion:
