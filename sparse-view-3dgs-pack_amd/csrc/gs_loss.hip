@@ -1137,16 +1137,21 @@ __global__ void __launch_bounds__(1024) lgdwt_combine_kernel(const float* __rest
                                                              const float* __restrict__ dwt_partials, int n_dwt,
                                                              const float* __restrict__ l1_partials, int n_l1) {
   // the per-workgroup partial sums of gs_l1_dwt2_patch_fwd_clamp_p (rows of 12: 8 bands, L1, 3 patch) and of gs_l1_fwd_p,
-  // added in index order by one thread per slot: the same total whatever order the workgroups finished in
+  // added in a fixed order (one wave per slot): the same total whatever order the workgroups finished in
   __shared__ float s_extra[13];
-  if (threadIdx.x < 13) {
-    float t = 0.f;
-    if (threadIdx.x < 12) {
-      for (int w = 0; w < n_dwt; w++) t += dwt_partials[(size_t)w * 12 + threadIdx.x];
-    } else {
-      for (int w = 0; w < n_l1; w++) t += l1_partials[w];
+  {  // wave k (of the 16) owns slot k: its lanes add strided partials, then a fixed shuffle tree - the same shape every run
+    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (slot < 13) {
+      float t = 0.f;
+      if (slot < 12) {
+        for (int w = lane; w < n_dwt; w += 64) t += dwt_partials[(size_t)w * 12 + slot];
+      } else {
+        for (int w = lane; w < n_l1; w += 64) t += l1_partials[w];
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) t += __shfl_down(t, off, 64);
+      if (lane == 0) s_extra[slot] = t;
     }
-    s_extra[threadIdx.x] = t;
   }
   __syncthreads();
   float sums[16];

@@ -307,10 +307,12 @@ def test_two_runs_of_the_train_step_are_the_same_bits(hip):
     for rep in range(2):
         tr = make(hip, True)
         tr.depth_limit = "deferred"
-        losses = [float(tr.step(k)) for k in range(24)]
+        losses = [tr.step(k) for k in range(24)]
         tr.sync()
         torch.cuda.synchronize()
-        runs.append((state(tr), losses))
+        # (read AFTER the verdicts are in: a step whose depth limits or binning capacity failed is repeated and its loss
+        #  tensor overwritten in place - whether that happens depends on the backend's capacity hints, not on the model)
+        runs.append((state(tr), [float(x) for x in losses]))
     for k in runs[0][0]:
         assert torch.equal(runs[0][0][k], runs[1][0][k]), (k, float((runs[0][0][k] - runs[1][0][k]).abs().max()))
     assert runs[0][1] == runs[1][1]
