@@ -81,6 +81,11 @@ SCENES = {
 }
 
 
+# The model keeps its rows in Morton order of the Gaussians' centres (GaussianModelLite(spatial_order=True): a permutation of
+# the same scene, applied at construction and after every densification); GS_BENCH_SPATIAL_ORDER=0 = rows as generated.
+SPATIAL_ORDER = os.environ.get("GS_BENCH_SPATIAL_ORDER", "1") != "0"
+
+
 def build_workload(cfg, device, rank, world, seed=0, scene_kind="trained_like", gts=None):
     import diff_gaussian_rasterization as dgr
     import lgdwt_loss
@@ -112,7 +117,7 @@ def build_workload(cfg, device, rank, world, seed=0, scene_kind="trained_like", 
         from gsplat_amd.trainer import NirCriterion, TrainerNIR
         g = torch.Generator().manual_seed(seed + 2)
         nirs = [None if x is None else (torch.round(torch.rand((1, H, W), generator=g) * 255.0) / 255.0).to(device) for x in gts]
-        model = GaussianModelLite(scene, device, api=hip_api_(), with_nir=True)
+        model = GaussianModelLite(scene, device, api=hip_api_(), with_nir=True, spatial_order=SPATIAL_ORDER)
         # the multispectral step on the fused machinery (GS_BENCH_NIR_FUSED=0: round-3 form - un-fused criterion and optimizer tail)
         nir_fused = os.environ.get("GS_BENCH_NIR_FUSED", "1") != "0"
         rgb_crit, masks = None, None
@@ -123,7 +128,7 @@ def build_workload(cfg, device, rank, world, seed=0, scene_kind="trained_like", 
         tr = TrainerNIR(model, cams, gts, nirs, NirCriterion(LossOps(hip_api_()), rgb_criterion=rgb_crit, fused=nir_fused),
                         dgr.GaussianRasterizationSettings, bg, rank=rank, world_size=world, masks=masks)
         return tr, scene, cams, gts
-    model = GaussianModelLite(scene, device, api=hip_api_())
+    model = GaussianModelLite(scene, device, api=hip_api_(), spatial_order=SPATIAL_ORDER)
     crit = lgdwt_loss.criterion(dwt_enable=dwt, patch_dwt_enable=patch)
     masks = None
     if patch:  # ELF / patch selection depends on the ground truth only: cached per camera
@@ -246,11 +251,11 @@ def counters_match(d, P, R):
     return None
 
 
-def valu_roofline(kernel, ms_per_launch, P=None, R=None):
+def valu_roofline(kernel, ms_per_launch, P=None, R=None, counters="sq_insts.json"):
     """VALU-issue fraction of a blend kernel: wave-instructions per launch (SQ_INSTS_VALU of the committed SQ-counter
     profile, profiles/sq_insts.json: {"tag": ..., "<kernel>": insts per launch}) / this run's launch duration / the
     MEASURED plain-f32 issue ceiling."""
-    f = os.path.join(ROOT, "profiles", "sq_insts.json")
+    f = os.path.join(ROOT, "profiles", counters)
     try:
         d = json.load(open(f))
         insts = float(d[kernel])
@@ -268,8 +273,8 @@ def valu_roofline(kernel, ms_per_launch, P=None, R=None):
             "mix_ceiling": ceil["blendmix"],
             "mix_ceiling_note": "measured rate of a stream of 11 plain f32 ops per v_exp_f32 (the alpha test's shape): a "
                                 "transcendental costs ~7 plain issue slots, so a kernel with them cannot reach `peak`",
-            "insts_from": "profiles/sq_insts.json (tag %s): SQ_INSTS_VALU per launch on the C3 workload; duration measured "
-                          "in this run" % d.get("tag", "?")}
+            "insts_from": "profiles/%s (tag %s): SQ_INSTS_VALU per launch on the %s; duration measured "
+                          "in this run" % (counters, d.get("tag", "?"), d.get("scene", "C3 workload"))}
 
 
 def main():
@@ -312,7 +317,9 @@ def main():
     api = hip_api()
     P, W, H, dwt, patch, desc = CONFIGS[args.config]
     t_setup = time.perf_counter()
-    tr, scene, cams, gts = build_workload(args.config, device, rank, world)
+    # (developer switch for profiles of SURVEY 8d's other inputs - profiles/collect.sh: the driver's line is the default scene)
+    main_scene = os.environ.get("GS_BENCH_SCENE", "trained_like")
+    tr, scene, cams, gts = build_workload(args.config, device, rank, world, scene_kind=main_scene)
     torch.cuda.synchronize()
     log("workload %s built in %.1f s" % (args.config, time.perf_counter() - t_setup))
 
@@ -363,17 +370,28 @@ def main():
     prof, prof_timed, dom_stage = {}, {}, os.environ.get("GS_BENCH_DOMINANT", "")
     prof_alone = None
 
-    def profile_all_stages(nsteps):
+    def profile_all_stages(nsteps, trainer=None, k0=None):
         nonlocal k
+        t_ = trainer if trainer is not None else tr
         api.call("profile_reset")
         api.call("profile_only", -1)
         api.call("profile_enable", 1)
-        for _ in range(nsteps):
-            tr.step(k)
-            k += 1
+        for j in range(nsteps):
+            if k0 is None:
+                t_.step(k)
+                k += 1
+            else:
+                t_.step(k0 + j)
+        t_.sync()
         barrier()
         api.call("profile_enable", 0)
         return read_profile(api)
+
+    def stage_ms(pr):
+        pr = dict(pr)
+        if "sort_depth" in pr and "sort" in pr:
+            pr["sort"] = (pr["sort"][0] + pr.pop("sort_depth")[0], pr["sort"][1])
+        return {n: round(ms / cnt, 5) for n, (ms, cnt) in pr.items()}
 
     if not args.no_stage_timers and not dom_stage:
         pre = profile_all_stages(min(args.steps, 4))
@@ -387,6 +405,49 @@ def main():
         tr.step(k)
         k += 1
     barrier()
+    # N > 1: which form of the gradient exchange runs the timed region - the dense sharded one (reduce-scatter, Adam on 1/N,
+    # all-gather: 244 B per Gaussian whatever the views saw) or the visibility-sparse one (only the rows of Gaussians some
+    # rank's view emitted instances for; one host read per step).  Which is faster depends on the scene and on the links:
+    # both are timed over a few untimed steps (GS_BENCH_EXCHANGE = auto, default), every rank takes the slower rank's
+    # times and so the same decision; dense / sparse force a form.  GS_SPARSE_EXCHANGE=1 (Trainer's own switch) = sparse.
+    exchange_trial = None
+    ex_mode = os.environ.get("GS_BENCH_EXCHANGE", "auto")
+    if world > 1 and hasattr(tr, "sparse_exchange") and not tr.sparse_exchange and ex_mode in ("auto", "sparse"):
+        def time_form(sparse, n=6):
+            nonlocal k
+            tr.sparse_exchange = sparse
+            for _ in range(2):
+                tr.step(k)
+                k += 1
+            tr.sync()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                tr.step(k)
+                k += 1
+            tr.sync()
+            barrier()
+            tt = torch.tensor([(time.perf_counter() - t1) / n * 1e3], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt[0])
+        if ex_mode == "auto":
+            # sparse first: it keeps every replica's moments whole, the sharded form after it may let the other shards' go stale
+            exchange_trial = {"sparse_ms_per_step": time_form(True), "dense_sharded_ms_per_step": time_form(False)}
+            exchange_trial["chosen"] = "sparse" if exchange_trial["sparse_ms_per_step"] < exchange_trial["dense_sharded_ms_per_step"] \
+                else "dense"
+            log("exchange form: sparse %.3f ms, dense %.3f ms per step -> %s" % (
+                exchange_trial["sparse_ms_per_step"], exchange_trial["dense_sharded_ms_per_step"], exchange_trial["chosen"]))
+        if ex_mode == "sparse" or exchange_trial["chosen"] == "sparse":
+            tr.sparse_exchange = False
+            tr.gather_optimizer_state()     # (the sharded steps of the trial left each rank with current moments of its shard only)
+            tr.sparse_exchange = True
+        else:
+            tr.sparse_exchange = False
+        for _ in range(2):
+            tr.step(k)
+            k += 1
+        tr.sync()
+        barrier()
     if graphed is not None:
         if graph_mode == "auto":
             t1 = time.perf_counter()
@@ -451,6 +512,12 @@ def main():
     gc.enable()
     dl1 = dict(_hb0().depth_limit_stats)
     R_timed = int(_hb0()._pinned[0]) if _hb0()._pinned is not None else 0
+    # how many 256-row blocks of the model are dormant (all Adam moments +0: FlatAdam.dormant_flags) after the timed region
+    dormant_info = None
+    opt_ = getattr(tr.model, "optimizer", None)
+    if world == 1 and getattr(opt_, "USE_DORMANT", False) and hasattr(opt_, "dormant_flags"):
+        fl = opt_.dormant_flags()
+        dormant_info = {"blocks": int(fl.numel()), "dormant": int(fl.sum())}
     if depth_limit and _hb0().last_deferred_num_rendered is not None:  # (deferred forwards report their count with the verdict)
         R_timed = int(_hb0().last_deferred_num_rendered)
     if not args.no_stage_timers:
@@ -493,7 +560,8 @@ def main():
                 k += 1
             barrier()
             dref = (time.perf_counter() - t1) / nref
-            ref_lists = {"ms_per_step": dref * 1e3, "views_per_s": 1.0 / dref, "steps": nref,
+            ref_stages = None if args.no_stage_timers else stage_ms(profile_all_stages(min(nref, 6)))
+            ref_lists = {"ms_per_step": dref * 1e3, "views_per_s": 1.0 / dref, "steps": nref, "stages_ms_per_launch": ref_stages,
                          "num_rendered_last_view": int(be._pinned[0]) if be._pinned is not None else None,
                          "what": "the identical step with GsView.tile_cull = 0: the instance lists (num_rendered, point_list, "
                                  "ranges) are the reference's, bit for bit; untimed by the driver"}
@@ -635,6 +703,15 @@ def main():
                  "num_rendered_last_view": int(be2.last_deferred_num_rendered if (depth_limit and be2.last_deferred_num_rendered
                                                                                    is not None) else be2._pinned[0]),
                  "limited_views": d1["used"] - d0["used"], "fallbacks": d1["failed"] - d0["failed"]}
+            if not args.no_stage_timers:   # HIP-event stage times of the same steps (untimed pass, every kernel bracketed)
+                e["stages_ms_per_launch"] = stage_ms(profile_all_stages(min(nx, 6), tr2, kk))
+                kk += min(nx, 6)
+                # (the blend kernels against the measured VALU issue ceiling, where profiles/ holds this scene's counts)
+                vf = {kn: valu_roofline(kn, e["stages_ms_per_launch"][kn], P, e["num_rendered_last_view"],
+                                        counters="sq_insts_%s.json" % kind)
+                      for kn in ("render_bwd", "render_fwd") if kn in e["stages_ms_per_launch"]}
+                if any(v is not None for v in vf.values()):
+                    e["blend_kernels_valu"] = vf
             if depth_limit:   # and with the full (culled) lists
                 tr2.depth_limit = None
                 for _ in range(3):
@@ -677,6 +754,7 @@ def main():
                                      "scatter, dense gated Adam)" if lx else
                                      ("sharded (reduce-scatter, Adam on 1/N, all-gather)" if tr.sharded_optimizer else
                                       "chunked all-reduce, Adam behind the chunks")),
+                   "exchange_trial": exchange_trial,
                    "exchange_bytes_per_gpu": nbytes,
                    "exchange_bytes_per_gpu_dense": dense_bytes,
                    "exchange_bytes_per_gpu_sparse": None if not lx else int(lx["sparse_bytes"]),
@@ -777,8 +855,11 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "gaussians": P, "image": "%dx%d" % (W, H), "sh_degree": 3,
-                       "scene": "trained-like (SURVEY 8d), seed 0", "cameras_per_step": world,
+            "config": {"workload": desc, "gaussians": P, "image": "%dx%d" % (W, H),
+                       "scene": SCENES[main_scene]["what"], "sh_degree": SCENES[main_scene]["sh_degree"], "cameras_per_step": world,
+                       "dormant_blocks": dormant_info,
+                       "row_order": ("Morton order of the centres (GaussianModelLite(spatial_order=True): a permutation of the "
+                                     "generated scene; GS_BENCH_SPATIAL_ORDER=0 = as generated)" if SPATIAL_ORDER else "as generated"),
                        # which instance lists the timed step renders from, and the same step on the reference's own lists
                        "lists": ("depth-limited (exact, verified per view: csrc/gs_tilecull.h, tests/test_gpu_fullsize.py::"
                                  "test_c3_benched_step_is_the_unlimited_run)" if depth_limit else
@@ -793,8 +874,11 @@ def main():
                            "(the backward kernel writes gradients, statistic increments and flag into the exchange buffer)"
                            if world > 1 else ("inside the backward's per-Gaussian kernel (gs_backward_step)"
                                               if "preprocess_bwd_step" in stages else "fused HIP kernel over the flat buffer")),
-                       "parallelism": ("camera-sharded dp%d, reduce-scatter of 59 f32/Gaussian + Adam on 1/N of the rows + "
-                                       "all-gather of the parameters (GS_SHARDED_ADAM=1)" % world)
+                       "parallelism": ("camera-sharded dp%d, visibility-sparse exchange: mask all-reduce, the union's gradient rows "
+                                       "packed and all-reduced, dense gated Adam on every replica" % world)
+                       if getattr(tr, "sparse_exchange", False) and world > 1 else
+                       ("camera-sharded dp%d, reduce-scatter of 59 f32/Gaussian + Adam on 1/N of the rows + "
+                        "all-gather of the parameters (GS_SHARDED_ADAM=1)" % world)
                        if getattr(tr, "sharded_optimizer", False) and world > 1 else
                        "camera-sharded dp%d, one all-reduce of 61 f32/Gaussian (59 gradients + 2 statistic increments)" % world},
             "roofline": roofline,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 4
+#define GS_ABI_VERSION 5
 
 /* error codes (negative = caller error) */
 #define GS_OK 0
@@ -337,7 +337,16 @@ typedef struct GsStepState {
    * instances), 0 where every one of its gradient floats was written as zero.  The union of the ranks' masks is what a
    * sparse exchange has to move (gsplat_amd.trainer: pack the union's rows, all-reduce, scatter back). */
   uint8_t* grad_mask;
+  /* Adam-inside-the-backward form, optional: one byte per block of GS_STEP_BLOCK (256) consecutive Gaussians, 1 = "BOTH
+   * Adam moments of EVERY row of every Gaussian of the block are +0" (the caller's claim; gsplat_amd.trainer derives it
+   * from the moments themselves).  The zero-gradient update of such a block changes no bit of parameters or moments
+   * (m' = v' = +0, p' = p - lr * (0 / eps) = p; needs eps > 0), so the kernels skip its parameter and moment traffic;
+   * a block in which a Gaussian receives a gradient gets its byte cleared by the kernel that writes its moments.
+   * View statistics are kept for every Gaussian as without it.  With the model's rows in spatial order (neighbours in
+   * memory = neighbours in space) the Gaussians no camera reaches fill whole blocks. */
+  uint8_t* dormant;
 } GsStepState;
+#define GS_STEP_BLOCK 256
 int gs_backward_step(const GsView* view, const GsGaussians* g, const int32_t* radii,
                      const GsScratch* scratch, int64_t num_rendered, const float* dL_dcolor,
                      const float* dL_dinvdepth, const GsStepState* st, void* workspace,

@@ -24,6 +24,11 @@ for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY 
   i=$((i+1))
   rocprofv3 --pmc $c --output-format csv -d $OUT/sq$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > /dev/null 2> $OUT/bench_sq$i.err
 done
+# SURVEY 8(d)'s init-like scene as the bench's main scene: kernel trace + the blend kernels' instruction counts
+export GS_BENCH_SCENE=init_like
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_init_like -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_trace_init_like.json 2> $OUT/bench_trace_init_like.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq_init_like -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > /dev/null 2> $OUT/bench_sq_init_like.err
+unset GS_BENCH_SCENE
 python3 $R/profiles/summarize.py $OUT $TAG $SUM > $SUM/summarize.log 2>&1 || tail -5 $SUM/summarize.log
 cp $OUT/bench_trace.json $SUM/${TAG}_bench_under_rocprof.json
 ls -la $SUM

@@ -172,3 +172,42 @@ if sq:
                     sq_insts[st + "_valu_active_share_under_profiler"] = m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles
     json.dump(sq_insts, open(os.path.join(here, "sq_insts.json"), "w"), indent=1)
     print(open(os.path.join(here, "%s_sq_counters.csv" % tag)).read())
+
+
+# SURVEY 8(d)'s other inputs (collect.sh: GS_BENCH_SCENE=<kind> passes) -> <tag>_<kind>_kernel_stats.csv, sq_insts_<kind>.json
+for kind in ("init_like",):
+    st_files = glob.glob(os.path.join(src, "trace_" + kind, "*", "*_kernel_stats.csv"))
+    if not st_files:
+        continue
+    shutil.copyfile(st_files[0], os.path.join(here, "%s_%s_rocprofv3_kernel_stats_full.csv" % (tag, kind)))
+    with open(os.path.join(here, "%s_%s_kernel_stats.csv" % (tag, kind)), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in list(csv.DictReader(open(st_files[0])))[:30]:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    ident = {"tag": tag, "source_id": source_id(os.path.dirname(script_dir)), "scene": kind}
+    try:
+        line = [x for x in open(os.path.join(src, "bench_trace_%s.json" % kind)).read().splitlines() if x.startswith("{")][-1]
+        j = json.loads(line)
+        ident["P"], ident["R"] = j["config"]["gaussians"], j["config"]["num_rendered_last_view"]
+        shutil.copyfile(os.path.join(src, "bench_trace_%s.json" % kind), os.path.join(here, "%s_%s_bench_under_rocprof.json" % (tag, kind)))
+    except Exception as e:   # noqa: BLE001
+        ident["identity_error"] = repr(e)
+    sqk = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, "sq_" + kind, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            sqk[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    ident["launches_counted"] = {}
+    for stn, kn in (("render_bwd", "render_bwd_wave_kernel"), ("render_fwd", "render_fwd_wave_kernel")):
+        v = sqk.get(kn, {}).get("SQ_INSTS_VALU", [])
+        if v:
+            ident[stn] = sum(v) / len(v)
+            ident["launches_counted"][stn] = len(v)
+            wv = sqk[kn].get("SQ_WAVES", [])
+            sa = sqk[kn].get("SQ_INSTS_SALU", [])
+            if wv and sum(wv):
+                ident[stn + "_valu_per_wave"] = sum(v) / sum(wv) * len(wv) / len(v)
+                if sa:
+                    ident[stn + "_salu_per_wave"] = sum(sa) / sum(wv) * len(wv) / len(sa)
+    json.dump(ident, open(os.path.join(here, "sq_insts_%s.json" % kind), "w"), indent=1)
+    print(kind, json.dumps(ident))

@@ -36,7 +36,9 @@ struct GeomHeader {
   uint32_t region_mode;   // 1: the lists of this view were built by region binning (gs_regionbin.hip), 0: by the LSD path
   uint32_t step_tag;      // word 8: GsScratch.step_tag as gs_forward_status found it
   uint32_t pad[55];       // pad[0] = word 9: GS_STATUS_CHECK over (step_tag, num_rendered, overflow, trunc_failed)
+                          // pad[HDR_SIDE_CURSOR]: next Gaussian block of step_uninstanced_kernel (zeroed with the header)
 };
+#define HDR_SIDE_CURSOR 1
 static_assert(sizeof(GeomHeader) == 256, "header is one 256-B block");
 
 // 64-byte per-Gaussian record written by the forward preprocess kernel.

@@ -150,10 +150,18 @@ GS_DEV void cov2d_common(V3 mean, float focal_x, float focal_y, float tan_fovx, 
 // GsGaussians.raw_activations: the model's activations applied where the parameters are read, in the arithmetic of
 // act_fwd_kernel (gs_model.hip) - exp, F.normalize (v / max(|v|, 1e-12)), sigmoid - so that both forms give the same bits.
 // (raw rows live in the flat parameter buffer, where the rotation segment is 16-byte aligned only for P % 4 == 0: scalar loads)
-GS_DEV V3 load_scales(const float* p, int idx, int raw) {
-  const V3 s = {p[3 * (size_t)idx], p[3 * (size_t)idx + 1], p[3 * (size_t)idx + 2]};
+GS_DEV V3 activate_scales(V3 s, int raw) {
   if (!raw) return s;
   return {expf(s.x), expf(s.y), expf(s.z)};
+}
+GS_DEV V4 activate_rotation(V4 q, int raw) {
+  if (!raw) return q;
+  const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+  return {q.x / n, q.y / n, q.z / n, q.w / n};
+}
+GS_DEV V3 load_scales(const float* p, int idx, int raw) {
+  const V3 s = {p[3 * (size_t)idx], p[3 * (size_t)idx + 1], p[3 * (size_t)idx + 2]};
+  return activate_scales(s, raw);
 }
 GS_DEV V4 load_rotation(const float* p, int idx, int raw) {
   if (!raw) {
@@ -161,9 +169,7 @@ GS_DEV V4 load_rotation(const float* p, int idx, int raw) {
     return {q4.x, q4.y, q4.z, q4.w};
   }
   const float* q = p + 4 * (size_t)idx;
-  const float x = q[0], y = q[1], z = q[2], w = q[3];
-  const float n = fmaxf(sqrtf(x * x + y * y + z * z + w * w), 1e-12f);
-  return {x / n, y / n, z / n, w / n};
+  return activate_rotation({q[0], q[1], q[2], q[3]}, raw);
 }
 // the 4th blended channel of the multispectral model: sigmoid(raw albedo) * clamp(gain, 0.1, 10)
 // (mult-dwtgs/gaussian_renderer/__init__.py:166-169; torch.clamp keeps the gradient on [min, max])
@@ -173,10 +179,8 @@ GS_DEV float load_extra(const float* p, const float* gain, int idx, int raw) {
   if (!raw || !gain) return x;
   return (1.0f / (1.0f + expf(-x))) * clamp_gain(*gain);
 }
-GS_DEV float load_opacity(const float* p, int idx, int raw) {
-  const float o = p[idx];
-  return raw ? 1.0f / (1.0f + expf(-o)) : o;
-}
+GS_DEV float activate_opacity(float o, int raw) { return raw ? 1.0f / (1.0f + expf(-o)) : o; }
+GS_DEV float load_opacity(const float* p, int idx, int raw) { return activate_opacity(p[idx], raw); }
 
 // auxiliary.h:21-38
 #define SH_C0 0.28209479177387814f

@@ -66,34 +66,110 @@ static inline size_t preprocess_limit_lds_floats(const PreprocessArgs& a) {
   return want <= GS_LIMIT_LDS_MAX_FLOATS ? want : 0;
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs a, GeomView g, int lds_floats) {
+__global__ void __launch_bounds__(GS_BLOCK, 5) preprocess_fwd_kernel(PreprocessArgs a, GeomView g, int lds_floats) {
   const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
   uint32_t tiles = 0;
   const int T = a.grid_x * a.grid_y;
   // region binning: up to four bucket counters waiting to be bumped (selects, not an indexed array: that would live in
-  // scratch memory), the slots they returned, and this Gaussian's bucket entry
-  int p0 = 0, p1 = 0, p2 = 0, p3 = 0, n_pend = 0;
-  uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu, dbits = 0;
+  // scratch memory), what their atomics returned, and this Gaussian's bucket entry.
+  // The atomics are issued per WAVE where that pays: lanes that bump the same counter form a group, the group's first lane
+  // adds the group's size and every member takes base + its rank (`ld` / `rk`: leader lane and rank of the four pending
+  // counters, a byte each).  With the model's rows in spatial order (GaussianModelLite.spatial_order) a wave's Gaussians
+  // share a handful of regions - tens of lanes per returning atomic instead of one; with rows in random order the first
+  // GS_PP_GROUPS groups are tried (cheap: scalar ballots) and the other lanes bump on their own as before.  The order of the
+  // entries inside a bucket is whatever the atomics make it - region_bin_kernel sorts each bucket by (depth, index).
+#ifndef GS_PP_GROUPS
+#define GS_PP_GROUPS 3
+#endif
+  // (registers: the four pending regions live in two words - 16 bits each, the glue keeps region binning to images with at
+  //  most 65 535 regions -, leader lanes and ranks in one word each, 6 bits per counter; `ld` bits 24.. = how many were bumped)
+  uint32_t p01 = 0, p23 = 0;
+  int n_pend = 0;
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, dbits = 0, ld = 0, rk = 0;
+  const int wlane = threadIdx.x & 63;
+  const unsigned long long lanes_below = (1ull << wlane) - 1ull;
+  auto pend_region = [&](int k) -> int { return (int)(((k < 2 ? p01 : p23) >> (16 * (k & 1))) & 0xFFFFu); };
+  auto bump_one = [&](int k, uint32_t& sk) {
+    const bool has = n_pend > k;
+    const int pk = pend_region(k);
+    unsigned long long todo = __ballot(has);
+    int lead = wlane;
+    uint32_t rank = 0, cnt = 1;
+    for (int it = 0; it < GS_PP_GROUPS && todo != 0ull; it++) {
+      const int L = __builtin_ctzll(todo);
+      const int r = __builtin_amdgcn_readlane(pk, L);
+      const bool in = has && pk == r;
+      const unsigned long long grp = __ballot(in);
+      if (in) {
+        lead = L;
+        rank = (uint32_t)__popcll(grp & lanes_below);
+        cnt = (uint32_t)__popcll(grp);
+      }
+      todo &= ~grp;
+    }
+    if (has) {
+      if (lead == wlane) sk = atomicAdd(&a.region_count[(size_t)pk * RG_COUNT_STRIDE], cnt);
+      ld |= (uint32_t)lead << (6 * k);
+      rk |= rank << (6 * k);
+    }
+  };
   auto bump = [&]() {
-    if (n_pend > 0) s0 = atomicAdd(&a.region_count[(size_t)p0 * RG_COUNT_STRIDE], 1u);
-    if (n_pend > 1) s1 = atomicAdd(&a.region_count[(size_t)p1 * RG_COUNT_STRIDE], 1u);
-    if (n_pend > 2) s2 = atomicAdd(&a.region_count[(size_t)p2 * RG_COUNT_STRIDE], 1u);
-    if (n_pend > 3) s3 = atomicAdd(&a.region_count[(size_t)p3 * RG_COUNT_STRIDE], 1u);
+    bump_one(0, s0);
+    bump_one(1, s1);
+    bump_one(2, s2);
+    bump_one(3, s3);
+    ld |= (uint32_t)n_pend << 24;
     n_pend = 0;
+  };
+  // (every lane that bumped collects, together with its group's leader: the leader's lane is read by a shuffle)
+  auto collect_one = [&](int k, uint32_t sk, uint2 entry) {
+    const uint32_t base = (uint32_t)__shfl((int)sk, (int)((ld >> (6 * k)) & 63u), 64);
+    if ((int)(ld >> 24) > k) {
+      const uint32_t slot = base + ((rk >> (6 * k)) & 63u);
+      if (slot < a.region_cap) a.region_bucket[(size_t)pend_region(k) * a.region_cap + slot] = entry;
+    }
   };
   auto collect = [&]() {
     const uint2 entry = make_uint2(dbits, (uint32_t)idx);
-    if (s0 < a.region_cap) a.region_bucket[(size_t)p0 * a.region_cap + s0] = entry;
-    if (s1 < a.region_cap) a.region_bucket[(size_t)p1 * a.region_cap + s1] = entry;
-    if (s2 < a.region_cap) a.region_bucket[(size_t)p2 * a.region_cap + s2] = entry;
-    if (s3 < a.region_cap) a.region_bucket[(size_t)p3 * a.region_cap + s3] = entry;
-    s0 = s1 = s2 = s3 = 0xFFFFFFFFu;
+    collect_one(0, s0, entry);
+    collect_one(1, s1, entry);
+    collect_one(2, s2, entry);
+    collect_one(3, s3, entry);
+    ld = rk = 0;
   };
+  const int lidx = min(idx, a.P - 1);  // (the last workgroup's spare lanes load the last Gaussian's rows and drop them)
+  // Every small row of this Gaussian is requested at once, ahead of the frustum test and of the limit table's copy:
+  // five dependent round trips per wave (table -> mean -> scale, rotation -> opacity -> SH row) become two, for 32 B
+  // more per Gaussian behind the camera.
+  // The camera (two 4 x 4 matrices, the camera centre): the same 35 floats for every lane.  Read through constant-address-
+  // space pointers they become scalar loads into SGPRs, issued here with everything else - as plain global pointers the
+  // compiler reads them with vector loads where they are first used: two more dependent round trips per wave.
+  typedef const __attribute__((address_space(4))) float* GsConstFloatPtr;
+  float vm[16], pm[16], cam[3];
+  {
+    const GsConstFloatPtr vmp = (GsConstFloatPtr)(uintptr_t)a.viewmatrix, pmp = (GsConstFloatPtr)(uintptr_t)a.projmatrix;
+    const GsConstFloatPtr cp = (GsConstFloatPtr)(uintptr_t)a.campos;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { vm[k] = vmp[k]; pm[k] = pmp[k]; }
+    cam[0] = cp[0]; cam[1] = cp[1]; cam[2] = cp[2];
+  }
+  const bool own_cov = a.cov3D_precomp == nullptr;
+  // (no branch around these loads - the merge of its two arms would wait for them -: with a precomputed covariance the two
+  // pointers aim at that row instead and the values are dropped)
+  const float* sc_p = own_cov ? a.scales + 3 * (size_t)lidx : a.cov3D_precomp + 6 * (size_t)lidx;
+  const float* rq_p = own_cov ? a.rotations + 4 * (size_t)lidx : a.cov3D_precomp + 6 * (size_t)lidx;
+  float op_in = a.opacities[lidx];
+  V3 p_orig = {a.means3D[3 * (size_t)lidx], a.means3D[3 * (size_t)lidx + 1], a.means3D[3 * (size_t)lidx + 2]};
+  V3 sc_in = {sc_p[0], sc_p[1], sc_p[2]};
+  V4 rq_in = {rq_p[0], rq_p[1], rq_p[2], rq_p[3]};
   if (lds_floats) {  // the tail of the limit buffer (segments), or all of it
     const float* src = a.tile_depth_limit + (GS_LIMIT_TILES_IN_LDS ? 0 : T);
     for (int i = threadIdx.x; i < lds_floats; i += GS_BLOCK) s_limit[i] = src[i];
     __syncthreads();
   }
+  // (keeps the compiler from sinking these loads to their uses, behind the frustum branch)
+  asm volatile("" : "+v"(op_in), "+v"(sc_in.x), "+v"(sc_in.y), "+v"(sc_in.z), "+v"(rq_in.x), "+v"(rq_in.y), "+v"(rq_in.z),
+               "+v"(rq_in.w));
   const GsLdsFloatPtr lds_seg = (GsLdsFloatPtr)s_limit + (GS_LIMIT_TILES_IN_LDS ? T : 0);
   if (idx < a.P) {
     Splat sp;
@@ -106,11 +182,10 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
     float cov3D[6] = {0, 0, 0, 0, 0, 0};
     bool write_cov = false;
     do {
-      V3 p_orig = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
       // in_frustum, auxiliary.h:151-176
-      V3 p_view = xform4x3(p_orig, a.viewmatrix);
+      V3 p_view = xform4x3(p_orig, vm);
       if (p_view.z <= 0.2f) break;
-      V4 p_hom = xform4x4(p_orig, a.projmatrix);
+      V4 p_hom = xform4x4(p_orig, pm);
       float p_w = 1.0f / (p_hom.w + 0.0000001f);
       V3 p_proj = {p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w};
 
@@ -119,8 +194,8 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
         for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[(size_t)idx * 6 + k];
       } else {
         // computeCov3D, forward.cu:114-148
-        const V3 sc = load_scales(a.scales, idx, a.raw_activations);
-        const V4 rq = load_rotation(a.rotations, idx, a.raw_activations);
+        const V3 sc = activate_scales(sc_in, a.raw_activations);
+        const V4 rq = activate_rotation(rq_in, a.raw_activations);
         M3 S = mat3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
         S.c[0][0] = a.scale_modifier * sc.x;
         S.c[1][1] = a.scale_modifier * sc.y;
@@ -138,7 +213,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       }
       // computeCov2D, forward.cu:74-109
       Cov2DInter ci;
-      cov2d_common(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.viewmatrix, ci);
+      cov2d_common(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, vm, ci);
       M3 cv = mul3(mul3(transpose3(ci.T), transpose3(ci.Vrk)), ci.T);
       V3 cov = {cv.c[0][0], cv.c[0][1], cv.c[1][1]};
 
@@ -170,7 +245,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       sp.x = pix_x;
       sp.y = pix_y;
       sp.cxx = conic.x; sp.cxy = conic.y; sp.cyy = conic.z;
-      sp.opacity = load_opacity(a.opacities, idx, a.raw_activations) * h_convolution_scaling;
+      sp.opacity = activate_opacity(op_in, a.raw_activations) * h_convolution_scaling;
       sp.rect_min = minx | (miny << 16);
       sp.rect_max = maxx | (maxy << 16);
       if (a.tile_cull == 2) {
@@ -215,10 +290,10 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
                 const int r = ry * a.rg_x + rx;
                 tiles++;
                 if (n_pend == 4) { bump(); collect(); }
-                p0 = n_pend == 0 ? r : p0;
-                p1 = n_pend == 1 ? r : p1;
-                p2 = n_pend == 2 ? r : p2;
-                p3 = n_pend == 3 ? r : p3;
+                if (n_pend == 0) { p01 = (uint32_t)r; p23 = 0; }
+                else if (n_pend == 1) p01 |= (uint32_t)r << 16;
+                else if (n_pend == 2) p23 = (uint32_t)r;
+                else p23 |= (uint32_t)r << 16;
                 n_pend++;
               }
             }
@@ -280,7 +355,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
       // coefficients are neither read nor evaluated (its gradient is zero as well, see preprocess_bwd)
       if (!(a.tile_depth_limit && tiles == 0)) {
         if (a.colors_precomp == nullptr) {
-          V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
+          V3 campos = {cam[0], cam[1], cam[2]};
           V3 rgb;
           uint32_t cl = 0;
           if (a.M == 16) {
@@ -379,6 +454,7 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(GeomView g, int n
     g.hdr->overflow = 0;
     g.hdr->P = P;
     g.hdr->region_mode = 0;
+    g.hdr->pad[HDR_SIDE_CURSOR] = 0;
   }
 }
 

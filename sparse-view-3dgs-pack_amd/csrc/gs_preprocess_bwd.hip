@@ -407,6 +407,11 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
       st.denom[idx] += 1.0f;
     }
   }
+  // ---- phase 2 only steps float4s that hold an element of a Gaussian with instances: a workgroup without one is done
+  const bool gain_block = st.extra && blockIdx.x == 0;  // (gain_step below is this workgroup's)
+  if (PHASE == 2 && !grads_out && !gain_block) {
+    if (!__syncthreads_or((in_range && instanced) ? 1 : 0)) return;
+  }
   // ---- activation backward of this Gaussian's rows into the LDS gradient image
   {
     if (PHASE == 2 && !mine) {  // (stepped by phase 1: zero gradient, no parameter read)
@@ -454,7 +459,26 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
       s_g[SG_XYZ + 3 * tid + 2] = gb.dmean.z;
     }
   }
-  __syncthreads();  // every thread of the workgroup has read its parameters: the rows may now change
+  // (barrier: every thread of the workgroup has read its parameters - the rows may now change)
+  // Dormant blocks (GsStepState.dormant: every moment of every row +0).  Does any Gaussian of the workgroup bring a gradient
+  // element that is not zero?  (-0 counts as zero: it leaves a +0 moment at +0; NaN counts as non-zero.)  If none does and
+  // the block is dormant, the update changes no bit: nothing is streamed.  If one does, the block stops being dormant.
+  bool brings = false;
+  if (active && in_range) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) brings |= s_g[SG_XYZ + 3 * tid + k] != 0.f || s_g[SG_SCALE + 3 * tid + k] != 0.f || dsh.p[16 + k] != 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) brings |= s_g[SG_ROT + 4 * tid + k] != 0.f;
+    brings |= s_g[SG_OPAC + tid] != 0.f || (st.extra && s_g[SG_EXTRA + tid] != 0.f);
+  }
+  const int block_brings = __syncthreads_or(brings ? 1 : 0);
+  if (!grads_out && st.dormant) {
+    if (block_brings) {
+      if (tid == 0) st.dormant[blockIdx.x] = 0;
+    } else if (eps > 0.f && !gain_block && st.dormant[blockIdx.x] != 0) {
+      return;
+    }
+  }
 
   // ---- Adam over the workgroup's contiguous pieces of the five row arrays: coalesced float4 streams of p, m, v
   const int first = blockIdx.x * GS_BLOCK;
@@ -526,7 +550,14 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) step_uninstanced_kernel(Preproces
   struct Zero {
     __device__ __forceinline__ float operator()(int) const { return 0.f; }
   };
-  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  // blocks are handed out by a cursor in the view's header (zeroed by the forward): with dormant blocks - cheap, and lying in
+  // long runs when the rows are in spatial order - a fixed round-robin would leave most workgroups waiting for the unluckiest
+  __shared__ int s_blk;
+  for (;;) {
+    if (tid == 0) s_blk = (int)atomicAdd(const_cast<uint32_t*>(&sa.hdr->pad[HDR_SIDE_CURSOR]), 1u);
+    __syncthreads();
+    const int blk = s_blk;
+    if (blk >= nblocks) break;
     const int idx = blk * GS_BLOCK + tid;
     const bool in_range = idx < a.P;
     const bool mine = in_range && a.tiles_touched[idx] == 0;
@@ -539,6 +570,11 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) step_uninstanced_kernel(Preproces
       }
     }
     __syncthreads();
+    // a dormant block (GsStepState.dormant: every moment of every row +0): the zero-gradient update changes nothing
+    if (st.dormant && eps > 0.f && st.dormant[blk] != 0) {
+      __syncthreads();  // (s_sel is rewritten by the next block)
+      continue;
+    }
     const int first = blk * GS_BLOCK;
     const int cnt = min(GS_BLOCK, a.P - first);
     if (st.step[0] > 0)

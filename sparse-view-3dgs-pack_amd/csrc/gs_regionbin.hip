@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(GS_BLOCK) region_prepare_kernel(GeomHeader* hd
     hdr->sort_n = 0u;
     hdr->n_ordered = 0u;
     hdr->region_mode = 1u;
+    hdr->pad[HDR_SIDE_CURSOR] = 0u;
   }
 }
 

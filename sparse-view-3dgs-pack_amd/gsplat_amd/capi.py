@@ -105,7 +105,7 @@ class GsStepState(C.Structure):
                 ("extra", C.c_void_p), ("extra_m", C.c_void_p), ("extra_v", C.c_void_p), ("gain", C.c_void_p),
                 ("gain_m", C.c_void_p), ("gain_v", C.c_void_p), ("lr_extra", C.c_float), ("lr_gain", C.c_float),
                 ("step_extra", C.c_int32), ("step_gain", C.c_int32), ("grad_out_extra", C.c_void_p),
-                ("grad_out_gain", C.c_void_p), ("grad_mask", C.c_void_p)]
+                ("grad_out_gain", C.c_void_p), ("grad_mask", C.c_void_p), ("dormant", C.c_void_p)]
 
 
 _P = C.c_void_p

@@ -191,3 +191,23 @@ def ball_in_shell(P, seed=0, knn=None, sh_degree=3, ball_radius=0.8, shell_radiu
     sh[:, 1:, :] = 0.15 * torch.randn((P, 15, 3), generator=g)
     return dict(means3D=xyz, scales=scales.float(), rotations=rots.float(), opacities=opac.float(), shs=sh,
                 sh_degree=sh_degree)
+
+
+def morton_order(xyz, bits=10):
+    """Permutation that sorts points along the 3-D Morton (Z-order) curve of their bounding box (`bits` per axis): rows that
+    are neighbours in memory are neighbours in space.  xyz: [P, 3] tensor -> LongTensor [P] (stable: ties keep their order)."""
+    x = xyz.detach().to("cpu", torch.float64)
+    lo, hi = x.min(dim=0).values, x.max(dim=0).values
+    q = ((x - lo) / (hi - lo).clamp_min(1e-30) * ((1 << bits) - 1)).round().to(torch.int64).clamp_(0, (1 << bits) - 1)
+    code = torch.zeros((x.shape[0],), dtype=torch.int64)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.sort(code, stable=True).indices
+
+
+def spatially_ordered(scene):
+    """The scene with its Gaussians (every [P, ...] tensor) in Morton order of their centres."""
+    perm = morton_order(scene["means3D"])
+    P = scene["means3D"].shape[0]
+    return {k: (v[perm].contiguous() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == P else v) for k, v in scene.items()}

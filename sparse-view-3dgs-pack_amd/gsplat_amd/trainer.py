@@ -75,6 +75,38 @@ class FlatAdam:
         self.exp_avg_sq_padded = torch.zeros_like(m.flat_padded)
         self.exp_avg = self.exp_avg_padded[:m.flat.numel()]
         self.exp_avg_sq = self.exp_avg_sq_padded[:m.flat.numel()]
+        self._dormant, self._dormant_valid = None, False
+
+    # Dormant blocks (GsStepState.dormant, include/gsplat.h): one byte per 256 consecutive Gaussians, 1 = every Adam moment
+    # of every row of the block is +0, so the zero-gradient update is a no-op and gs_backward_step / gs_step_uninstanced
+    # skip the block's parameter and moment traffic.  DERIVED from the moments (never assumed), kept current by the fused
+    # kernels (a block that receives a gradient is cleared on the device) and recomputed after anything else wrote the
+    # moments (invalidate_dormant).  Pays when the rows are in spatial order (GaussianModelLite(spatial_order=True)): the
+    # Gaussians no camera reaches - more than half of bench.py's scene - then fill whole blocks.  GS_DORMANT_BLOCKS=0: off.
+    USE_DORMANT = __import__("os").environ.get("GS_DORMANT_BLOCKS", "1") != "0"
+    DORMANT_BLOCK = 256
+
+    def invalidate_dormant(self):
+        self._dormant_valid = False
+
+    def dormant_flags(self):
+        """The current flags (uint8 [ceil(P / 256)], same tensor until the model is re-laid out), recomputed from the moment
+        buffers when something other than the fused step may have written them."""
+        m = self.model
+        B = self.DORMANT_BLOCK
+        nb = (m.P + B - 1) // B
+        if getattr(self, "_dormant", None) is None or self._dormant.numel() != nb or self._dormant.device != m.flat.device:
+            self._dormant = torch.zeros((nb,), dtype=torch.uint8, device=m.flat.device)
+            self._dormant_valid = False
+        if not self._dormant_valid:
+            with torch.no_grad():
+                live = torch.zeros((nb * B,), dtype=torch.bool, device=m.flat.device)
+                for buf in (self.exp_avg, self.exp_avg_sq):
+                    for name, view in self.field_views(buf).items():
+                        live[:m.P] |= (view.view(torch.int32) != 0).any(dim=1)   # (bit patterns: -0.0 is not +0)
+                self._dormant.copy_((~live.view(nb, B).any(dim=1)).to(torch.uint8))
+            self._dormant_valid = True
+        return self._dormant
 
     def segments(self, skip=()):
         P = self.model.P
@@ -157,6 +189,7 @@ class FlatAdam:
         segs, nseg = self.segments(skip)
         if nseg == 0 or hi <= lo:
             return
+        self._dormant_valid = False   # (gs_adam_step writes moments without keeping the dormant-block flags)
         for k in range(nseg):
             segs[k].begin -= lo
             segs[k].end -= lo
@@ -220,6 +253,8 @@ class FlatAdam:
         self._nir_into(st, False)
         if m.with_nir and "nir_albedo" in skip:
             st.step_extra = 0
+        if self.USE_DORMANT and m.flat.is_cuda:
+            st.dormant = self.dormant_flags().data_ptr()
         return st
 
     def field_views(self, buf):
@@ -273,10 +308,21 @@ class _FusedActivations(torch.autograd.Function):
 class GaussianModelLite:
     """Raw (pre-activation) parameters of P Gaussians at max SH degree 3."""
 
-    def __init__(self, scene, device, spatial_lr_scale=1.0, api=None, with_nir=False):
+    def __init__(self, scene, device, spatial_lr_scale=1.0, api=None, with_nir=False, spatial_order=None):
         """scene: dict of ACTIVATED tensors as produced by gsplat_amd.synthetic (means3D, scales,
         rotations, opacities, shs[P,16,3]) - converted back to raw form as create_from_pcd would hold them.
-        api: C-ABI implementation that provides adam_step (None: torch.optim.Adam on the same flat buffers)."""
+        api: C-ABI implementation that provides adam_step (None: torch.optim.Adam on the same flat buffers).
+        spatial_order: keep the rows in Morton order of the centres (here, and again after every densification): rows that
+        are neighbours in memory are neighbours in space, so whole wavefronts / 256-row blocks are culled, depth-limited
+        away, stepped or skipped (FlatAdam.dormant_flags) together.  The model is the same set of Gaussians; only which row
+        holds which one differs from the reference's [survivors, clones, split samples] order.  Default: GS_SPATIAL_ORDER
+        (off)."""
+        if spatial_order is None:
+            spatial_order = __import__("os").environ.get("GS_SPATIAL_ORDER", "0") == "1"
+        self.spatial_order = bool(spatial_order)
+        if self.spatial_order:
+            from . import synthetic
+            scene = synthetic.spatially_ordered(scene)
         P = scene["means3D"].shape[0]
         self.P = P
         self.device = device
@@ -382,7 +428,7 @@ class GaussianModelLite:
 
     # ------------------------------------------------------------------ files (formats: gsplat_amd/io.py)
     @classmethod
-    def create_from_pcd(cls, points, colors, device, spatial_lr_scale=1.0, api=None, knn=None):
+    def create_from_pcd(cls, points, colors, device, spatial_lr_scale=1.0, api=None, knn=None, spatial_order=None):
         """create_from_pcd (gaussian_model.py:149-176): DC = RGB2SH(colour), rest 0, scale = sqrt of the mean squared
         distance to the 3 nearest neighbours (clamped at 1e-7) on all axes, identity rotation, opacity 0.1, active
         SH degree 0.  knn: callable [P,3] -> [P] (simple_knn's distCUDA2); default = the float64 brute force."""
@@ -396,7 +442,7 @@ class GaussianModelLite:
         scene = dict(means3D=pts, shs=shs, scales=torch.sqrt(dist2)[:, None].repeat(1, 3),
                      rotations=torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(P, 1), opacities=torch.full((P, 1), 0.1),
                      sh_degree=0)
-        return cls(scene, device, spatial_lr_scale=spatial_lr_scale, api=api)
+        return cls(scene, device, spatial_lr_scale=spatial_lr_scale, api=api, spatial_order=spatial_order)
 
     def save_ply(self, path):
         """save_ply (gaussian_model.py:240-256): raw parameters, the reference's 62-property layout."""
@@ -551,6 +597,9 @@ class GaussianModelLite:
             keep_new = ~prune[n_keep_old:]
             new = {name: v[keep_new] for name, v in new.items()}
             self._relayout(src, new)
+            if getattr(self, "spatial_order", False):   # the new rows go where their neighbours are
+                from . import synthetic
+                self._relayout(synthetic.morton_order(self.params["xyz"]).to(self.device), {})
             self.xyz_gradient_accum = torch.zeros((self.P, 1), device=self.device)
             self.denom = torch.zeros((self.P, 1), device=self.device)
             self.max_radii2D = torch.zeros((self.P,), device=self.device)
@@ -1501,7 +1550,8 @@ class GraphedStep:
                 m.active_sh_degree, int(cam.image_height), int(cam.image_width), float(cam.FoVx), float(cam.FoVy),
                 cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr(), cam.camera_center.data_ptr(),
                 tr.gts[ci].data_ptr(), None if mask is None else mask.data_ptr(), self.capacity, bool(tr.depth_limit),
-                self._entry_ptrs(ci), self._backend().rows_epoch)
+                self._entry_ptrs(ci), self._backend().rows_epoch,
+                m.optimizer.dormant_flags().data_ptr() if m.optimizer.USE_DORMANT else None)
 
     def _entry_ptrs(self, ci):
         """The addresses a capture of camera `ci` bakes in from the backend's per-camera entry (tile order, depth limits,
@@ -1604,6 +1654,8 @@ class GraphedStep:
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
             self._coef_for_next()
+            if opt.USE_DORMANT:
+                opt.dormant_flags()   # (derived from the moments by torch kernels: now, not inside the capture)
             gc_was_on = gc.isenabled()
             gc.disable()
             try:
@@ -1756,6 +1808,8 @@ class GraphedStep:
             return self._capture(ci)
         self._coef_for_next()
         self._upload_tag()
+        if tr.model.optimizer.USE_DORMANT:
+            tr.model.optimizer.dormant_flags()   # (in place: the graph holds the tensor's address; a no-op while they are current)
         g["graph"].replay()
         if tr.depth_limit:
             ent = self.camera_entry(ci)

@@ -23,14 +23,15 @@ cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(W, H)]
 api = hip_api()
 g = torch.Generator().manual_seed(0)
 dL = torch.randn((3, H, W), generator=g).to(dev)
-for it in range(reps + 3):
-    if it == 3:
+warm = 26 if os.environ.get("GS_KT_KEYED") else 3   # (keyed: every camera visited once, later visits are depth-limited)
+for it in range(reps + warm):
+    if it == warm:
         torch.cuda.synchronize()
         api.call("profile_reset")
         api.call("profile_enable", 1)
     model.zero_grad()
     pkg = render(cams[it % 24], model, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings, torch.zeros(3, device=dev),
-                 filter_as_indices=False)
+                 filter_as_indices=False, camera_key=("kt", it % 24) if os.environ.get("GS_KT_KEYED") else None)
     (pkg["render"] * dL).sum().backward()
 torch.cuda.synchronize()
 api.call("profile_enable", 0)

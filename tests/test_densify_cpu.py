@@ -208,3 +208,70 @@ def test_train_iteration_schedule(oracle):
     n_dens = sum(1 for o in log if o["densified"] is not None)
     assert tr.model.optimizer.t == 25 - n_dens
     assert tr.model.flat.numel() == tr.model.P * 59 and tr.model.xyz_gradient_accum.shape == (tr.model.P, 1)
+
+
+def _row_set(m):
+    """The model as a sorted list of rows (parameters | both moments): what must not depend on the row order."""
+    opt = m.optimizer
+    cols = [m.params[n].detach().reshape(m.P, w) for n, w in m.fields]
+    cols += [v for v in opt.field_views(opt.exp_avg).values()] + [v for v in opt.field_views(opt.exp_avg_sq).values()]
+    rows = torch.cat(cols, dim=1)
+    key = torch.argsort(rows[:, 0], stable=True)
+    for c in (1, 2):   # sort by xyz (distinct points)
+        key = key[torch.argsort(rows[key, c], stable=True)]
+    return rows[key[torch.argsort(rows[key, 0], stable=True)]]
+
+
+def test_spatial_order_is_a_permutation_of_the_same_model(oracle):
+    """GaussianModelLite(spatial_order=True): the same Gaussians, rows in Morton order of the centres - at construction and
+    after a densification (parameters and moments travel with their Gaussian)."""
+    sc = synthetic.trained_like(700, seed=5, scale_mult=1.5)
+    perm = synthetic.morton_order(sc["means3D"])
+    assert sorted(perm.tolist()) == list(range(700))
+    so = synthetic.spatially_ordered(sc)
+    assert torch.equal(so["means3D"], sc["means3D"][perm]) and torch.equal(so["shs"], sc["shs"][perm])
+    # neighbours in memory are neighbours in space: the mean step between consecutive rows shrinks by a lot
+    step = lambda x: float((x[1:] - x[:-1]).norm(dim=1).mean())  # noqa: E731
+    assert step(so["means3D"]) < 0.4 * step(sc["means3D"])
+    models = []
+    for flag in (False, True):
+        m = GaussianModelLite(sc, torch.device("cpu"), api=oracle.api, spatial_order=flag)
+        g = torch.Generator().manual_seed(1)
+        # the same per-GAUSSIAN gradient whatever the row: derive it from the parameters themselves
+        for _ in range(3):
+            m.flat_grad.copy_(torch.sin(m.flat.detach() * 37.0) * 1e-2)
+            m.optimizer.step()
+        m.xyz_gradient_accum = (m.params["xyz"].detach()[:, :1].abs() * 4e-4).clone()
+        m.denom = torch.ones((m.P, 1))
+        m.max_radii2D = torch.zeros((m.P,))
+        models.append((m, g))
+    assert torch.equal(_row_set(models[0][0]), _row_set(models[1][0]))
+    for m, g in models:
+        # no split samples (their noise is drawn per row): max_grad such that only clones and prunes happen
+        m.percent_dense = 1e9
+        m.densify_and_prune(2e-4, 0.005, 4.0, None, generator=g)
+    a, b = models[0][0], models[1][0]
+    assert a.P == b.P and a.P != 700
+    assert torch.equal(_row_set(a), _row_set(b))
+    assert torch.equal(b.params["xyz"].detach(), b.params["xyz"].detach()[synthetic.morton_order(b.params["xyz"])])
+
+
+def test_dormant_flags_are_derived_from_the_moments(oracle):
+    """FlatAdam.dormant_flags: 1 exactly for the 256-row blocks all of whose moments are +0; recomputed after anything but the
+    fused step wrote the moments."""
+    sc = synthetic.trained_like(1000, seed=2)
+    m = GaussianModelLite(sc, torch.device("cpu"), api=oracle.api)
+    opt = m.optimizer
+    assert opt.dormant_flags().tolist() == [1, 1, 1, 1]
+    m.flat_grad.zero_()
+    m.grad_views()["opacity"][300] = 1e-3     # one Gaussian of block 1 gets a gradient
+    opt.step()
+    assert opt.dormant_flags().tolist() == [1, 0, 1, 1]
+    opt.field_views(opt.exp_avg_sq)["rotation"][999, 3] = -0.0   # a bit pattern that is not +0
+    opt.invalidate_dormant()
+    assert opt.dormant_flags().tolist() == [1, 0, 1, 0]
+    state = m.capture()
+    m2 = GaussianModelLite(sc, torch.device("cpu"), api=oracle.api)
+    assert m2.optimizer.dormant_flags().tolist() == [1, 1, 1, 1]
+    m2.restore(state)
+    assert m2.optimizer.dormant_flags().tolist() == [1, 0, 1, 0]

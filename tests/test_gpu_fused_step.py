@@ -27,14 +27,16 @@ def one_binning_path(hip):
     hip._cam_cache.clear()
 
 
-def make(hip, fused, P=30000, W=480, H=320, seed=3, sh_degree=3, skip_rows=None, n_cams=4):
+def make(hip, fused, P=30000, W=480, H=320, seed=3, sh_degree=3, skip_rows=None, n_cams=4, spatial_order=False, lifted=0.0):
     from simple_knn._C import distCUDA2
     dev = torch.device("cuda")
     sc = synthetic.trained_like(P, seed=seed, sh_degree=sh_degree, knn=lambda x: distCUDA2(x.to(dev)).cpu())
+    if lifted > 0.0:   # this share of the Gaussians sits 50 units above the scene: outside every camera's frustum
+        sc["means3D"][: int(P * lifted), 2] += 50.0
     cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(W, H)[:n_cams]]
     g = torch.Generator().manual_seed(5)
     gts = [torch.rand((3, H, W), generator=g).to(dev) for _ in cams]
-    model = GaussianModelLite(sc, dev, api=hip.api)
+    model = GaussianModelLite(sc, dev, api=hip.api, spatial_order=spatial_order)
     crit = lgdwt_loss.criterion(dwt_enable=True, patch_dwt_enable=True)
     tr = Trainer(model, cams, gts, crit, dgr.GaussianRasterizer, dgr.GaussianRasterizationSettings,
                  torch.zeros(3, device=dev), optimizer_step=True)
@@ -316,3 +318,39 @@ def test_two_runs_of_the_train_step_are_the_same_bits(hip):
     for k in runs[0][0]:
         assert torch.equal(runs[0][0][k], runs[1][0][k]), (k, float((runs[0][0][k] - runs[1][0][k]).abs().max()))
     assert runs[0][1] == runs[1][1]
+
+
+@pytest.mark.parametrize("two_phase", [True, False], ids=["two_phase", "one_launch"])
+def test_dormant_blocks_are_skipped_without_changing_a_bit(hip, two_phase):
+    """GsStepState.dormant on a model in spatial order (whole 256-row blocks are never reached by a camera): the step that
+    skips those blocks' parameter / moment traffic against the step that streams them - same parameters, moments and
+    statistics, bit for bit (the backward is reproducible), in the two-phase and in the one-launch form, on depth-limited
+    lists; and every flag still standing is TRUE of the moments."""
+    a = make(hip, True, P=150000, W=640, H=400, n_cams=6, spatial_order=True, lifted=0.4)
+    b = make(hip, True, P=150000, W=640, H=400, n_cams=6, spatial_order=True, lifted=0.4)
+    assert a.model.spatial_order and torch.equal(a.model.flat, b.model.flat)
+    b.model.optimizer.USE_DORMANT = False
+    a.depth_limit = b.depth_limit = "deferred"
+    hip.TWO_PHASE, hip.TWO_PHASE_MIN_P = two_phase, 0
+    n0 = hip.two_phase_launches
+    try:
+        for k in range(14):
+            a.step(k)
+            b.step(k)
+        a.sync()
+        b.sync()
+    finally:
+        del hip.TWO_PHASE, hip.TWO_PHASE_MIN_P
+    assert (hip.two_phase_launches - n0 > 0) == two_phase
+    sa, sb = state(a), state(b)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), (k, float((sa[k] - sb[k]).abs().max()))
+    opt = a.model.optimizer
+    kept = opt.dormant_flags().clone()        # maintained by the kernels
+    opt.invalidate_dormant()
+    derived = opt.dormant_flags().clone()     # recomputed from the moments
+    assert bool(((kept == 0) | (derived == 1)).all()), "a block is flagged dormant although one of its moments is not +0"
+    n_blocks = kept.numel()
+    assert 0.3 * n_blocks < int(kept.sum()) < n_blocks, (int(kept.sum()), n_blocks)   # the skip really happened
+    assert int(derived.sum()) >= int(kept.sum())
+    assert float(sa["denom"].max()) >= 2.0

@@ -24,7 +24,8 @@ if os.environ.get("PROBE_TRAINER_FIRST"):
     for k in range(30):
         tr.step(k)
     tr.sync()
-del tr
+if not os.environ.get("PROBE_KEEP_TRAINER"):
+    del tr
 be, api = hip_backend(), hip_api()
 for mode in modes:
     loop = DropInLoop(scene, cams, gts, dev, dwt=True, patch=True, optimizer="torch" if mode == "torch" else "fused",

@@ -5,6 +5,7 @@
 step() {
   local secs=$1 log=$2; shift 2
   echo "== $(date +%T) $* -> $log"
+  mkdir -p "$(dirname "$log")"
   timeout -k 10 "$secs" "$@" > "$log" 2>&1
   local rc=$?
   echo "   rc=$rc"
