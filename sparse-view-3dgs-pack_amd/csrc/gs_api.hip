@@ -48,7 +48,6 @@ static int region_layout(const GsView* v, const GsScratch* sc, RegionLayout& rl)
   if (sc->binning_bytes < bin_bytes((size_t)cap)) return GS_E_SCRATCH;
   rl.rg_x = (gx + RG_TILES - 1) / RG_TILES;
   rl.rg_y = (gy + RG_TILES - 1) / RG_TILES;
-  if ((int64_t)rl.rg_x * rl.rg_y > 65535) return GS_E_UNSUPPORTED;  // (preprocess_fwd_kernel packs region numbers into 16 bits)
   rl.cap = region_capacity(cap, rl.rg_x * rl.rg_y);
   if (rl.cap == 0) return GS_E_SHAPE;  // fewer instances of capacity than regions
   ImgView iv = img_view(sc->img, N, T);

@@ -66,76 +66,32 @@ static inline size_t preprocess_limit_lds_floats(const PreprocessArgs& a) {
   return want <= GS_LIMIT_LDS_MAX_FLOATS ? want : 0;
 }
 
-__global__ void __launch_bounds__(GS_BLOCK, 5) preprocess_fwd_kernel(PreprocessArgs a, GeomView g, int lds_floats) {
+__global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs a, GeomView g, int lds_floats) {
   const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
   uint32_t tiles = 0;
   const int T = a.grid_x * a.grid_y;
   // region binning: up to four bucket counters waiting to be bumped (selects, not an indexed array: that would live in
-  // scratch memory), what their atomics returned, and this Gaussian's bucket entry.
-  // The atomics are issued per WAVE where that pays: lanes that bump the same counter form a group, the group's first lane
-  // adds the group's size and every member takes base + its rank (`ld` / `rk`: leader lane and rank of the four pending
-  // counters, a byte each).  With the model's rows in spatial order (GaussianModelLite.spatial_order) a wave's Gaussians
-  // share a handful of regions - tens of lanes per returning atomic instead of one; with rows in random order the first
-  // GS_PP_GROUPS groups are tried (cheap: scalar ballots) and the other lanes bump on their own as before.  The order of the
-  // entries inside a bucket is whatever the atomics make it - region_bin_kernel sorts each bucket by (depth, index).
-#ifndef GS_PP_GROUPS
-#define GS_PP_GROUPS 3
-#endif
-  // (registers: the four pending regions live in two words - 16 bits each, the glue keeps region binning to images with at
-  //  most 65 535 regions -, leader lanes and ranks in one word each, 6 bits per counter; `ld` bits 24.. = how many were bumped)
-  uint32_t p01 = 0, p23 = 0;
-  int n_pend = 0;
-  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, dbits = 0, ld = 0, rk = 0;
-  const int wlane = threadIdx.x & 63;
-  const unsigned long long lanes_below = (1ull << wlane) - 1ull;
-  auto pend_region = [&](int k) -> int { return (int)(((k < 2 ? p01 : p23) >> (16 * (k & 1))) & 0xFFFFu); };
-  auto bump_one = [&](int k, uint32_t& sk) {
-    const bool has = n_pend > k;
-    const int pk = pend_region(k);
-    unsigned long long todo = __ballot(has);
-    int lead = wlane;
-    uint32_t rank = 0, cnt = 1;
-    for (int it = 0; it < GS_PP_GROUPS && todo != 0ull; it++) {
-      const int L = __builtin_ctzll(todo);
-      const int r = __builtin_amdgcn_readlane(pk, L);
-      const bool in = has && pk == r;
-      const unsigned long long grp = __ballot(in);
-      if (in) {
-        lead = L;
-        rank = (uint32_t)__popcll(grp & lanes_below);
-        cnt = (uint32_t)__popcll(grp);
-      }
-      todo &= ~grp;
-    }
-    if (has) {
-      if (lead == wlane) sk = atomicAdd(&a.region_count[(size_t)pk * RG_COUNT_STRIDE], cnt);
-      ld |= (uint32_t)lead << (6 * k);
-      rk |= rank << (6 * k);
-    }
-  };
+  // scratch memory), the slots they returned, and this Gaussian's bucket entry.
+  // (Round 4 tried the atomics per WAVE - lanes that bump the same counter form a group, its first lane adds the group's
+  //  size, members take base + rank through a shuffle -: correct, and slower with rows in random order (0.114 -> 0.134 ms)
+  //  AND in spatial order (0.120 -> 0.128 ms, where a wave shares a handful of regions): the scalar grouping loop and the
+  //  shuffles cost more than the returning atomics they save.)
+  int p0 = 0, p1 = 0, p2 = 0, p3 = 0, n_pend = 0;
+  uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu, dbits = 0;
   auto bump = [&]() {
-    bump_one(0, s0);
-    bump_one(1, s1);
-    bump_one(2, s2);
-    bump_one(3, s3);
-    ld |= (uint32_t)n_pend << 24;
+    if (n_pend > 0) s0 = atomicAdd(&a.region_count[(size_t)p0 * RG_COUNT_STRIDE], 1u);
+    if (n_pend > 1) s1 = atomicAdd(&a.region_count[(size_t)p1 * RG_COUNT_STRIDE], 1u);
+    if (n_pend > 2) s2 = atomicAdd(&a.region_count[(size_t)p2 * RG_COUNT_STRIDE], 1u);
+    if (n_pend > 3) s3 = atomicAdd(&a.region_count[(size_t)p3 * RG_COUNT_STRIDE], 1u);
     n_pend = 0;
-  };
-  // (every lane that bumped collects, together with its group's leader: the leader's lane is read by a shuffle)
-  auto collect_one = [&](int k, uint32_t sk, uint2 entry) {
-    const uint32_t base = (uint32_t)__shfl((int)sk, (int)((ld >> (6 * k)) & 63u), 64);
-    if ((int)(ld >> 24) > k) {
-      const uint32_t slot = base + ((rk >> (6 * k)) & 63u);
-      if (slot < a.region_cap) a.region_bucket[(size_t)pend_region(k) * a.region_cap + slot] = entry;
-    }
   };
   auto collect = [&]() {
     const uint2 entry = make_uint2(dbits, (uint32_t)idx);
-    collect_one(0, s0, entry);
-    collect_one(1, s1, entry);
-    collect_one(2, s2, entry);
-    collect_one(3, s3, entry);
-    ld = rk = 0;
+    if (s0 < a.region_cap) a.region_bucket[(size_t)p0 * a.region_cap + s0] = entry;
+    if (s1 < a.region_cap) a.region_bucket[(size_t)p1 * a.region_cap + s1] = entry;
+    if (s2 < a.region_cap) a.region_bucket[(size_t)p2 * a.region_cap + s2] = entry;
+    if (s3 < a.region_cap) a.region_bucket[(size_t)p3 * a.region_cap + s3] = entry;
+    s0 = s1 = s2 = s3 = 0xFFFFFFFFu;
   };
   const int lidx = min(idx, a.P - 1);  // (the last workgroup's spare lanes load the last Gaussian's rows and drop them)
   // Every small row of this Gaussian is requested at once, ahead of the frustum test and of the limit table's copy:
@@ -290,10 +246,10 @@ __global__ void __launch_bounds__(GS_BLOCK, 5) preprocess_fwd_kernel(PreprocessA
                 const int r = ry * a.rg_x + rx;
                 tiles++;
                 if (n_pend == 4) { bump(); collect(); }
-                if (n_pend == 0) { p01 = (uint32_t)r; p23 = 0; }
-                else if (n_pend == 1) p01 |= (uint32_t)r << 16;
-                else if (n_pend == 2) p23 = (uint32_t)r;
-                else p23 |= (uint32_t)r << 16;
+                p0 = n_pend == 0 ? r : p0;
+                p1 = n_pend == 1 ? r : p1;
+                p2 = n_pend == 2 ? r : p2;
+                p3 = n_pend == 3 ? r : p3;
                 n_pend++;
               }
             }

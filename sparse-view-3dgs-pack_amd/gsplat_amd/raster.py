@@ -579,8 +579,6 @@ class RasterBackend:
             self.api.call("forward_geometry", C.byref(view), C.byref(g), C.byref(scratch_of(empty, 0, limit)),
                           radii.data_ptr(), status.data_ptr(), stream)
 
-        if view.tile_cull == 2 and ((((W + 15) // 16) + 3) // 4) * ((((H + 15) // 16) + 3) // 4) > 65535:
-            view.tile_cull = 1   # (the forward keeps a Gaussian's pending regions as 16-bit numbers: images beyond ~16k x 16k)
         if view.tile_cull == 2 and self.binning == "auto" and limit is None and not static:
             regions = ((((W + 15) // 16) + 3) // 4) * ((((H + 15) // 16) + 3) // 4)
             if self._capacity_hint > self.REGION_AUTO_MAX * regions:

@@ -9,7 +9,7 @@ step() {
   timeout -k 10 "$secs" "$@" > "$log" 2>&1
   local rc=$?
   echo "   rc=$rc"
-  tail -n 3 "$log" | sed 's/^/   | /'
+  tail -n 3 "$log" | cut -c1-400 | sed 's/^/   | /'
   if [ $rc -ge 124 ]; then echo "step timed out or was killed: stopping"; exit $rc; fi
   return 0
 }
