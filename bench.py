@@ -597,10 +597,27 @@ def main():
                 loop.iteration(j % len(cams))
             torch.cuda.synchronize()
             dd0 = dict(bed.depth_limit_stats)
+            # (as in the timed region: no cyclic-garbage sweep inside a 60 ms window - a generation-2 sweep of this process is
+            #  tens of milliseconds and used to land in one variant or another: 6.5-8.5 ms/step instead of 3.1)
+            gc.collect()
+            gc.disable()
+            prof_ = None
+            if os.environ.get("GS_BENCH_DROP_IN_PROFILE"):   # developer switch: where the host time of an iteration goes
+                import cProfile
+                prof_ = cProfile.Profile()
+                prof_.enable()
             t1 = time.perf_counter()
             for j in range(n_di):
                 loop.iteration((j + 2) % len(cams))
             torch.cuda.synchronize()
+            gc.enable()
+            if prof_ is not None:
+                import io
+                import pstats
+                prof_.disable()
+                buf_ = io.StringIO()
+                pstats.Stats(prof_, stream=buf_).sort_stats("tottime").print_stats(10)
+                log(label + "\n" + buf_.getvalue())
             drop_in[label] = {"ms_per_step": (time.perf_counter() - t1) / n_di * 1e3, "steps": n_di,
                               "depth_limited_views": bed.depth_limit_stats["used"] - dd0["used"],
                               "fallbacks": bed.depth_limit_stats["failed"] - dd0["failed"]}

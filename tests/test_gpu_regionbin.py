@@ -151,13 +151,13 @@ def test_a_region_too_crowded_for_one_workgroup_falls_back_to_the_lsd_path(hip):
     hip.binning = "region"
     hip._capacity_hint = 0
     b = forward_state(hip, sc, cam, DEV, bg, False)
-    assert (P, W, H) in hip._region_off
+    assert (P, W, H, False) in hip._region_off
     assert a["num_rendered"] == b["num_rendered"]
     assert np.array_equal(canonical_lists(a)[1], canonical_lists(b)[1]) and torch.equal(a["color"], b["color"])
     # sizes that fit keep using regions
     sc2 = synthetic.trained_like(2000, seed=2, sh_degree=0)
     c = forward_state(hip, sc2, cam, DEV, bg, False)
-    assert (2000, W, H) not in hip._region_off and c["num_rendered"] > 0
+    assert (2000, W, H, False) not in hip._region_off and c["num_rendered"] > 0
 
 
 def test_fused_train_step_on_region_lists_is_the_lsd_run(hip):

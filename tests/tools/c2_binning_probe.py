@@ -1,0 +1,19 @@
+import os, sys
+sys.path.insert(0, "/root/repo/sparse-view-3dgs-pack_amd"); sys.path.insert(0, "/root/repo")
+import torch, bench
+from gsplat_amd import hip_backend
+from gsplat_amd._lib import hip_api
+from gsplat_amd.capi import read_profile
+dev = torch.device("cuda", 0)
+tr, scene, cams, gts = bench.build_workload("c2", dev, 0, 1)
+tr.depth_limit = "deferred"
+be, api = hip_backend(), hip_api()
+for k in range(30):
+    tr.step(k)
+tr.sync()
+print("region_off", be._region_off, "hints", be._capacity_hint, be._capacity_hint_limited, "stats", be.depth_limit_stats)
+api.call("profile_reset"); api.call("profile_enable", 1)
+for k in range(30, 40):
+    tr.step(k)
+tr.sync(); api.call("profile_enable", 0)
+print({k: round(v[0] / v[1], 4) for k, v in read_profile(api).items()})

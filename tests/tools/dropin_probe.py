@@ -24,6 +24,24 @@ if os.environ.get("PROBE_TRAINER_FIRST"):
     for k in range(30):
         tr.step(k)
     tr.sync()
+if os.environ.get("PROBE_GRAPH"):       # ... and replayed from hipGraphs, as bench.py's launch trial does
+    from gsplat_amd.trainer import GraphedStep
+    gs_ = GraphedStep(tr)
+    for k in range(60):
+        gs_.step(k)
+    gs_.sync()
+if os.environ.get("PROBE_REFLISTS"):    # ... and the reference-lists leg of bench.py (tile_cull off for a dozen steps, then back)
+    be0 = hip_backend()
+    old = be0.tile_cull
+    be0.tile_cull = False
+    for k in range(12):
+        tr.step(100 + k)
+    torch.cuda.synchronize()
+    be0.tile_cull = old
+    for k in range(2):
+        tr.step(120 + k)
+    tr.sync()
+    print("after the reference-lists leg: capacity hints", be0._capacity_hint, be0._capacity_hint_limited, flush=True)
 if not os.environ.get("PROBE_KEEP_TRAINER"):
     del tr
 be, api = hip_backend(), hip_api()
@@ -34,11 +52,20 @@ for mode in modes:
         loop.iteration(j % len(cams))
     torch.cuda.synchronize()
     d0 = dict(be.depth_limit_stats)
+    prof_ = None
+    if os.environ.get("PROBE_CPROFILE"):
+        import cProfile
+        prof_ = cProfile.Profile()
+        prof_.enable()
     t0 = time.perf_counter()
     for j in range(n):
         loop.iteration((j + 2) % len(cams))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
+    if prof_ is not None:
+        import pstats
+        prof_.disable()
+        pstats.Stats(prof_).sort_stats("tottime").print_stats(12)
     api.call("profile_reset")
     api.call("profile_enable", 1)
     for j in range(6):
