@@ -135,7 +135,7 @@ print(open(os.path.join(here, "%s_pmc_traffic.csv" % tag)).read())
 
 # SQ counters -> <tag>_sq_counters.csv (per kernel: instructions per wave, VALU-busy share of the SIMD cycles, wait shares)
 sq = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "sq*", "*", "*_counter_collection.csv")):
+for f in glob.glob(os.path.join(src, "sq[0-9]*", "*", "*_counter_collection.csv")):   # (not sq_<scene>: the other scenes' passes)
     for r in csv.DictReader(open(f)):
         sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if sq:
