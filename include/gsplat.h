@@ -303,7 +303,7 @@ typedef struct GsStepState {
    * (gs_adam_step_gated takes it as its gate). */
   float* grad_out[5];
   float* fail_flag;
-  /* ---- two-phase step (single GPU, GsView.tile_cull != 0) ----
+  /* ---- two-phase step (single GPU; any list mode) ----
    * 0: gs_backward_step handles every Gaussian.  2: only the Gaussians that emitted instances in this view - the caller has
    * already run gs_step_uninstanced on the same state for the others. */
   int32_t phase;
@@ -368,8 +368,9 @@ int gs_backward_step_x(const GsView* view, const GsGaussians* g, const int32_t* 
  * takes, measured).  gs_backward_step steps the Gaussians with instances; its per-Gaussian kernel must be ordered after
  * this call (st->phase1_done; the two split the float4s of the parameter rows between them).  Like gs_backward_step a no-op on the device when the forward had flagged
  * overflow or trunc_failed - so it must not start before the forward BLEND has finished.  Same element arithmetic: the
- * two calls together leave the bits gs_backward_step (phase 0) leaves.  GS_E_UNSUPPORTED with tile_cull = 0 (every visible
- * Gaussian has instances there) and in the data-parallel form. */
+ * two calls together leave the bits gs_backward_step (phase 0) leaves.  With tile_cull = 0 every visible Gaussian has
+ * instances, and the Gaussians without are the ones outside the frustum (59 % of bench.py's scene: with the rows in spatial
+ * order most of their blocks are dormant, see GsStepState.dormant).  GS_E_UNSUPPORTED in the data-parallel form. */
 int gs_step_uninstanced(const GsView* view, const GsGaussians* g, const int32_t* radii,
                         const GsScratch* scratch, const GsStepState* st, void* stream);
 

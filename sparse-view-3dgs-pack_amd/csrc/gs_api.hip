@@ -446,7 +446,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     rows = const_cast<gs_row_t*>(step->rows_override);
   } else if (rows_clean != 2) {  // (2: the previous step's per-Gaussian kernel left every row zero)
     GS_PROF(ST_BWD_MEMSET, s);
-    launch_zero_rows(rows, (size_t)P, v->tile_cull ? gv.tiles_touched : nullptr, s);
+    launch_zero_rows(rows, (size_t)P, (v->tile_cull || (step && step->phase == 2)) ? gv.tiles_touched : nullptr, s);
   }
   if (num_rendered > 0 && !given_rows) {
     {
@@ -457,7 +457,9 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     GS_LAUNCH_CHECK(s, v->debug);
   }
   PreprocessBwdArgs a = preprocess_bwd_args(v, g, radii, gv, fsgs ? 2 : (dL_dinvdepth != nullptr ? 1 : 0), rows, recs, grads);
-  a.skip_uninstanced = v->tile_cull ? 1 : 0;  // (with the reference's lists every visible Gaussian has instances)
+  // (with the reference's lists every visible Gaussian has instances and tiles_touched == 0 means "not visible": skipping on it
+  //  is the same thing there; the two-phase step splits the Gaussians on it in either list mode)
+  a.skip_uninstanced = (v->tile_cull || (step && step->phase == 2)) ? 1 : 0;
   a.clean_rows = rows_clean != 0;
   if (step && step->extra) {  // per-wave partial sums of dL/dgain: behind the records
     float* gp = reinterpret_cast<float*>((char*)workspace + gs_align((size_t)P * GR_ROW_BYTES) + gs_align((size_t)P * GC_REC_BYTES));
@@ -475,7 +477,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
     sa.hdr = gv.hdr;
 
     if (step->phase == 2) {  // the Gaussians without instances are stepped by gs_step_uninstanced (maybe still running)
-      if (!v->tile_cull || step->grad_out[0]) return GS_E_UNSUPPORTED;
+      if (step->grad_out[0]) return GS_E_UNSUPPORTED;
       sa.phase = 2;
       if (step->phase1_done) {
         const hipError_t e = hipStreamWaitEvent(s, (hipEvent_t)step->phase1_done, 0);
@@ -517,7 +519,7 @@ int gs_step_uninstanced(const GsView* v, const GsGaussians* g, const int32_t* ra
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !st) return GS_E_NULL;
-  if (!v->tile_cull || st->grad_out[0]) return GS_E_UNSUPPORTED;
+  if (st->grad_out[0]) return GS_E_UNSUPPORTED;
   const int P = g->P;
   if (P == 0) return GS_OK;
   StepArgs sa;

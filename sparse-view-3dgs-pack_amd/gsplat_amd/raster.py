@@ -416,7 +416,7 @@ class RasterBackend:
         step = self.fused_step
         if step is not None and not fsgs and means3D.device.type == "cuda" and self.UNINST_AT != "raster_backward":
             P = int(means3D.shape[0])
-            if self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and self.tile_cull and not step.grad_out[0] and not step.rows_override:
+            if self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and not step.grad_out[0] and not step.rows_override:
                 self._early = dict(args=(bg, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
                                          projmatrix, campos, tanfovx, tanfovy, int(image_height), int(image_width),
                                          scale_modifier, degree, antialiasing, debug),
@@ -808,7 +808,7 @@ class RasterBackend:
             _, _, _, wsb = self.scratch_bytes(P, W, H, R)
             # (the backward clears only the rows of Gaussians that emitted instances; a probe that reads the rows gets zeros
             # for the others too)
-            two_phase = self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and view.tile_cull != 0 and not step.grad_out[0]
+            two_phase = self.TWO_PHASE and P >= self.TWO_PHASE_MIN_P and not step.grad_out[0]
             if self.keep_workspace or step.rows_override:
                 ws = (torch.zeros if self.keep_workspace else torch.empty)((wsb,), dtype=torch.uint8, device=device)
                 if self.keep_workspace:

@@ -74,7 +74,8 @@ def test_fused_tail_equals_the_three_kernels_bit_for_bit(hip, skip, deg):
     assert float(a.model.denom.max()) == 3.0 and float((sa["flat"] - make(hip, False, sh_degree=deg).model.flat).abs().max()) > 0
 
 
-def test_two_phase_step_leaves_the_bits_of_the_one_launch_step(hip):
+@pytest.mark.parametrize("lists", ["culled", "reference"])
+def test_two_phase_step_leaves_the_bits_of_the_one_launch_step(hip, lists):
     """gs_step_uninstanced (the Adam step and statistics of the Gaussians WITHOUT instances, on a side stream under the
     criterion and the backward blend) + gs_backward_step phase 2 (the others) against the one-launch step, on depth-limited
     lists (most Gaussians are then without instances) and with the blend sums pinned: the very same bits, step after step."""
@@ -85,7 +86,11 @@ def test_two_phase_step_leaves_the_bits_of_the_one_launch_step(hip):
     rows[:, :9] = (torch.randn((P, 9), generator=g) * 1e-3).double()
     rows = rows.cuda()
     a.rows_override = b.rows_override = rows
-    a.depth_limit = b.depth_limit = "deferred"
+    old_cull = hip.tile_cull
+    if lists == "reference":     # GsView.tile_cull = 0: the Gaussians without instances are the ones outside the frustum
+        hip.tile_cull = False
+    else:
+        a.depth_limit = b.depth_limit = "deferred"
     n0 = hip.two_phase_launches
     try:
         for k in range(10):
@@ -97,6 +102,7 @@ def test_two_phase_step_leaves_the_bits_of_the_one_launch_step(hip):
         b.sync()
     finally:
         del hip.TWO_PHASE, hip.TWO_PHASE_MIN_P     # (back to the class defaults)
+        hip.tile_cull = old_cull
     assert hip.two_phase_launches - n0 >= 10
     sa, sb = state(a), state(b)
     for k in sa:
