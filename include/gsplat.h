@@ -151,6 +151,12 @@ typedef struct GsScratch {
                                       are multiplied by it.  A caller whose model moves fast between two visits of a camera (early
                                       training) raises it for the cameras whose limits fail and lowers it again when they hold:
                                       longer lists, fewer repeated views.  Device memory so that a replayed graph sees changes. */
+  uint32_t* status_host;           /* optional: 16 words of PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory).
+                                      gs_forward_render* then delivers what gs_forward_status would - words 0-3 = num_rendered,
+                                      overflow, trunc_failed, largest region count; with step_tag also word 8 = *step_tag and word 9 =
+                                      GS_STATUS_CHECK - from its LAST kernel, with system-scope stores: no copy command, no extra
+                                      launch on the stream.  Complete when the call's work has completed; a host that polls for
+                                      the tag accepts the block when the check word matches, as with gs_forward_status. */
 } GsScratch;
 
 /* Gradient outputs of gs_backward (rasterize_points.cu:163-178).  All are written in full by

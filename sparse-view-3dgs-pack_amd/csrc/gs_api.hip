@@ -295,7 +295,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
   {
     GS_PROF(ST_TILE_ORDER, s);
     launch_tile_order(iv.tile_work, iv.tile_order, (int)T, sc->tile_order_out, iv.tile_stop_depth, sc->tile_depth_limit_out, gx, gy,
-                      gv.hdr, s, sc->tile_depth_limit_slack);
+                      gv.hdr, s, sc->tile_depth_limit_slack, sc->status_host, sc->step_tag);
   }
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;

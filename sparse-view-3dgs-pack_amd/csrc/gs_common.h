@@ -280,7 +280,7 @@ int launch_render_fwd_wave(const uint2* ranges, const uint32_t* point_list, int 
 int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, int grid_y, hipStream_t s);
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, uint32_t* order_out, const float* stop_depth,
                       float* limit_out, int grid_x, int grid_y, const GeomHeader* hdr, hipStream_t s,
-                      const float* slack_dev = nullptr);
+                      const float* slack_dev = nullptr, uint32_t* status_host = nullptr, const uint32_t* step_tag = nullptr);
 int launch_zero_rows(gs_row_t* rows, size_t P, const uint32_t* tiles_touched, hipStream_t s);
 int launch_render_bwd_wave(const uint2* ranges, const uint32_t* point_list, int W, int H, int grid_x, int grid_y,
                            const Splat* splat, const float* bg, const float* final_T, const uint32_t* n_contrib,

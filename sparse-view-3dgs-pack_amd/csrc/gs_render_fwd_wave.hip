@@ -292,7 +292,22 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint32_t* 
                                                                 const float* __restrict__ stop_depth,
                                                                 float* __restrict__ limit_out, int grid_x, int grid_y,
                                                                 const GeomHeader* __restrict__ hdr,
-                                                                const float* __restrict__ slack_dev) {
+                                                                const float* __restrict__ slack_dev,
+                                                                uint32_t* status_host, const uint32_t* step_tag) {
+  // GsScratch.status_host: this is the forward's last kernel and every status word is final (the blend before it raised
+  // trunc_failed): one thread delivers the block straight into the caller's pinned memory - no copy command behind the forward
+  if (status_host && blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t nr = hdr->num_rendered, ov = hdr->overflow, tf = hdr->trunc_failed;
+    volatile uint32_t* out = status_host;
+    out[0] = nr; out[1] = ov; out[2] = tf; out[3] = hdr->zero;
+    if (step_tag) {
+      const uint32_t t = *step_tag;
+      out[9] = gs_status_check(t, nr, ov, tf);
+      __threadfence_system();
+      out[8] = t;   // (the tag last: a poller that sees it finds the words above in place, and verifies the check word anyway)
+    }
+    __threadfence_system();
+  }
   // a forward that ran out of binning capacity blended nothing and is about to be repeated with the SAME hints and
   // bounds (the geometry phase has already counted with them): it must not overwrite them with what it did not measure
   if (hdr->overflow) order_out = nullptr;
@@ -387,9 +402,10 @@ int launch_export_stop_depth(const float* stop_depth, float* out, int grid_x, in
 }
 
 int launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int T, uint32_t* order_out, const float* stop_depth,
-                      float* limit_out, int grid_x, int grid_y, const GeomHeader* hdr, hipStream_t s, const float* slack_dev) {
+                      float* limit_out, int grid_x, int grid_y, const GeomHeader* hdr, hipStream_t s, const float* slack_dev,
+                      uint32_t* status_host, const uint32_t* step_tag) {
   const int extra = limit_out ? ((int)depth_limit_floats((uint32_t)grid_x, (uint32_t)grid_y) + TO_THREADS - 1) / TO_THREADS : 0;
   hipLaunchKernelGGL(tile_order_kernel, dim3(8 + extra), dim3(TO_THREADS), 0, s, tile_work, tile_order, T, (T + 7) / 8, order_out,
-                     stop_depth, limit_out, grid_x, grid_y, hdr, slack_dev);
+                     stop_depth, limit_out, grid_x, grid_y, hdr, slack_dev, status_host, step_tag);
   return 0;
 }

@@ -64,6 +64,7 @@ class GsScratch(C.Structure):
         ("_pad", C.c_int32),
         ("step_tag", C.c_void_p),
         ("tile_depth_limit_slack", C.c_void_p),
+        ("status_host", C.c_void_p),
     ]
 
 

@@ -388,6 +388,10 @@ class RasterBackend:
     # the stream hand-offs cost more than the hidden stream saves); GS_TWO_PHASE_STEP=0 switches it off.
     # depth-limited lists for callers that name their cameras (GaussianRasterizer.camera_key); GS_KEYED_LIMITS=0: never
     KEYED_LIMITS = os.environ.get("GS_KEYED_LIMITS", "1") != "0"
+    # region-binned forwards whose verdict is collected later (deferred eager steps, replayed graphs): the status block is
+    # written into the pinned host block by the forward's own last kernel (GsScratch.status_host) instead of by a copy
+    # command behind it - one launch less on the stream.  GS_STATUS_IN_RENDER=0: gs_forward_status as before.
+    STATUS_IN_RENDER = os.environ.get("GS_STATUS_IN_RENDER", "1") != "0"
     TWO_PHASE = os.environ.get("GS_TWO_PHASE_STEP", "1") != "0"
     TWO_PHASE_MIN_P = 100_000
 
@@ -691,10 +695,13 @@ class RasterBackend:
             s = scratch_of(binning, cap, limit)
             geometry(s)
             self.api.call("forward_bin", C.byref(view), C.byref(g), C.byref(s), None, stream)
+            if self.STATUS_IN_RENDER:
+                s.status_host = status.data_ptr()   # the forward's last kernel delivers the status block (+ tag) itself
             render(s)
             if limit is not None:
                 self.depth_limit_stats["used"] += 1
-            self.api.call("forward_status", C.byref(s), status.data_ptr(), stream)
+            if not self.STATUS_IN_RENDER:
+                self.api.call("forward_status", C.byref(s), status.data_ptr(), stream)
             remember(s)
             return cap, binning
 
@@ -711,14 +718,17 @@ class RasterBackend:
                 if limited and defer:
                     # the caller collects the verdict (capacity AND limits) later: no host wait at all in this forward
                     self.api.call("forward_bin", C.byref(view), C.byref(g), C.byref(s), None, stream)
-                    render(s)
-                    self.depth_limit_stats["used"] += 1
                     ring = self._status_ring.setdefault(cur.device.index if hasattr(cur, "device") else 0, [[], 0])
                     if len(ring[0]) < 8:
                         ring[0].append(torch.zeros((16,), dtype=torch.int32).pin_memory())
                     block = ring[0][ring[1] % len(ring[0])]
                     ring[1] += 1
-                    self.api.call("forward_status", C.byref(s), block.data_ptr(), stream)
+                    if self.STATUS_IN_RENDER:   # the forward's last kernel writes the status words into the pinned block
+                        s.status_host = block.data_ptr()
+                    render(s)
+                    self.depth_limit_stats["used"] += 1
+                    if not self.STATUS_IN_RENDER:
+                        self.api.call("forward_status", C.byref(s), block.data_ptr(), stream)
                     done = torch.cuda.Event()
                     done.record(cur)
                     self.deferred = dict(status=block, event=done, cache=cache, regions=regions, limited=True, size=(P, W, H, True))
