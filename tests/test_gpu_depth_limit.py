@@ -367,3 +367,27 @@ def test_graphed_step_with_stale_limits_falls_back(hip, step_form):
     d = (a.model.flat - b.model.flat).double()
     assert float(d.pow(2).mean().sqrt()) <= 1e-4 * float(a.model.flat.double().pow(2).mean().sqrt())
     assert abs(la[-1] - lb[-1]) <= 1e-3 * la[-1]
+
+
+def test_status_block_from_the_forwards_last_kernel_is_the_copied_one(hip):
+    """GsScratch.status_host (the forward's last kernel writes the status words into the pinned block) against
+    gs_forward_status (a copy command behind the forward): the deferred, depth-limited run - verdicts, fall-backs, every
+    parameter bit - is the same run."""
+    runs = []
+    old = hip.STATUS_IN_RENDER
+    try:
+        for flag in (True, False):
+            hip.STATUS_IN_RENDER = flag
+            hip._cam_cache.clear()
+            t = make(hip)
+            t.depth_limit = "deferred"
+            used0, failed0 = hip.depth_limit_stats["used"], hip.depth_limit_stats["failed"]
+            losses = [t.step(k) for k in range(14)]
+            t.sync()
+            runs.append(([float(x) for x in losses], t.model.flat.detach().clone(), t.model.denom.clone(),
+                         hip.depth_limit_stats["used"] - used0, hip.depth_limit_stats["failed"] - failed0))
+    finally:
+        hip.STATUS_IN_RENDER = old
+    a, b = runs
+    assert a[3] == b[3] >= 8   # (fall-backs may differ by one: the first run also sizes the binning capacity of limited views)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])

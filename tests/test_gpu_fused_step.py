@@ -360,3 +360,25 @@ def test_dormant_blocks_are_skipped_without_changing_a_bit(hip, two_phase):
     assert 0.3 * n_blocks < int(kept.sum()) < n_blocks, (int(kept.sum()), n_blocks)   # the skip really happened
     assert int(derived.sum()) >= int(kept.sum())
     assert float(sa["denom"].max()) >= 2.0
+
+
+def test_rows_in_spatial_order_train_the_same_model(hip):
+    """GaussianModelLite(spatial_order=True) is a permutation of the rows: the renders are the same images (up to the order of
+    equal-depth neighbours in a tile), so the run is the same run - losses to rounding, every Gaussian's parameters after the
+    permutation is undone."""
+    a = make(hip, True, P=40000, n_cams=4)
+    b = make(hip, True, P=40000, n_cams=4, spatial_order=True)
+    from simple_knn._C import distCUDA2
+    sc = synthetic.trained_like(40000, seed=3, sh_degree=3, knn=lambda x: distCUDA2(x.to("cuda")).cpu())
+    perm = synthetic.morton_order(sc["means3D"]).cuda()
+    assert torch.equal(a.model.params["xyz"].detach()[perm], b.model.params["xyz"].detach())
+    la = [float(a.step(k)) for k in range(12)]
+    lb = [float(b.step(k)) for k in range(12)]
+    assert max(abs(x - y) for x, y in zip(la, lb)) <= 1e-4 * max(la), (la, lb)
+    for name, n in a.model.fields:
+        pa = a.model.params[name].detach().reshape(a.model.P, n)[perm].double()
+        pb = b.model.params[name].detach().reshape(b.model.P, n).double()
+        # (the bar of two runs that differ in rounding only - test_fused_train_step_tracks_the_unfused_one: Adam turns a last-bit
+        #  difference of a tiny gradient into a step of the learning rate)
+        assert float((pa - pb).pow(2).mean().sqrt()) <= 1e-4 * float(pa.pow(2).mean().sqrt()) + 1e-9, name
+    assert torch.equal(a.model.denom[perm], b.model.denom)
