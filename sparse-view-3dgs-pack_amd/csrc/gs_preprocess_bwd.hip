@@ -598,9 +598,12 @@ int launch_preprocess_bwd_step(const PreprocessBwdArgs& a, const StepArgs& sa, h
   const dim3 grid((a.P + GS_BLOCK - 1) / GS_BLOCK), block(GS_BLOCK);
   if (sa.phase == 1) {
     const int nblocks = (int)grid.x;
-    // grid of the throttled kernel (C3, 1 M Gaussians: 320 / 384 / 448 / 512 / 640 workgroups -> step 1.01 / 0.975 / 0.996 /
-    // 0.995 / 1.02 ms; C4, 2 M - the stream outlasts the blend: 384 / 512 / 768 -> 1.379 / 1.336 / 1.337 ms)
-    int wgs = sa.phase1_workgroups > 0 ? sa.phase1_workgroups : (nblocks >= 5860 ? 512 : 384);
+    // grid of the throttled kernel.  Round 3 (round-robin blocks, every block streamed): C3 320 / 384 / 448 / 512 / 640 workgroups
+    // -> step 1.01 / 0.975 / 0.996 / 0.995 / 1.02 ms, C4 (2 M) 384 / 512 / 768 -> 1.379 / 1.336 / 1.337: 384 below 1.5 M, 512 above.
+    // Round 4 (block cursor, dormant blocks skipped, rows in spatial order - profiles/r04_side_kernel_experiments.txt):
+    // C3 256 / 320 / 384 / 512 / 640 -> 0.914 / 0.911 / 0.912 / 0.929 / 0.938 ms; C4 256 / 320 / 384 / 448 / 512 / 640 / 768 ->
+    // 1.093 / 1.061-1.067 / 1.092 / 1.107 / 1.113 / 1.116 / 1.135: 320 at every size.
+    int wgs = sa.phase1_workgroups > 0 ? sa.phase1_workgroups : 320;
     if (wgs > nblocks) wgs = nblocks;
     hipLaunchKernelGGL(step_uninstanced_kernel, dim3(wgs), block, 0, s, a, sa, nblocks);
   } else if (sa.phase == 2) hipLaunchKernelGGL(preprocess_bwd_step_kernel<2>, grid, block, 0, s, a, sa);
