@@ -82,21 +82,36 @@ __global__ void __launch_bounds__(RB_THREADS) region_bin_kernel(GeomHeader* hdr,
     s_key[i] = k;
   }
   __syncthreads();
-  // ---- bitonic sort, ascending (keys are unique: an index appears once per region)
-  for (uint32_t k = 2; k <= n_pad; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = tid; i < (n_pad >> 1); i += RB_THREADS) {
-        const uint32_t lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-        const uint32_t hi = lo | j;
-        const unsigned long long a = s_key[lo], b = s_key[hi];
-        const bool up = (lo & k) == 0u;
-        if ((a > b) == up) {
-          s_key[lo] = b;
-          s_key[hi] = a;
-        }
+  // ---- bitonic sort, ascending (keys are unique: an index appears once per region).
+  // Pair i of a step with distance j <= 64 lies inside the 128-element chunk i / 64 - and the 64 pairs of a chunk are one wave's
+  // (i = tid + t * RB_THREADS: chunk = wave + 16 t).  So the steps with j <= 64 of a stage run back to back inside each wave
+  // (LDS operations of a wave execute in order; the compiler is told not to move them) and only the steps with j >= 128
+  // need the workgroup barrier: 14 barriers instead of 66 for 2 048 entries, 27 instead of 91 for 8 192.
+  auto step = [&](uint32_t k, uint32_t j) {
+    for (uint32_t i = tid; i < (n_pad >> 1); i += RB_THREADS) {
+      const uint32_t lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+      const uint32_t hi = lo | j;
+      const unsigned long long a = s_key[lo], b = s_key[hi];
+      const bool up = (lo & k) == 0u;
+      if ((a > b) == up) {
+        s_key[lo] = b;
+        s_key[hi] = a;
       }
+    }
+  };
+  for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+    uint32_t j = k >> 1;
+    for (; j > 64; j >>= 1) {
+      step(k, j);
       __syncthreads();
     }
+    for (; j > 0; j >>= 1) {   // inside the wave's own chunks
+      step(k, j);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (k >= 128u || k == n_pad) __syncthreads();   // (the next stage's first steps - or the pass below - read other waves' chunks)
   }
   // ---- tile mask of every entry: bit 4 k + c = tile (4 ry + k, 4 rx + c)
   for (uint32_t e = tid; e < n; e += RB_THREADS) {
