@@ -141,7 +141,9 @@ typedef struct GsScratch {
                                       gs_forward_render* then only blends.  Written by the library: gs_forward_geometry
                                       clears it (a new geometry state invalidates any lists), gs_forward_bin sets it - a
                                       caller that re-uses one GsScratch across views need not touch it */
-  int32_t _pad;
+  int32_t defer_tile_order;        /* 1: gs_forward_render* stops after the blend; the caller runs gs_forward_tile_order (the forward's
+                                      last kernel: launch order of the backward, the camera's next hints / depth bounds, status_host)
+                                      itself - on another stream, beside whatever follows the forward, ordered before gs_backward* */
   const uint32_t* step_tag;        /* optional, device: gs_forward_status then copies TWELVE words out - the four status words,
                                       four reserved ones, *step_tag, three reserved - so that a caller that replays a
                                       captured graph of the step can tell, by polling its pinned block for the tag it
@@ -422,6 +424,9 @@ int gs_export_tile_stop_depth(const GsScratch* scratch, int32_t W, int32_t H, fl
   ((((uint32_t)(tag)) * 2654435761u) ^ (((uint32_t)(num_rendered)) * 40503u) ^ (((uint32_t)(overflow)) << 30) ^ \
    (((uint32_t)(trunc_failed)) << 31) ^ 0x5bd1e995u)
 int gs_forward_status(const GsScratch* scratch, uint32_t* out /*[4] or [12] host*/, void* stream);
+/* The last kernel of gs_forward_render* on its own (GsScratch.defer_tile_order = 1): same arguments, any stream that is ordered
+ * after the render's. */
+int gs_forward_tile_order(const GsView* view, const GsScratch* scratch, void* stream);
 /* Developer statistics of the last forward on this scratch: what the backward blend's loop meets.  out (device, 8 x u64,
  * zeroed by the caller) += [entries visited, entries with a valid pixel, (entry, quadrant) pairs with a valid pixel,
  * valid (entry, pixel) pairs, tiles with work, list entries of those tiles, 0, 0].  tests/tools/blend_stats.py */

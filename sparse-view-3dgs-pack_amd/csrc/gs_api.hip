@@ -292,7 +292,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
                            sc->tile_order_hint, sc->tile_depth_limit, iv.tile_stop_depth, &gv.hdr->trunc_failed, out_color,
                            out_invdepth, out_extra, fsgs, v->tile_cull ? 0 : 1, s);
   }
-  {
+  if (!sc->defer_tile_order) {
     GS_PROF(ST_TILE_ORDER, s);
     launch_tile_order(iv.tile_work, iv.tile_order, (int)T, sc->tile_order_out, iv.tile_stop_depth, sc->tile_depth_limit_out, gx, gy,
                       gv.hdr, s, sc->tile_depth_limit_slack, sc->status_host, sc->step_tag);
@@ -692,6 +692,23 @@ __global__ void status_tag_kernel(GeomHeader* hdr, const uint32_t* __restrict__ 
   const uint32_t t = *tag;
   hdr->step_tag = t;
   hdr->pad[0] = gs_status_check(t, hdr->num_rendered, hdr->overflow, hdr->trunc_failed);
+}
+
+int gs_forward_tile_order(const GsView* v, const GsScratch* sc, void* stream) {
+  if (!v || !sc || !sc->geom || !sc->img) return GS_E_NULL;
+  const int W = v->image_width, H = v->image_height;
+  if (W <= 0 || H <= 0) return GS_E_SHAPE;
+  int gx, gy;
+  tile_grid(v, gx, gy);
+  const size_t T = (size_t)gx * gy, N = (size_t)W * H;
+  if (sc->img_bytes < img_bytes(N, T) || sc->geom_bytes < sizeof(GeomHeader)) return GS_E_SCRATCH;
+  hipStream_t s = (hipStream_t)stream;
+  ImgView iv = img_view(sc->img, N, T);
+  GS_PROF(ST_TILE_ORDER, s);
+  launch_tile_order(iv.tile_work, iv.tile_order, (int)T, sc->tile_order_out, iv.tile_stop_depth, sc->tile_depth_limit_out, gx, gy,
+                    (const GeomHeader*)sc->geom, s, sc->tile_depth_limit_slack, sc->status_host, sc->step_tag);
+  GS_LAUNCH_CHECK(s, v->debug);
+  return GS_OK;
 }
 
 int gs_forward_status(const GsScratch* sc, uint32_t* out, void* stream) {

@@ -61,7 +61,7 @@ class GsScratch(C.Structure):
         ("tile_order_out", C.c_void_p),
         ("tile_depth_limit_out", C.c_void_p),
         ("binned", C.c_int32),
-        ("_pad", C.c_int32),
+        ("defer_tile_order", C.c_int32),
         ("step_tag", C.c_void_p),
         ("tile_depth_limit_slack", C.c_void_p),
         ("status_host", C.c_void_p),
@@ -146,6 +146,7 @@ PROTOTYPES = {
     "export_tile_order": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _P, _P]),
     "export_tile_stop_depth": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _P, _P]),
     "forward_status": (C.c_int, [C.POINTER(GsScratch), _P, _P]),
+    "forward_tile_order": (C.c_int, [C.POINTER(GsView), C.POINTER(GsScratch), _P]),
     "forward_bin": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P]),
     "export_binning_region": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _I64, _P, _P, _P]),
     "debug_blend_stats": (C.c_int, [C.POINTER(GsScratch), _I32, _I32, _I32, _P, _P]),
@@ -199,7 +200,7 @@ PROTOTYPES = {
 # (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
 # reference's two 3-channel passes, so the checker does not need it)
 DEVICE_ONLY = ("backward_step", "backward_step_x", "step_uninstanced", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "adam_step_gated", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
-               "forward_render_x", "backward_x")
+               "forward_render_x", "backward_x", "forward_tile_order")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}
 

@@ -392,6 +392,17 @@ class RasterBackend:
     # written into the pinned host block by the forward's own last kernel (GsScratch.status_host) instead of by a copy
     # command behind it - one launch less on the stream.  GS_STATUS_IN_RENDER=0: gs_forward_status as before.
     STATUS_IN_RENDER = os.environ.get("GS_STATUS_IN_RENDER", "1") != "0"
+    # Train step (a fused step is armed): the forward's last kernel (tile_order: the backward's launch order, the camera's next
+    # hints and depth bounds, the status block) is issued on the SIDE stream - nothing before the backward blend needs it, so
+    # it runs beside the criterion's first kernel instead of in front of it (GsScratch.defer_tile_order +
+    # gs_forward_tile_order); the backward waits for it.  GS_SPLIT_TILE_ORDER=0: in line, as the plain forward does.
+    SPLIT_TILE_ORDER = os.environ.get("GS_SPLIT_TILE_ORDER", "1") != "0"
+
+    def _side_stream(self, device):
+        side = self._side_streams.get(device.index)
+        if side is None:
+            side = self._side_streams[device.index] = torch.cuda.Stream(device=device)
+        return side
     TWO_PHASE = os.environ.get("GS_TWO_PHASE_STEP", "1") != "0"
     TWO_PHASE_MIN_P = 100_000
 
@@ -452,11 +463,9 @@ class RasterBackend:
 
     def _launch_uninstanced(self, device, view, g, radii, s, step):
         main = torch.cuda.current_stream(device)
-        side = self._side_streams.get(device.index)
-        if side is None:
-            # (a CU-masked side stream - hipExtStreamCreateWithCUMask, 64 / 96 / 128 CUs - was tried in round 4: the two
-            #  queues then did not overlap at all, every kernel of the step ran ~10 % slower, step 0.98 -> 1.18-1.20 ms)
-            side = self._side_streams[device.index] = torch.cuda.Stream(device=device)
+        # (a CU-masked side stream - hipExtStreamCreateWithCUMask, 64 / 96 / 128 CUs - was tried in round 4: the two
+        #  queues then did not overlap at all, every kernel of the step ran ~10 % slower, step 0.98 -> 1.18-1.20 ms)
+        side = self._side_stream(device)
         side.wait_stream(main)   # (the forward has decided overflow / trunc_failed)
         with torch.cuda.stream(side):
             self.api.call("step_uninstanced", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),
@@ -505,6 +514,8 @@ class RasterBackend:
             raise RuntimeError("raw activations do not serve the FSGS rasterizer generation")
         if (extra_gain is not None) != (raw and extra is not None):
             raise RuntimeError("extra_gain goes with a RAW 4th channel (raw activations), and only with it")
+        if device.type == "cuda":
+            self._join_tile_order(device)   # (a forward whose backward never ran: its hints must be complete before this one reads them)
         cache = self._camera_cache(device, W, H, viewmatrix)
         static = self.static_capacity is not None
         use_order = cache is not None and self.order_hint_on
@@ -697,7 +708,8 @@ class RasterBackend:
             self.api.call("forward_bin", C.byref(view), C.byref(g), C.byref(s), None, stream)
             if self.STATUS_IN_RENDER:
                 s.status_host = status.data_ptr()   # the forward's last kernel delivers the status block (+ tag) itself
-            render(s)
+            render(s)   # (tile_order stays in line here: inside a captured graph the extra cross-stream edge costs more than the
+            #              kernel it takes off the chain - C3 replay 0.96 -> 1.00 ms; the eager step below gains 6-10 us)
             if limit is not None:
                 self.depth_limit_stats["used"] += 1
             if not self.STATUS_IN_RENDER:
@@ -725,12 +737,16 @@ class RasterBackend:
                     ring[1] += 1
                     if self.STATUS_IN_RENDER:   # the forward's last kernel writes the status words into the pinned block
                         s.status_host = block.data_ptr()
+                    split = self._split_tile_order(s)
                     render(s)
                     self.depth_limit_stats["used"] += 1
                     if not self.STATUS_IN_RENDER:
                         self.api.call("forward_status", C.byref(s), block.data_ptr(), stream)
-                    done = torch.cuda.Event()
-                    done.record(cur)
+                    if split:
+                        done = self._tile_order_on_side(view, s, cur)   # (the status block arrives with that kernel)
+                    else:
+                        done = torch.cuda.Event()
+                        done.record(cur)
                     self.deferred = dict(status=block, event=done, cache=cache, regions=regions, limited=True, size=(P, W, H, True))
                     remember(s)
                     return cap, binning
@@ -767,6 +783,34 @@ class RasterBackend:
             remember(s)
             return num_rendered, binning
 
+    def _split_tile_order(self, scratch):
+        """Arm GsScratch.defer_tile_order for the render about to be issued?  Only inside a train step (a fused step is armed:
+        its backward is what waits for the side launch) and only with the status delivered by that kernel."""
+        if not (self.SPLIT_TILE_ORDER and self.fused_step is not None and self.STATUS_IN_RENDER):
+            return False
+        scratch.defer_tile_order = 1
+        return True
+
+    def _tile_order_on_side(self, view, scratch, main):
+        """gs_forward_tile_order on the side stream, ordered behind the render just issued on `main`; the event it returns (also
+        kept in _tile_order_done) is what the backward - and any later forward - waits for."""
+        side = self._side_stream(main.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self.api.call("forward_tile_order", C.byref(view), C.byref(scratch), C.c_void_p(side.cuda_stream))
+            done = torch.cuda.Event()
+            done.record(side)
+        self._tile_order_done = done
+        return done
+
+    def _join_tile_order(self, device):
+        """Order the current stream behind a tile_order still pending on the side stream (no-op otherwise)."""
+        done, self._tile_order_done = getattr(self, "_tile_order_done", None), None
+        if done is not None:
+            torch.cuda.current_stream(device).wait_event(done)
+
     def _render(self, scratch, fsgs, extra, view, g, out_color, out_invdepth, out_extra, stream):
         if fsgs:
             self.api.call("forward_render_fsgs", C.byref(view), C.byref(g), C.byref(scratch), out_color.data_ptr(),
@@ -794,6 +838,8 @@ class RasterBackend:
         P = int(means3D.shape[0])
         H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
         self._region_key = None
+        if device.type == "cuda":
+            self._join_tile_order(device)   # (the blend backward reads the launch order that kernel writes)
         M = int(sh.shape[1]) if (sh is not None and sh.numel() != 0) else 0
         f32 = dict(dtype=torch.float32, device=device)
         # every row is written by gs_backward (culled rows become 0): empty, not zeros
