@@ -81,9 +81,10 @@ SCENES = {
 }
 
 
-# The model keeps its rows in Morton order of the Gaussians' centres (GaussianModelLite(spatial_order=True): a permutation of
-# the same scene, applied at construction and after every densification); GS_BENCH_SPATIAL_ORDER=0 = rows as generated.
-SPATIAL_ORDER = os.environ.get("GS_BENCH_SPATIAL_ORDER", "1") != "0"
+# The model keeps its rows in Morton order of the Gaussians' centres (GaussianModelLite.spatial_order - the model's own default from
+# 100 000 Gaussians on: a permutation of the same scene, applied at construction and after every densification);
+# GS_BENCH_SPATIAL_ORDER=0 / 1 = rows as generated / ordered at every size.
+SPATIAL_ORDER = None if os.environ.get("GS_BENCH_SPATIAL_ORDER", "") not in ("0", "1") else os.environ["GS_BENCH_SPATIAL_ORDER"] == "1"
 
 
 def build_workload(cfg, device, rank, world, seed=0, scene_kind="trained_like", gts=None):
@@ -875,8 +876,9 @@ def main():
             "config": {"workload": desc, "gaussians": P, "image": "%dx%d" % (W, H),
                        "scene": SCENES[main_scene]["what"], "sh_degree": SCENES[main_scene]["sh_degree"], "cameras_per_step": world,
                        "dormant_blocks": dormant_info,
-                       "row_order": ("Morton order of the centres (GaussianModelLite(spatial_order=True): a permutation of the "
-                                     "generated scene; GS_BENCH_SPATIAL_ORDER=0 = as generated)" if SPATIAL_ORDER else "as generated"),
+                       "row_order": ("Morton order of the centres (GaussianModelLite.spatial_order, the model's default from 100 000 "
+                                     "Gaussians on: a permutation of the generated scene; GS_BENCH_SPATIAL_ORDER=0 = as generated)"
+                                     if getattr(tr.model, "spatial_order", False) else "as generated"),
                        # which instance lists the timed step renders from, and the same step on the reference's own lists
                        "lists": ("depth-limited (exact, verified per view: csrc/gs_tilecull.h, tests/test_gpu_fullsize.py::"
                                  "test_c3_benched_step_is_the_unlimited_run)" if depth_limit else

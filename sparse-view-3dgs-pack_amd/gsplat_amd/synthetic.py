@@ -195,11 +195,11 @@ def ball_in_shell(P, seed=0, knn=None, sh_degree=3, ball_radius=0.8, shell_radiu
 
 def morton_order(xyz, bits=10):
     """Permutation that sorts points along the 3-D Morton (Z-order) curve of their bounding box (`bits` per axis): rows that
-    are neighbours in memory are neighbours in space.  xyz: [P, 3] tensor -> LongTensor [P] (stable: ties keep their order)."""
-    x = xyz.detach().to("cpu", torch.float64)
+    are neighbours in memory are neighbours in space.  xyz: [P, 3] tensor -> int64 tensor [P] on xyz's device (stable: ties keep their order)."""
+    x = xyz.detach().to(torch.float64)   # (on the tensor's own device: a million points are a millisecond on the GPU)
     lo, hi = x.min(dim=0).values, x.max(dim=0).values
     q = ((x - lo) / (hi - lo).clamp_min(1e-30) * ((1 << bits) - 1)).round().to(torch.int64).clamp_(0, (1 << bits) - 1)
-    code = torch.zeros((x.shape[0],), dtype=torch.int64)
+    code = torch.zeros((x.shape[0],), dtype=torch.int64, device=x.device)
     for b in range(bits):
         for a in range(3):
             code |= ((q[:, a] >> b) & 1) << (3 * b + a)

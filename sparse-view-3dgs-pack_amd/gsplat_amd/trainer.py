@@ -308,6 +308,8 @@ class _FusedActivations(torch.autograd.Function):
 class GaussianModelLite:
     """Raw (pre-activation) parameters of P Gaussians at max SH degree 3."""
 
+    SPATIAL_ORDER_MIN_P = 100_000
+
     def __init__(self, scene, device, spatial_lr_scale=1.0, api=None, with_nir=False, spatial_order=None):
         """scene: dict of ACTIVATED tensors as produced by gsplat_amd.synthetic (means3D, scales,
         rotations, opacities, shs[P,16,3]) - converted back to raw form as create_from_pcd would hold them.
@@ -315,10 +317,12 @@ class GaussianModelLite:
         spatial_order: keep the rows in Morton order of the centres (here, and again after every densification): rows that
         are neighbours in memory are neighbours in space, so whole wavefronts / 256-row blocks are culled, depth-limited
         away, stepped or skipped (FlatAdam.dormant_flags) together.  The model is the same set of Gaussians; only which row
-        holds which one differs from the reference's [survivors, clones, split samples] order.  Default: GS_SPATIAL_ORDER
-        (off)."""
+        holds which one differs from the reference's [survivors, clones, split samples] order.  Default (None): on from
+        SPATIAL_ORDER_MIN_P = 100 000 Gaussians - below, a step is launch-bound and the row order buys nothing -;
+        GS_SPATIAL_ORDER=0 / 1 forces it off / on for models that do not say."""
         if spatial_order is None:
-            spatial_order = __import__("os").environ.get("GS_SPATIAL_ORDER", "0") == "1"
+            env = __import__("os").environ.get("GS_SPATIAL_ORDER", "")
+            spatial_order = (env == "1") if env in ("0", "1") else int(scene["means3D"].shape[0]) >= self.SPATIAL_ORDER_MIN_P
         self.spatial_order = bool(spatial_order)
         if self.spatial_order:
             from . import synthetic
@@ -599,7 +603,7 @@ class GaussianModelLite:
             self._relayout(src, new)
             if getattr(self, "spatial_order", False):   # the new rows go where their neighbours are
                 from . import synthetic
-                self._relayout(synthetic.morton_order(self.params["xyz"]).to(self.device), {})
+                self._relayout(synthetic.morton_order(self.params["xyz"]), {})
             self.xyz_gradient_accum = torch.zeros((self.P, 1), device=self.device)
             self.denom = torch.zeros((self.P, 1), device=self.device)
             self.max_radii2D = torch.zeros((self.P,), device=self.device)
