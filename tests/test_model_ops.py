@@ -82,7 +82,9 @@ def test_trainer_fused_path_equals_torch_path(oracle):
     assert float((a.model.flat_grad - m.flat_grad).abs().max()) <= 2e-6 * float(m.flat_grad.abs().max())
     ref = stats_reference(pkg["radii"], pkg["viewspace_points"].grad, torch.zeros(300), torch.zeros((300, 1)), torch.zeros((300, 1)))
     assert torch.equal(a.model.max_radii2D, ref[0]) and torch.equal(a.model.denom, ref[2])
-    assert torch.allclose(a.model.xyz_gradient_accum, ref[1], rtol=1e-5, atol=1e-12)
+    # (atol: a gradient that is ~1e-11 on one path and exactly 0 on the other - the oracle's OpenMP partition depends on the host's
+    #  thread count; seen with 128 threads)
+    assert torch.allclose(a.model.xyz_gradient_accum, ref[1], rtol=1e-5, atol=1e-9)
 
 
 @pytest.mark.gpu
