@@ -397,6 +397,7 @@ class RasterBackend:
     # it runs beside the criterion's first kernel instead of in front of it (GsScratch.defer_tile_order +
     # gs_forward_tile_order); the backward waits for it.  GS_SPLIT_TILE_ORDER=0: in line, as the plain forward does.
     SPLIT_TILE_ORDER = os.environ.get("GS_SPLIT_TILE_ORDER", "1") != "0"
+    REUSE_BUILT = os.environ.get("GS_REUSE_BUILT", "1") != "0"   # the forward's GsView / GsGaussians structs serve its backward too
 
     def _side_stream(self, device):
         side = self._side_streams.get(device.index)
@@ -449,12 +450,16 @@ class RasterBackend:
         (bg, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx,
          tanfovy, H, W, scale_modifier, degree, antialiasing, debug) = e["args"]
         device = means3D.device
-        keep = []
         self._region_key = None
-        view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier, degree,
-                          False, antialiasing, debug)
-        g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, e["extra"],
-                        raw=e["raw"], extra_gain=e["extra_gain"])
+        built = getattr(self, "_built", None)
+        if self.REUSE_BUILT and built is not None and built["geom"] == e["geom"].data_ptr() and built["raw"] == e["raw"]:
+            view, g, keep = built["view"], built["g"], built["keep"]
+        else:
+            keep = []
+            view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier, degree,
+                              False, antialiasing, debug)
+            g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, e["extra"],
+                            raw=e["raw"], extra_gain=e["extra_gain"])
         empty = torch.empty((0,), dtype=torch.uint8, device=device)
         s = self._scratch(e["geom"], e["img"], empty, 0)
         e["done"] = self._launch_uninstanced(device, view, g, e["radii"], s, e["step"])
@@ -567,6 +572,9 @@ class RasterBackend:
         geom = torch.empty((gb,), **u8)
         img = torch.empty((ib,), **u8)
         empty = torch.empty((0,), **u8)
+        # (the train step's side launch and its backward describe the same view and the same Gaussians: they take these
+        #  structs - and the tensors `keep` holds alive - instead of building them again; keyed by this forward's geometry buffer)
+        self._built = dict(geom=geom.data_ptr(), view=view, g=g, keep=keep, raw=raw)
 
         def new_binning(cap):
             _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
@@ -852,11 +860,15 @@ class RasterBackend:
         if step is not None and P != 0:
             if fsgs:
                 raise RuntimeError("the fused train-step backward does not serve the FSGS rasterizer generation")
-            keep = []
-            view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
-                              degree, False, antialiasing, debug)
-            g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra, raw=raw,
-                            extra_gain=extra_gain)
+            built = getattr(self, "_built", None)
+            if self.REUSE_BUILT and built is not None and built["geom"] == geomBuffer.data_ptr() and built["raw"] == raw:
+                view, g, keep = built["view"], built["g"], built["keep"]   # (this view's forward built them: same pointers)
+            else:
+                keep = []
+                view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
+                                  degree, False, antialiasing, debug)
+                g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra,
+                                raw=raw, extra_gain=extra_gain)
             if extra is not None:
                 dL_dout_extra = torch.zeros((1, H, W), **f32) if dL_dout_extra is None else _prep(dL_dout_extra, device)
             dL_dout_color = _prep(dL_dout_color, device)
