@@ -472,11 +472,10 @@ class RasterBackend:
         #  queues then did not overlap at all, every kernel of the step ran ~10 % slower, step 0.98 -> 1.18-1.20 ms)
         side = self._side_stream(device)
         side.wait_stream(main)   # (the forward has decided overflow / trunc_failed)
-        with torch.cuda.stream(side):
-            self.api.call("step_uninstanced", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),
-                          C.byref(step), C.c_void_p(side.cuda_stream))
-            done = torch.cuda.Event()
-            done.record(side)
+        self.api.call("step_uninstanced", C.byref(view), C.byref(g), radii.contiguous().data_ptr(), C.byref(s),
+                      C.byref(step), C.c_void_p(side.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(side)
         self.two_phase_launches += 1
         return done
 
@@ -806,10 +805,11 @@ class RasterBackend:
         ev = torch.cuda.Event()
         ev.record(main)
         side.wait_event(ev)
-        with torch.cuda.stream(side):
-            self.api.call("forward_tile_order", C.byref(view), C.byref(scratch), C.c_void_p(side.cuda_stream))
-            done = torch.cuda.Event()
-            done.record(side)
+        # (no `with torch.cuda.stream(side)`: the call takes the stream, the event records on it - the context switch alone
+        #  is ~20 us of host time per step)
+        self.api.call("forward_tile_order", C.byref(view), C.byref(scratch), C.c_void_p(side.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(side)
         self._tile_order_done = done
         return done
 

@@ -239,11 +239,17 @@ class FlatAdam:
         st = GsStepState()
         if coef_dev is not None:
             st.coef_dev = coef_dev.data_ptr()
-        p, ea, eas = self.field_views(m.flat), self.field_views(self.exp_avg), self.field_views(self.exp_avg_sq)
         names = ("xyz", "features", "opacity", "scaling", "rotation")
+        # (the eighteen row addresses only change when the buffers do: a re-layout, a restore - not every step)
+        key = (m.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), m.P)
+        ptrs = getattr(self, "_row_ptrs", None)
+        if ptrs is None or ptrs[0] != key:
+            p, ea, eas = self.field_views(m.flat), self.field_views(self.exp_avg), self.field_views(self.exp_avg_sq)
+            ptrs = self._row_ptrs = (key, [(p[n].data_ptr(), ea[n].data_ptr(), eas[n].data_ptr()) for n in names])
         for k, name in enumerate(names):
-            setattr(st, name, p[name].data_ptr())
-            st.m[k], st.v[k] = ea[name].data_ptr(), eas[name].data_ptr()
+            pp, pm, pv = ptrs[1][k]
+            setattr(st, name, pp)
+            st.m[k], st.v[k] = pm, pv
             st.step[k] = 0 if name in skip else (self.seg_steps[name] if self.seg_steps[name] > 0 else self.t)
         for k, name in enumerate(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")):
             st.lr[k] = self.lr[name]
