@@ -423,9 +423,12 @@ class LGDWTCriterion:
                 pass
         return s
 
-    def fused_call(self, raw_image, gt_image, mask=None):
+    def fused_call(self, raw_image, gt_image, mask=None, manual_ctx=None):
         """Criterion on the rasterizer's raw output (the clamp of gaussian_renderer/__init__.py:119 is applied -
-        and differentiated - inside).  Returns (loss, parts) like __call__."""
+        and differentiated - inside).  Returns (loss, parts) like __call__.
+        manual_ctx: an object that stands in for the autograd context - the node's forward runs under no_grad and the caller
+        calls FusedLGDWTLoss.backward(manual_ctx, seed, None) itself (gsplat_amd.trainer: the train step without the autograd
+        engine)."""
         key = tuple(raw_image.shape)
         fp = self._fp.get(key)
         if fp is None:
@@ -442,7 +445,11 @@ class LGDWTCriterion:
             if mask is None:
                 mask = self._no_mask[dev] = torch.zeros((1,), dtype=torch.uint8, device=dev)
             sums = self.sums_for(None, dev)
-        loss, out = FusedLGDWTLoss.apply(self.ops, raw_image, gt_image, mask, sums, self.dwt_running_mean, fp)
+        if manual_ctx is not None:
+            with torch.no_grad():
+                loss, out = FusedLGDWTLoss.forward(manual_ctx, self.ops, raw_image, gt_image, mask, sums, self.dwt_running_mean, fp)
+        else:
+            loss, out = FusedLGDWTLoss.apply(self.ops, raw_image, gt_image, mask, sums, self.dwt_running_mean, fp)
         parts = {"l1": out[5], "ssim": out[6], "dwt": out[2], "dwt_scale": out[4], "patch": out[3], "base": out[1],
                  "running_mean_before": out[7:8]}
         return loss, parts

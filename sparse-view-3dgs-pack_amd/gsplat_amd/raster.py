@@ -61,6 +61,7 @@ class RasterBackend:
         self.last_deferred_num_rendered = None  # instance count of the last deferred forward whose verdict was collected
         self._region_off = set()   # (P, W, H, limited lists?) whose regions hold more Gaussians than one workgroup sorts: LSD path
         self._cap_memo = {}
+        self._scratch_memo = {}
         self._cap_by_buffer = {}
         self._cam_cache = {}
         # one-shot identity of the camera of the NEXT forward (GaussianRasterizer.camera_key); None = hash the view matrix
@@ -255,10 +256,18 @@ class RasterBackend:
         return self._capacity_of(P, W, H, binning.numel(), R)
 
     def scratch_bytes(self, P, W, H, R):
-        out = (C.c_size_t * 3)()
-        ws = C.c_size_t(0)
-        self.api.call("scratch_bytes", P, W, H, R, out, C.byref(ws))
-        return out[0], out[1], out[2], ws.value
+        # (a pure function of four integers, asked two or three times per forward and once per backward: remembered)
+        key = (int(P), int(W), int(H), int(R))
+        memo = self._scratch_memo
+        got = memo.get(key)
+        if got is None:
+            out = (C.c_size_t * 3)()
+            ws = C.c_size_t(0)
+            self.api.call("scratch_bytes", P, W, H, R, out, C.byref(ws))
+            if len(memo) > 256:
+                memo.clear()
+            got = memo[key] = (out[0], out[1], out[2], ws.value)
+        return got
 
     def _camera_identity(self, viewmatrix):
         """Who is this camera?  An explicit key when the caller gave one (GaussianRasterizer.camera_key), else a hash of the

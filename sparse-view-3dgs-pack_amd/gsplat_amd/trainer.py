@@ -1016,6 +1016,62 @@ class Trainer:
         be = getattr(getattr(self.Rasterizer, "_fn", None), "_impl", None)
         return getattr(be, "backend", None)
 
+    # The single-GPU fused step without the autograd engine: its graph is two custom nodes in a row (rasterizer, criterion) whose
+    # gradients end inside gs_backward_step, so the step calls their forward / backward bodies itself (a stand-in context
+    # object each) - no graph construction, no engine thread hand-off: ~0.15 ms less host time per step, which is what
+    # keeps the eager step GPU-bound on slow hosts.  Same kernels, same arguments, same bits.  GS_MANUAL_BACKWARD=0: autograd.
+    MANUAL_BACKWARD = __import__("os").environ.get("GS_MANUAL_BACKWARD", "1") != "0"
+
+    class _ManualCtx:
+        """What a torch.autograd.Function's forward / backward use of their context, and nothing else."""
+
+        def __init__(self):
+            self.saved_tensors = ()
+
+        def save_for_backward(self, *tensors):
+            self.saved_tensors = tensors
+
+        def mark_non_differentiable(self, *a):
+            pass
+
+        def set_materialize_grads(self, v):
+            pass
+
+    def _manual_step_ok(self, fused_step, fused):
+        fn = getattr(self.Rasterizer, "_fn", None)
+        return (self.MANUAL_BACKWARD and fused_step and fused and self.model.exposure is None and fn is not None
+                and getattr(getattr(fn, "_impl", None), "backend", None) is not None
+                and type(self)._render_view is Trainer._render_view and type(self)._criterion_backward is Trainer._criterion_backward)
+
+    def _manual_step(self, ci, mask, backend, deferred):
+        """render -> criterion -> backward of the fused single-GPU step, by hand (see MANUAL_BACKWARD) -> (pkg, loss, parts,
+        the forward's deferred verdict or None)"""
+        m, cam = self.model, self.cameras[ci]
+        fn = self.Rasterizer._fn
+        rs = self.Settings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+            tanfovy=math.tan(cam.FoVy * 0.5), bg=self.bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=m.active_sh_degree, campos=cam.camera_center, prefiltered=False,
+            debug=False, antialiasing=False)
+        backend.camera_key = ("trainer", self.uid, ci)   # (as GaussianRasterizer.forward does with its camera_key)
+        backend.camera_key_limits = False
+        empty = getattr(self, "_empty_cpu", None)
+        if empty is None:
+            empty = self._empty_cpu = torch.Tensor([])
+        rctx, lctx = self._ManualCtx(), self._ManualCtx()
+        with torch.no_grad():
+            p = m.params
+            color, radii, depth = fn.forward(rctx, p["xyz"], None, p["features"], empty, p["opacity"], p["scaling"], p["rotation"],
+                                             empty, rs)
+            verdict = backend.take_deferred() if deferred else None
+            loss, parts = self.criterion.fused_call(color, self.gts[ci], mask=mask, manual_ctx=lctx)
+            self._arm_side_launch(backend.launch_uninstanced_early)
+            from .losses import FusedLGDWTLoss
+            grad_img = FusedLGDWTLoss.backward(lctx, self.criterion.ops.unit_grad(loss.device), None)[1]
+            fn.backward(rctx, grad_img, None, None)
+        pkg = {"render": color, "viewspace_points": None, "visibility_filter": None, "radii": radii, "depth": depth}
+        return pkg, loss, parts, verdict
+
     # -- what differs between the RGB step and the multispectral one (TrainerNIR)
     def _render_view(self, ci, fused, raw):
         m = self.model
@@ -1087,15 +1143,19 @@ class Trainer:
         elif backend is not None and hasattr(backend, "grad_arena") and not m.with_nir:
             m.arm_grad_arena(backend)
         fused = getattr(self.criterion, "fused", False)
-        pkg = self._render_view(ci, fused, (fused_step or fused_dp) and self.RAW_ACTIVATIONS)
         mask = None if self.masks is None else self.masks[ci]
-        verdict = backend.take_deferred() if deferred else None
         rm = None
-        if verdict is not None and not fused:
-            rm = getattr(self.criterion, "dwt_running_mean", None)
-            rm = None if rm is None else rm.clone()
-        loss, parts = self._criterion_backward(pkg, ci, mask, fused,
-                                               backend.launch_uninstanced_early if (fused_step and fused) else None)
+        if self.RAW_ACTIVATIONS and self._manual_step_ok(fused_step, fused):
+            # (the deferred verdict of THIS forward is picked up inside: the backend parks it when the forward returns)
+            pkg, loss, parts, verdict = self._manual_step(ci, mask, backend, deferred)
+        else:
+            pkg = self._render_view(ci, fused, (fused_step or fused_dp) and self.RAW_ACTIVATIONS)
+            verdict = backend.take_deferred() if deferred else None
+            if verdict is not None and not fused:
+                rm = getattr(self.criterion, "dwt_running_mean", None)
+                rm = None if rm is None else rm.clone()
+            loss, parts = self._criterion_backward(pkg, ci, mask, fused,
+                                                   backend.launch_uninstanced_early if (fused_step and fused) else None)
         radii = pkg["radii"]
         if fused_dp:
             # gradients, statistic increments and the validity flag are in the exchange buffer: reduce, then the gated

@@ -382,3 +382,21 @@ def test_rows_in_spatial_order_train_the_same_model(hip):
         #  difference of a tiny gradient into a step of the learning rate)
         assert float((pa - pb).pow(2).mean().sqrt()) <= 1e-4 * float(pa.pow(2).mean().sqrt()) + 1e-9, name
     assert torch.equal(a.model.denom[perm], b.model.denom)
+
+
+def test_step_without_the_autograd_engine_is_the_autograd_step(hip):
+    """Trainer.MANUAL_BACKWARD (the fused single-GPU step calls the two nodes' forward / backward bodies itself) against the same
+    step through torch.autograd: the same kernels with the same arguments - losses, parameters, moments, statistics bit for bit,
+    with deferred depth limits and the two-phase side launch in play."""
+    a, b = make(hip, True, P=120000, W=640, H=400, n_cams=4), make(hip, True, P=120000, W=640, H=400, n_cams=4)
+    a.MANUAL_BACKWARD, b.MANUAL_BACKWARD = True, False
+    a.depth_limit = b.depth_limit = "deferred"
+    la = [a.step(k) for k in range(12)]
+    lb = [b.step(k) for k in range(12)]
+    a.sync()
+    b.sync()
+    assert [float(x) for x in la] == [float(x) for x in lb]
+    sa, sb = state(a), state(b)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), (k, float((sa[k] - sb[k]).abs().max()))
+    assert a.model.optimizer.t == b.model.optimizer.t == 12
