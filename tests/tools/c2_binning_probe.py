@@ -1,3 +1,5 @@
+"""Developer tool: which binning path (regions / LSD) the C2-size train step takes on its limited views, and its stage times.
+   python tests/tools/c2_binning_probe.py"""
 import os, sys
 sys.path.insert(0, "/root/repo/sparse-view-3dgs-pack_amd"); sys.path.insert(0, "/root/repo")
 import torch, bench
