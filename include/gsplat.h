@@ -378,7 +378,11 @@ int gs_backward_step_x(const GsView* view, const GsGaussians* g, const int32_t* 
  * overflow or trunc_failed - so it must not start before the forward BLEND has finished.  Same element arithmetic: the
  * two calls together leave the bits gs_backward_step (phase 0) leaves.  With tile_cull = 0 every visible Gaussian has
  * instances, and the Gaussians without are the ones outside the frustum (59 % of bench.py's scene: with the rows in spatial
- * order most of their blocks are dormant, see GsStepState.dormant).  GS_E_UNSUPPORTED in the data-parallel form. */
+ * order most of their blocks are dormant, see GsStepState.dormant).  GS_E_UNSUPPORTED in the data-parallel form.
+ * Although `scratch` is const, the call WRITES one word of the geometry header it points at: the block cursor its
+ * workgroups draw their work from (zeroed by gs_forward_geometry, re-armed by the call's last workgroup).  Every call is
+ * therefore one full zero-gradient step of the uninstanced Gaussians - calling it twice behind one forward steps them
+ * twice; two calls on the SAME scratch must not overlap in time (they would share the cursor). */
 int gs_step_uninstanced(const GsView* view, const GsGaussians* g, const int32_t* radii,
                         const GsScratch* scratch, const GsStepState* st, void* stream);
 

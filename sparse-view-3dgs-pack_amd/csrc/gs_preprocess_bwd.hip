@@ -557,7 +557,13 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) step_uninstanced_kernel(Preproces
     if (tid == 0) s_blk = (int)atomicAdd(const_cast<uint32_t*>(&sa.hdr->pad[HDR_SIDE_CURSOR]), 1u);
     __syncthreads();
     const int blk = s_blk;
-    if (blk >= nblocks) break;
+    if (blk >= nblocks) {
+      // every workgroup draws exactly one ticket past the end: the one holding the last of the nblocks + gridDim.x tickets knows
+      // that nobody will draw again and re-arms the cursor - a second gs_step_uninstanced on the same geometry state (a retry,
+      // a probe that re-times the launch) then steps again instead of silently doing nothing
+      if (tid == 0 && blk == nblocks + (int)gridDim.x - 1) const_cast<uint32_t*>(sa.hdr->pad)[HDR_SIDE_CURSOR] = 0u;
+      break;
+    }
     const int idx = blk * GS_BLOCK + tid;
     const bool in_range = idx < a.P;
     const bool mine = in_range && a.tiles_touched[idx] == 0;

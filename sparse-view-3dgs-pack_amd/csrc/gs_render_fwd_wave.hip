@@ -11,9 +11,6 @@
 #include "gs_tilecull.h"
 
 #define WB 64
-#ifndef GS_FWD_SELECT
-#define GS_FWD_SELECT 0
-#endif
 
 // FSGS: the older rasterizer generation of FSGS / DNGaussian (-confidence fork, forward.cu:262-380): out_invdepth
 // receives depth = sum depth_i alpha_i T_i, out_extra receives alpha = sum alpha_i T_i.  The image state keeps the
@@ -129,51 +126,6 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
         if (ddx > k.w || ddy > a.w) continue;
       }
       const float4 co = s_c[j];
-#if GS_FWD_SELECT
-      // Round 4: the update of the four pixels without exec-mask regions.  A scalar instruction costs 2.7 vector issue slots
-      // (tests/tools/valu_peak_probe.hip) and the branchy form spent ~45 of them per entry (three lane masks AND-ed per
-      // pixel, twice; s_and_saveexec / s_cbranch_execz / s_or per touched quadrant) against ~80 vector instructions.  Here
-      // every condition of a pixel is folded into its alpha - alpha_h = alpha if (power <= 0 and alpha >= 1/255) else 0 -
-      // and the pixel state absorbs the rest:
-      //   * alpha_h = 0 leaves everything as it is (T (1 - 0) = T exactly, w = 0, and a live pixel has T >= 1e-4: it does
-      //     not "saturate");
-      //   * a pixel that is done carries T < 0: T (1 - alpha_h) < 1e-4 reads as "saturates" -> w = 0, T = -|T| = T;
-      //   * the last contributor moves exactly when w > 0 (hit and not saturated: alpha_h >= 1/255, T > 0).
-      // Same values in the same order for every pixel that is really blended: bit-identical images.
-      float alpha_h[4];
-      unsigned long long hmask = 0ull;
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const float dx = a.x - (pixfx0 + (float)((s & 1) * 8));
-        const float dy = a.y - (pixfy0 + (float)((s >> 1) * 8));
-        const float p2 = blend_power2(co, dx, dy);
-        float al = fminf(0.99f, co.w * blend_exp2(p2));
-        al = p2 <= 0.0f ? al : 0.f;
-        const bool h = al >= 1.0f / 255.0f;
-        alpha_h[s] = h ? al : 0.f;
-        hmask |= __ballot(h);
-      }
-      if (hmask == 0ull) continue;
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const float test_T = T[s] * (1 - alpha_h[s]);
-        const bool sat = test_T < 0.0001f;
-        const float w = sat ? 0.f : alpha_h[s] * T[s];
-        C0[s] += k.x * w;
-        C1[s] += k.y * w;
-        C2[s] += k.z * w;
-        D[s] += a.z * w;
-        if (HAS_EXTRA) X[s] += s_e[j] * w;
-        if (FSGS) X[s] += w;
-        T[s] = sat ? -fabsf(T[s]) : test_T;
-        last_contributor[s] = w > 0.f ? contributor : last_contributor[s];
-      }
-      {  // "some pixel is still alive": T > 0 as a float is T > 0 as a signed integer (no NaN canonicalisation needed)
-        const int m = max(max(__float_as_int(T[0]), __float_as_int(T[1])), max(__float_as_int(T[2]), __float_as_int(T[3])));
-        running = __any(m > 0);
-      }
-      if (!running && !CULL) stop_z = a.w;
-#else
       float alpha[4];
       bool hit[4];
       unsigned long long hmask = 0ull;  // lane masks stay scalar (see the backward kernel)
@@ -190,7 +142,7 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       }
       if (hmask == 0ull) continue;
       // one exec-mask region per touched quadrant, no branch inside it (a fully branch-free, select-masked update of all
-      // four pixels was measured 5 % slower in round 2: 0.215 vs 0.204 ms)
+      // four pixels was measured slower twice: round 2 0.215 vs 0.204 ms, round 4 0.156 vs 0.137 ms - DESIGN_APPENDIX)
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         if (hit[s]) {
@@ -209,7 +161,6 @@ __global__ void __launch_bounds__(64) render_fwd_wave_kernel(const uint2* __rest
       }
       running = __any(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f);
       if (!running && !CULL) stop_z = a.w;
-#endif
     }
   }
   if (lane == 0) {

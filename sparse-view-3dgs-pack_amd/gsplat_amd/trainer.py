@@ -511,6 +511,12 @@ class GaussianModelLite:
             with torch.no_grad():
                 self.nir_gain.copy_(state["nir_gain"])
             self.nir_gain_optimizer.load_state_dict(state["nir_gain_optimizer"])
+        if self.with_nir and "nir_gain" not in opt.seg_steps:
+            # a checkpoint from before the gain's step count moved into seg_steps: it lived in the gain optimizer's own state
+            try:
+                opt.seg_steps["nir_gain"] = int(state["nir_gain_optimizer"]["state"][0]["step"])
+            except (KeyError, IndexError, TypeError):
+                opt.seg_steps["nir_gain"] = int(state["t"])
 
     def oneupSHdegree(self):
         """gaussian_model.py:145-147"""
@@ -557,14 +563,22 @@ class GaussianModelLite:
                          2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), dim=1)
         return R.view(-1, 3, 3)
 
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, radii=None, generator=None, N=2):
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, radii=None, generator=None, N=2,
+                          decisions=None):
         """gaussian_model.py:395-467 in one re-layout: clone small Gaussians with a large view-space gradient,
         split large ones into N samples of their own distribution (scale / (0.8 N)), drop the split originals,
         then prune by opacity / world size.  Row order = the reference's: [survivors, clones, split samples].
         `generator`: CPU generator for the split samples (drawn on the CPU so every rank and every backend
         sees the same numbers).  Returns (n_clone, n_split, n_pruned).
         Note: the reference zeroes max_radii2D inside densification_postfix (:383) BEFORE the screen-size test of
-        :458 reads it, so that test never fires; reproduced by construction."""
+        :458 reads it, so that test never fires; reproduced by construction.
+        `decisions` (parity instrument, normally None): a dict.  Without the key "replay" the three DISCRETE decisions of this
+        call - the clone mask, the split mask (both [P]) and the prune mask (over [survivors, clones, samples]) - are
+        recorded into it (CPU bool tensors, plus the statistic `g` and the threshold they were taken with).  With
+        decisions["replay"] = such a record, the recorded masks are USED instead of this model's own, and what this model
+        would have decided is reported beside them (decisions["own"], decisions["disagree"]): two implementations whose
+        statistics differ in the last bits take the same discrete trajectory, which separates threshold chaos from
+        arithmetic differences (tests/test_gpu_psnr_parity.py)."""
         with torch.no_grad():
             P0 = self.P
             grads = self.xyz_gradient_accum / self.denom
@@ -575,6 +589,15 @@ class GaussianModelLite:
             small = max_scale <= self.percent_dense * extent
             clone = (g.abs() >= max_grad) & small        # torch.norm over the single column (:435)
             split = (g >= max_grad) & ~small             # padded_grad of the clones is 0: never selected (:399-402)
+            replay = decisions.get("replay") if decisions is not None else None
+            if decisions is not None:
+                own = dict(clone=clone.cpu(), split=split.cpu(), g=g.detach().cpu().clone(), max_grad=float(max_grad),
+                           max_scale=max_scale.detach().cpu().clone(), scale_bound=float(self.percent_dense * extent))
+                if replay is None:
+                    decisions.update(own)
+                else:
+                    decisions["own"] = own
+                    clone, split = replay["clone"].to(clone.device), replay["split"].to(split.device)
             ci = clone.nonzero().squeeze(1)
             si = split.nonzero().squeeze(1)
             ns = int(si.numel())
@@ -602,6 +625,17 @@ class GaussianModelLite:
             if max_screen_size:
                 sc_all = torch.cat((max_scale[keep_old], torch.exp(new["scaling"]).max(dim=1).values), dim=0)
                 prune = prune | (sc_all > 0.1 * extent)  # big_points_vs is all-False (max_radii2D was just zeroed)
+            if decisions is not None:
+                if replay is None:
+                    decisions["prune"] = prune.cpu()
+                    decisions["opacity"] = op_all.cpu()
+                else:
+                    decisions["own"]["prune"], decisions["own"]["opacity"] = prune.cpu(), op_all.cpu()
+                    prune = replay["prune"].to(prune.device)
+                    o = decisions["own"]
+                    decisions["disagree"] = dict(clone=int((o["clone"] != replay["clone"]).sum()),
+                                                 split=int((o["split"] != replay["split"]).sum()),
+                                                 prune=int((o["prune"] != replay["prune"]).sum()))
             n_keep_old = int(keep_old.sum())
             src = keep_old.nonzero().squeeze(1)[~prune[:n_keep_old]]
             keep_new = ~prune[n_keep_old:]
@@ -907,6 +941,8 @@ class Trainer:
                 mine = ci
         return mine
 
+    densify_decisions = None
+
     def train_iteration(self, iteration, opt):
         """One iteration (1-based) of LGDWT-GS/train.py:97-288: LR schedule, SH ramp, camera draw, render + loss +
         backward, densification statistics, densify / prune / opacity reset on schedule, Adam.
@@ -940,8 +976,10 @@ class Trainer:
             self.gather_optimizer_state()
             thr = opt.size_threshold if iteration > opt.opacity_reset_interval else None
             gen = torch.Generator().manual_seed(opt.seed * 1000003 + iteration)
+            # (densify_decisions: parity instrument, see GaussianModelLite.densify_and_prune - a callable iteration -> dict)
+            dec = self.densify_decisions(iteration) if self.densify_decisions is not None else None
             densified = m.densify_and_prune(opt.densify_grad_threshold, opt.min_opacity, opt.cameras_extent, thr,
-                                            self.last["radii"], generator=gen)
+                                            self.last["radii"], generator=gen, decisions=dec)
         if will_reset:
             m.reset_opacity()
             reset = True

@@ -45,3 +45,16 @@ def hip():
     assert torch.cuda.is_available(), "GPU test running without a GPU"
     from gsplat_amd import hip_backend
     return hip_backend()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured threshold-flip counts of the GPU parity tests (test_gpu_raster_parity.FLIPS) -> gpurun_out/flip_counts.json."""
+    mod = sys.modules.get("test_gpu_raster_parity")
+    flips = getattr(mod, "FLIPS", None) if mod else None
+    if flips:
+        import json
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            json.dump(flips, open(os.path.join(ROOT, "gpurun_out", "flip_counts.json"), "w"), indent=1)
+        except OSError:
+            pass

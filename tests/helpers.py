@@ -69,6 +69,7 @@ TOL = 1e-4        # north_star: within 1e-4 relative (to the tensor's largest en
 CHAIN_TOL = TOL
 CHAIN_TENSORS = ("scales", "rotations")
 MEASURED = {}
+ROTATION_COLLAPSED = 1e-3
 
 
 def rotation_scale_floor(grads, scene):
@@ -93,9 +94,11 @@ def check_grads(hg, og, name, tol=TOL, chain_tol=CHAIN_TOL, scene=None):
             continue
         errs[k] = rel_err(hg[k], og[k])
         if k == "rotations" and scene is not None:
+            # only where the tensor has collapsed (isotropic, init-like scene: largest entry below 1e-3 of what a rotation
+            # gradient of this scene could be - measured there 1e-10 ... 1e-9 of the floor); everywhere else the stated scale
             floor = rotation_scale_floor(og, scene)
-            ref = max(float(og[k].abs().max()), floor, 1e-12)
-            errs[k] = float((hg[k].double().cpu() - og[k].double().cpu()).abs().max()) / ref
+            if float(og[k].abs().max()) < ROTATION_COLLAPSED * floor:
+                errs[k] = float((hg[k].double().cpu() - og[k].double().cpu()).abs().max()) / max(floor, 1e-12)
     MEASURED[name] = errs
     print("grads %s: %s" % (name, {k: "%.1e" % v for k, v in errs.items()}))
     try:

@@ -115,7 +115,12 @@ def test_densify_and_prune_equals_the_reference_sequence(oracle):
         for n, w in FIELDS:
             # (rows are copies except the split samples' centres and scales, which both sides COMPUTE - torch may vectorise
             #  exp / bmm differently for the two call shapes on some CPUs: a last-bit tolerance there, copies stay exact)
-            assert torch.allclose(m.params[n].detach().reshape(m.P, w), rf[n], rtol=2e-6, atol=1e-6), n
+            got = m.params[n].detach().reshape(m.P, w)
+            if n in ("xyz", "scaling"):
+                assert torch.allclose(got, rf[n], rtol=2e-6, atol=1e-6), n
+                assert int((got != rf[n]).any(dim=1).sum()) <= 2 * ns, n   # (only split samples may differ in a last bit)
+            else:
+                assert torch.equal(got, rf[n]), n
             assert torch.equal(v1[n], r1[n]) and torch.equal(v2[n], r2[n]), n
             assert m.params[n].grad is None
         assert opt.seg_steps == steps_before

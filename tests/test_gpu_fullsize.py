@@ -22,7 +22,7 @@ import diff_gaussian_rasterization as dgr
 import fullsize_parity as fp
 from gsplat_amd import synthetic
 from helpers import run_scene
-from test_gpu_raster_parity import forward_state
+from test_gpu_raster_parity import flip_bound, forward_state
 
 pytestmark = pytest.mark.gpu
 P, W, H = 1_000_000, 1920, 1080
@@ -140,6 +140,7 @@ TOL = 1e-4          # north_star: renders and gradients within 1e-4 relative (to
 #     and HIP-vs-oracle is covered by it: end_to_end <= hip_vs_exact + oracle_vs_exact + stage1_image + TOL.
 # Every other tensor is held to TOL end to end against the oracle, and to TOL with stage 2 alone fed the oracle's sums.
 CHAIN_TENSORS = ("scales", "rotations")
+ORACLE_FP32_CHAIN_CAP = 5e-3   # the oracle's fp32 chain vs its float64 image (measured <= 2.0e-3)
 REPEAT_TOL = 1e-6   # two runs of the HIP backward, relative to the tensor's largest entry
 
 
@@ -216,7 +217,7 @@ def check_view_against_oracle(hip, oracle, tag, P, W, H, cam_i=3, cotangents=("n
             flip = dc > 0.2 * TOL * scale  # a threshold decision (alpha < 1/255, T < 1e-4) that went the other way
             rep["flipped_pixels"] = int(flip.sum())
             assert rep["pixels_over_tol"] <= max(2, dc.numel() // 20000), rep
-            assert rep["flipped_pixels"] <= max(2, dc.numel() // 2000), rep
+            assert rep["flipped_pixels"] <= flip_bound(dc.numel()), rep
             for cname, cot in cots.items():
                 cot = cot.clone()
                 cot[:, flip] = 0  # for both sides (test_gpu_raster_parity.flip_mask explains why)
@@ -287,6 +288,9 @@ def check_view_against_oracle(hip, oracle, tag, P, W, H, cam_i=3, cotangents=("n
                         # HIP vs the oracle's fp32 run of the reference formula: covered by the oracle's own distance
                         assert c["end_to_end"] <= c["hip_vs_exact"] + c["oracle_vs_exact"] + c["stage1_image"] + TOL, \
                             (tag, cull, cname, k, c)
+                        # ... and the oracle's fp32 transcription itself stays where it was measured (round 4, C2 / C3 / C4:
+                        # <= 1.0e-3 scales, <= 2.0e-3 rotations): a regression of THAT path would otherwise go unseen
+                        assert c["oracle_vs_exact"] <= ORACLE_FP32_CHAIN_CAP, (tag, cull, cname, k, c)
                     else:
                         assert v["max_rel"] <= TOL, (tag, cull, cname, k, v)
                         assert s2 <= TOL, (tag, cull, cname, k, "stage 2 alone", s2)

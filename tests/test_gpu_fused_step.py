@@ -112,6 +112,44 @@ def test_two_phase_step_leaves_the_bits_of_the_one_launch_step(hip, lists):
     assert float(sb["denom"].mean()) > 5.0
 
 
+def test_a_second_side_launch_steps_again(hip):
+    """gs_step_uninstanced draws its blocks from a cursor in the geometry header; the call's last workgroup re-arms it, so a
+    second call behind the same forward (a retry, a probe that re-times the launch) is a second zero-gradient step of the
+    Gaussians without instances - not a silent no-op: their first moments decay twice, their `denom` counts twice."""
+    a, b = make(hip, True, P=120000, W=320, H=240), make(hip, True, P=120000, W=320, H=240)
+    a.depth_limit = b.depth_limit = "deferred"
+    once = hip._launch_uninstanced
+
+    def twice(*args):
+        once(*args)
+        return once(*args)
+    hip.TWO_PHASE, hip.TWO_PHASE_MIN_P = True, 0
+    n0 = hip.two_phase_launches
+    try:
+        for k in range(3):   # (steps 2 and 3 meet non-zero moments on Gaussians camera k does not list)
+            a.step(k)
+            b.step(k)
+        a.sync(); b.sync()
+        sa0, sb0 = state(a), state(b)
+        for k in sa0:
+            assert torch.equal(sa0[k], sb0[k]), k
+        a.step(3)
+        hip._launch_uninstanced = twice
+        b.step(3)
+        a.sync(); b.sync()
+    finally:
+        hip.__dict__.pop("_launch_uninstanced", None)
+        del hip.TWO_PHASE, hip.TWO_PHASE_MIN_P
+    assert hip.two_phase_launches - n0 == 9
+    sa, sb = state(a), state(b)
+    b1 = 0.9
+    same = sb["exp_avg"] == sa["exp_avg"]
+    again = torch.isclose(sb["exp_avg"], b1 * sa["exp_avg"], rtol=1e-6, atol=0.0) & (sa["exp_avg"] != 0)
+    assert bool((same | again).all()) and int(again.sum()) > 1000, (int((~(same | again)).sum()), int(again.sum()))
+    d = sb["denom"] - sa["denom"]
+    assert bool(((d == 0) | (d == 1)).all()) and int((d == 1).sum()) > 100
+
+
 def test_fused_train_step_tracks_the_unfused_one(hip):
     """Without the probe both paths run their own blend backward (float atomics in a run-dependent order): the
     trajectories agree to rounding, the loss falls on both."""

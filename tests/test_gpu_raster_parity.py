@@ -58,6 +58,18 @@ def forward_state(backend, scene, cam, device, bg, antialiasing):
     return st
 
 
+FLIPS = {}   # name -> measured counts (written to gpurun_out/flip_counts.json by conftest at session end)
+
+
+def flip_bound(npix):
+    """Pixels whose last contributor / threshold decision may differ from the oracle's (log2-domain alpha + FMA in
+    csrc/gs_blend.h against the oracle's expf form: a pixel within rounding of alpha = 1/255 or T = 1e-4 takes the other branch).
+    Measured (round 4, profiles/r04_parity_fullsize_c*.json): 2 of 0.64 M pixels at C2, 6 of 2.07 M at C3, 10 at C4 - about 3-5 per
+    million.  The bar is 4x that rate, with a floor for small images (where a handful is the measured worst: round 5,
+    profiles/r05_flip_counts.json)."""
+    return max(4, npix // 80000)
+
+
 BINNING_STATE = ("tiles_touched", "point_offsets", "keys_sorted", "point_list", "ranges")
 
 
@@ -100,7 +112,8 @@ def compare_forward(h, o, name, skip=(), culled=False):
     # quantisation step of alpha (1/255) times the colour range
     assert int(bad.sum()) <= max(2, npix // 20000), "%s: %d/%d pixels beyond %.0e" % (name, int(bad.sum()), npix, TOL)
     assert float(dc.max()) <= 1.5 / 255.0 * max(1.0, float(o["rgb"].abs().max())), "%s: max colour err %.3e" % (name, float(dc.max()))
-    assert nflip <= max(2, npix // 2000), "%s: last contributor differs on %d pixels" % (name, nflip)
+    assert nflip <= flip_bound(npix), "%s: last contributor differs on %d pixels (bound %d)" % (name, nflip, flip_bound(npix))
+    FLIPS[name] = dict(nflip=nflip, npix=npix, bad=int(bad.sum()))
     dT = (h["final_T"] - o["final_T"]).abs()
     assert int((dT > TOL).sum()) <= max(2, npix // 20000)
     di = (h["invdepth"] - o["invdepth"]).abs()
@@ -114,7 +127,7 @@ def flip_mask(h, o):
     m = (h["color"] - o["color"]).abs().amax(dim=0) > 0.2 * TOL * scale
     m |= (h["final_T"] - o["final_T"]).abs().reshape(m.shape) > 0.2 * TOL
     m |= last_contributor_id(h, m.shape[1], m.shape[0]) != last_contributor_id(o, m.shape[1], m.shape[0])
-    assert int(m.sum()) <= max(2, m.numel() // 2000), "%d flipped pixels" % int(m.sum())
+    assert int(m.sum()) <= flip_bound(m.numel()), "%d flipped pixels (bound %d)" % (int(m.sum()), flip_bound(m.numel()))
     return m
 
 

@@ -52,6 +52,14 @@ def test_nir_step_on_the_oracle_with_two_passes(oracle):
     m.restore(state)
     assert float(m.nir_gain) == gain1
     assert float(m.nir_gain_optimizer.state_dict()["state"][0]["exp_avg"]) == float(state["nir_gain_optimizer"]["state"][0]["exp_avg"])
+    # a checkpoint written before the gain's step count moved into seg_steps restores too (the count is migrated)
+    steps = int(state["seg_steps"]["nir_gain"])
+    old_state = dict(state, seg_steps={k: v for k, v in state["seg_steps"].items() if k != "nir_gain"})
+    m.restore(old_state)
+    assert m.optimizer.seg_steps["nir_gain"] == int(state["nir_gain_optimizer"]["state"][0]["step"])
+    assert abs(m.optimizer.seg_steps["nir_gain"] - steps) <= 1
+    out = tr.train_iteration(202, TrainOptions(iterations=1000, densify_from_iter=1000, cameras_extent=4.4))
+    assert torch.isfinite(out["loss"]) and float(m.nir_gain) != gain1
 
 
 @pytest.mark.gpu
