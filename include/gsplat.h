@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 5
+#define GS_ABI_VERSION 6  /* round 5: gs_depth_l1, GsView.debug bit 1, binning buffer = sort arrays + region / chunk / tile tables */
 
 /* error codes (negative = caller error) */
 #define GS_OK 0
@@ -66,7 +66,10 @@ typedef struct GsView {
   int32_t sh_degree;   /* active degree D, 0..3 */
   int32_t prefiltered; /* bool */
   int32_t antialiasing; /* bool */
-  int32_t debug;       /* bool: synchronise + check after every launch (auxiliary.h:178-185) */
+  int32_t debug;       /* non-zero: synchronise + check after every launch (auxiliary.h:178-185).  Bit 1 (value 2 or 3) is a
+                          self-test of the list construction of tile_cull = 0 / 1 (csrc/gs_tilebin.hip): every third Gaussian
+                          takes the row-wise entry enumeration that is normally reserved for Gaussians whose span hull holds
+                          more regions than tiles; the lists must not change */
   int32_t tile_cull;   /* 0: instance lists = the reference's bounding-square rule (rasterizer_impl.cu:70-111), bit-identical
                           point_list / ranges / num_rendered; 1: additionally drop (tile, Gaussian) pairs on which alpha <
                           1/255 for every pixel (csrc/gs_tilecull.h) - same images and gradients, ~2.6x fewer instances;
@@ -353,6 +356,11 @@ typedef struct GsStepState {
    * View statistics are kept for every Gaussian as without it.  With the model's rows in spatial order (neighbours in
    * memory = neighbours in space) the Gaussians no camera reaches fill whole blocks. */
   uint8_t* dormant;
+  /* "sparse_adam" (train.py:282-284): 1 = a Gaussian with radii <= 0 in this view is not stepped at all - its parameters and
+   * both moments keep their bits (with the default optimizer it takes a zero-gradient step: the moments decay, the
+   * parameter moves by the old momentum).  Visible Gaussians without instances (culled spans, depth limits) still take
+   * their zero-gradient step.  Blocks of 256 rows without a visible Gaussian cost no parameter or moment traffic. */
+  int32_t sparse;
 } GsStepState;
 #define GS_STEP_BLOCK 256
 int gs_backward_step(const GsView* view, const GsGaussians* g, const int32_t* radii,
@@ -435,9 +443,10 @@ int gs_forward_tile_order(const GsView* view, const GsScratch* scratch, void* st
  * zeroed by the caller) += [entries visited, entries with a valid pixel, (entry, quadrant) pairs with a valid pixel,
  * valid (entry, pixel) pairs, tiles with work, list entries of those tiles, 0, 0].  tests/tools/blend_stats.py */
 int gs_debug_blend_stats(const GsScratch* scratch, int32_t P, int32_t W, int32_t H, uint64_t* out, void* stream);
-/* gs_export_binning for lists built by region binning (GsView.tile_cull = 2; gs_export_binning returns GS_E_UNSUPPORTED
- * for their keys): keys_sorted[i] = (tile << 32 | depth bits) of list entry i, rebuilt from ranges[] - the lists of
- * different tiles lie in point_list in no particular order, inside a tile the order is the reference's. */
+/* keys_sorted for the product's lists (the product keeps no tile-key array in any list mode: gs_export_binning returns
+ * GS_E_UNSUPPORTED when asked for keys): keys_sorted[i] = (tile << 32 | depth bits) of list entry i, rebuilt from ranges[] and
+ * the Gaussians' depths.  tile_cull = 0 / 1: point_list is the reference's, tile after tile.  tile_cull = 2 (region
+ * binning): the lists of different tiles lie in point_list in no particular order, inside a tile the order is the reference's. */
 int gs_export_binning_region(const GsScratch* scratch, int32_t W, int32_t H, int64_t num_rendered, uint64_t* keys_sorted,
                              uint32_t* point_list, void* stream);
 
@@ -547,6 +556,15 @@ int gs_l1_dwt2_patch_fwd_clamp_p(const float* raw, const float* gt, int32_t C, i
                                  const uint8_t* mask, float* partials, float* clamped_out, void* stream);
 int64_t gs_l1_partials_count(int64_t n);
 int gs_l1_fwd_p(const float* a, const float* b, int64_t n, float* partials, void* stream);
+/* Depth regularisation of the step (LGDWT-GS/train.py:204-216): Ll1depth_pure = mean |(invDepth - mono_invdepth) * depth_mask|
+ * over the n pixels of the rasterizer's inverse-depth output.  One pass gives both halves (either pointer may be NULL, not
+ * both): partials[w] = workgroup w's sum of |(d - m) k| (gs_depth_l1_partials_count(n) entries; the caller adds them in
+ * index order and divides by n), and grad[i] = coef * (coef_dev ? coef_dev[0] : 1) * sign((d - m) k) * k - the gradient of
+ * weight * mean with coef = weight / n (sign(0) = 0 as torch.abs has it).  mask NULL: all ones.  grad is what
+ * gs_backward* takes as dL_dinvdepth. */
+int64_t gs_depth_l1_partials_count(int64_t n);
+int gs_depth_l1(const float* invdepth, const float* mono_invdepth, const float* mask, int64_t n, float* partials, float coef,
+                const float* coef_dev, float* grad, void* stream);
 /* like gs_ssim_fwd but returns sum(ssim_map) (+=, zero it first) instead of the map.  One atomic per workgroup on
  * sum_out: prefer gs_ssim_fwd_partials below for large images (the atomics serialise: 98 vs 59 us at 1080p). */
 int gs_ssim_fwd_sum(const float* img1, const float* img2, int32_t B, int32_t C, int32_t H, int32_t W, float C1,
@@ -609,7 +627,9 @@ typedef struct GsAdamSeg {
   int64_t begin, end;
   float lr_a, lr_b;
   int32_t period, split;
-  int32_t step, _pad;
+  int32_t step;
+  int32_t row_width; /* gs_adam_step_masked: floats per Gaussian in this segment (element i belongs to row (i - begin) / row_width);
+                        0: the segment is not masked */
 } GsAdamSeg;
 /* segs is a HOST array (<= 8 entries, copied into the launch); step = 1-based iteration for the bias correction. */
 int gs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
@@ -621,6 +641,13 @@ int gs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 int gs_adam_step_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                        const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
                        const float* gate, void* stream);
+/* "sparse_adam" (LGDWT-GS/train.py:282-284: `visible = radii > 0; optimizer.step(visible, N)`; the optimizer class itself,
+ * SparseGaussianAdam, lives in a branch of the rasterizer that the reference does not vendor): the same update, but only for
+ * the rows with row_mask[row] > 0 (device, float [P]; segments with row_width > 0) - the parameters AND both moments of
+ * every other row keep their bits.  gate as gs_adam_step_gated (may be NULL). */
+int gs_adam_step_masked(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const GsAdamSeg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
+                        const float* gate, const float* row_mask, void* stream);
 
 /* ---- per-Gaussian elementwise work of the train step outside the rasterizer ----
  * Parameter activations of GaussianModel (LGDWT-GS/scene/gaussian_model.py:40-60,102-117): scales = exp(scaling),

@@ -389,9 +389,18 @@ int gso_ssim_bwd(const float* img1, const float* img2, int32_t B, int32_t C, int
 /* torch.optim.Adam arithmetic (no amsgrad / weight decay) over a flat buffer with a learning-rate segment table;
  * restates the update of LGDWT-GS/scene/gaussian_model.py:183-193 + train.py:279-288 (pinned against
  * torch.optim.Adam itself in tests/test_adam.py) */
+int gso_adam_step_masked(float* p, const float* g, float* m, float* v, int64_t n, const GsAdamSeg* segs, int32_t nseg,
+                         float b1, float b2, float eps, int32_t step, const float* gate, const float* row_mask, void*);
 int gso_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const GsAdamSeg* segs, int32_t nseg,
                   float b1, float b2, float eps, int32_t step, void*) {
+  return gso_adam_step_masked(p, g, m, v, n, segs, nseg, b1, b2, eps, step, nullptr, nullptr, nullptr);
+}
+/* + "sparse_adam" (LGDWT-GS/train.py:282-284: visible = radii > 0; optimizer.step(visible, N)): rows with row_mask <= 0 keep
+ * parameters and moments; gate != 0: nobody steps (data-parallel validity flag) */
+int gso_adam_step_masked(float* p, const float* g, float* m, float* v, int64_t n, const GsAdamSeg* segs, int32_t nseg,
+                         float b1, float b2, float eps, int32_t step, const float* gate, const float* row_mask, void*) {
   if (!p || !g || !m || !v) return GS_E_NULL;
+  if (gate && *gate != 0.0f) return GS_OK;
   if (step < 1 || nseg < 0 || nseg > 8) return GS_E_SHAPE;
   float seg_inv_bc1[8], seg_inv_sqrt_bc2[8];
   for (int k = 0; k < nseg; k++) {
@@ -409,6 +418,7 @@ int gso_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
         seg = k;
       }
     if (seg < 0) continue;  // not optimised this step (torch skips parameters without a gradient)
+    if (row_mask && segs[seg].row_width > 0 && !(row_mask[(i - segs[seg].begin) / segs[seg].row_width] > 0.f)) continue;
     const float inv_bc1 = seg_inv_bc1[seg], inv_sqrt_bc2 = seg_inv_sqrt_bc2[seg];
     m[i] = b1 * m[i] + (1.f - b1) * g[i];
     v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
@@ -627,6 +637,24 @@ int gso_l1_dwt2_patch_fwd_clamp_p(const float* raw, const float* gt, int32_t C, 
   return GS_OK;
 }
 int64_t gso_l1_partials_count(int64_t n) { return n <= 0 ? 0 : 1; }
+/* Depth regularisation, LGDWT-GS/train.py:204-216: Ll1depth_pure = torch.abs((invDepth - mono_invdepth) * depth_mask).mean()
+ * -> partials[0] = the sum (one "workgroup"); grad = coef * sign((d - m) k) k (torch.abs backward: sign(0) = 0) */
+int64_t gso_depth_l1_partials_count(int64_t n) { return n <= 0 ? 0 : 1; }
+int gso_depth_l1(const float* d, const float* m, const float* k, int64_t n, float* partials, float coef, const float* coef_dev,
+                 float* grad, void*) {
+  if (!d || !m || (!partials && !grad)) return GS_E_NULL;
+  if (n <= 0) return GS_OK;
+  if (coef_dev) coef *= coef_dev[0];
+  double s = 0.0;
+  for (int64_t i = 0; i < n; i++) {
+    const float w = k ? k[i] : 1.0f;
+    const float v = (d[i] - m[i]) * w;
+    s += (double)fabsf(v);
+    if (grad) grad[i] = coef * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * w;
+  }
+  if (partials) partials[0] = (float)s;
+  return GS_OK;
+}
 int gso_l1_fwd_p(const float* a, const float* b, int64_t n, float* partials, void*) {
   if (!a || !b || !partials) return GS_E_NULL;
   partials[0] = 0.f;

@@ -45,7 +45,7 @@ static int region_layout(const GsView* v, const GsScratch* sc, RegionLayout& rl)
   if (sc->img_bytes < img_bytes(N, T)) return GS_E_SCRATCH;
   const int64_t cap = sc->binning_capacity;
   if (cap <= 0 || cap > 0xFFFFFFFFll) return GS_E_SHAPE;
-  if (sc->binning_bytes < bin_bytes((size_t)cap)) return GS_E_SCRATCH;
+  if (sc->binning_bytes < bin_bytes((size_t)cap, T)) return GS_E_SCRATCH;
   rl.rg_x = (gx + RG_TILES - 1) / RG_TILES;
   rl.rg_y = (gy + RG_TILES - 1) / RG_TILES;
   rl.cap = region_capacity(cap, rl.rg_x * rl.rg_y);
@@ -73,7 +73,7 @@ int gs_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R_capacity, size_t
   const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
   out[0] = geom_bytes((size_t)P);
   out[1] = img_bytes((size_t)W * H, T);
-  out[2] = bin_bytes((size_t)R_capacity);
+  out[2] = bin_bytes((size_t)R_capacity, T);
   if (bwd_ws) *bwd_ws = bwd_workspace_bytes((size_t)P);
   return GS_OK;
 }
@@ -188,27 +188,13 @@ static int forward_bin_stage(const GsView* v, const GsScratch* sc, const GeomVie
       rc = launch_radix_sort(gv.gsort, &gv.hdr->P, P, 32, 0, gv.depth_keys, s, v->debug, &gv.hdr->n_ordered);
       if (rc) return rc;
     }
-    // 2. instances in depth order; 3. stable partition by tile id.  The unsorted list goes into the ping-pong
-    // half from which `passes` passes end in half 0, so backward / exports always find the result in half 0.
-    const int bit = (int)gs_higher_msb((uint32_t)(gx * gy));
-    const int passes = (bit + RS_BITS - 1) / RS_BITS;
-    const int start = passes & 1;
-    {
-      GS_PROF(ST_DUPLICATE, s);
-      rc = launch_emit_instances(gv, P, &gv.hdr->n_ordered, gx, gy, v->tile_cull, sc->tile_depth_limit, gv.gsort.vals[0], bv.keys[start], bv.vals[start], s, v->debug);
-      if (rc) return rc;
-    }
-    {
-      GS_PROF(ST_SORT, s);
-      rc = launch_radix_sort(bv, &gv.hdr->sort_n, cap, bit, start, nullptr, s, v->debug);
-      if (rc) return rc;
-    }
+    // 2. region entries in depth order, stable partition by region id, expansion into the tile lists (gs_tilebin.hip):
+    //    point_list ends in ids[0] of the binning buffer, where the blend kernels and the exports look for it
+    const TileBinView tb = tilebin_view((char*)sc->binning + sort_bytes((size_t)cap), (size_t)cap, T);
+    rc = launch_tile_binning(gv, bv, tb, P, cap, gx, gy, v->tile_cull, sc->tile_depth_limit, iv.ranges, (v->debug & 2) ? 1 : 0, s,
+                             v->debug & 1);
+    if (rc) return rc;
   }
-  {
-    GS_PROF(ST_RANGES, s);
-    rc = launch_tile_ranges(bv.keys[0], &gv.hdr->sort_n, cap, iv.ranges, (int)T, s);
-  }
-  if (rc) return rc;
   GS_LAUNCH_CHECK(s, v->debug);
   return GS_OK;
 }
@@ -230,7 +216,7 @@ int gs_forward_bin(const GsView* v, const GsGaussians* g, GsScratch* sc, uint32_
     if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
     const int64_t cap = sc->binning_capacity;
     if (cap < 0) return GS_E_SHAPE;
-    if (cap > 0 && (!sc->binning || sc->binning_bytes < bin_bytes((size_t)cap))) return GS_E_SCRATCH;
+    if (cap > 0 && (!sc->binning || sc->binning_bytes < bin_bytes((size_t)cap, T))) return GS_E_SCRATCH;
     if (cap > 0xFFFFFFFFll) return GS_E_UNSUPPORTED;
     GeomView gv = geom_view(sc->geom, (size_t)P);
     ImgView iv = img_view(sc->img, N, T);
@@ -276,7 +262,7 @@ static int forward_render_impl(const GsView* v, const GsGaussians* g, GsScratch*
   if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
   const int64_t cap = sc->binning_capacity;
   if (cap < 0) return GS_E_SHAPE;
-  if (cap > 0 && (!sc->binning || sc->binning_bytes < bin_bytes((size_t)cap))) return GS_E_SCRATCH;
+  if (cap > 0 && (!sc->binning || sc->binning_bytes < bin_bytes((size_t)cap, T))) return GS_E_SCRATCH;
   if (cap > 0xFFFFFFFFll) return GS_E_UNSUPPORTED;
   GeomView gv = geom_view(sc->geom, (size_t)P);
   ImgView iv = img_view(sc->img, N, T);
@@ -623,13 +609,6 @@ __global__ void export_offsets_kernel(GeomView g, int P, uint32_t* point_offsets
     point_offsets[i] = run;
   }
 }
-__global__ void export_keys_kernel(const uint32_t* tkeys, const uint32_t* point_list, const Splat* splat, int64_t R,
-                                   uint64_t* keys_sorted) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R) return;
-  keys_sorted[i] = ((uint64_t)tkeys[i] << 32) | (uint64_t)__float_as_uint(splat[point_list[i]].depth);
-}
-
 int gs_export_geom(const GsScratch* sc, int32_t P, float* depths, float* means2D, float* cov3D, float* conic_opacity,
                    float* rgb, uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_offsets, void* stream) {
   if (!sc || !sc->geom) return GS_E_NULL;
@@ -733,23 +712,9 @@ int gs_export_binning(const GsScratch* sc, int64_t R, uint64_t* keys_sorted, uin
   hipStream_t s = (hipStream_t)stream;
   if (!sc->geom) return GS_E_NULL;
   SortBufs bv = sort_view(sc->binning, (size_t)sc->binning_capacity);
-  if (keys_sorted) {
-    // the product keeps (tile id) and (depth bits) in separate arrays; rebuild the reference's 64-bit key
-    const Splat* splat = (const Splat*)((const char*)sc->geom + sizeof(GeomHeader));
-    GeomHeader hdr;  // (parity export: a blocking read of the header is fine here)
-    GS_HIP_CHECK(hipStreamSynchronize(s));
-    GS_HIP_CHECK(hipMemcpy(&hdr, sc->geom, sizeof(hdr), hipMemcpyDeviceToHost));
-    (void)hipGetLastError();
-    if (hdr.region_mode) {
-      // region binning: no tile-key array exists; every list entry's key from ranges[] (needs the image buffer: W x H
-      // are not known here, so the ranges pointer is recovered the way gs_export_img lays the buffer out is not possible -
-      // the caller passes them through gs_export_binning_region instead)
-      return GS_E_UNSUPPORTED;
-    }
-    hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, bv.keys[0], bv.vals[0], splat,
-                       R, keys_sorted);
-    GS_LAUNCH_CHECK(s, 0);
-  }
+  // no tile-key array exists in any list mode (region binning, two-level binning): the reference's 64-bit key of every list
+  // entry is rebuilt from ranges[] (tile) and the Gaussian's depth by gs_export_binning_region, which knows the image size
+  if (keys_sorted) return GS_E_UNSUPPORTED;
   if (point_list) GS_HIP_CHECK(hipMemcpyAsync(point_list, bv.vals[0], 4 * (size_t)R, hipMemcpyDeviceToDevice, s));
   return GS_OK;
 }

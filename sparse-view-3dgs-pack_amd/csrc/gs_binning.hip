@@ -1,22 +1,14 @@
-// gs_binning.hip - tile binning: depth order of the Gaussians, key duplication, stable tile partition,
-// tile ranges.  Integer/byte work, HBM-bound.
+// gs_binning.hip - the stable LSD radix sort of (u32 key, u32 value) pairs behind the tile binning of tile_cull = 0 / 1.
+// Integer/byte work, HBM-bound.
 //
-// Replaces duplicateWithKeys (rasterizer_impl.cu:70-111), cub::DeviceRadixSort::SortPairs over R
-// 64-bit (tile|depth) keys (rasterizer_impl.cu:306-311) and identifyTileRanges (:116-138), and produces
-// EXACTLY the reference's point_list (stable order: tile, then depth bits, then Gaussian index).
-//
-// MI355X-first restructuring.  The reference sorts R = sum(tiles_touched) 12-byte pairs on 45 key bits
-// (6 radix passes, ~24 B x R each).  Here the two key fields are separated:
+// The reference sorts R = sum(tiles_touched) 12-byte pairs on 45 key bits (cub::DeviceRadixSort::SortPairs,
+// rasterizer_impl.cu:306-311: 6 radix passes, ~24 B x R each).  Here the two key fields are separated:
 //   1. the P Gaussians (not the R instances; R/P ~ 20) are stably sorted by their 32 depth bits
-//      (culled ones get key 0xFFFFFFFF) - 4 passes over 8 B x P;
-//   2. instances are emitted in that depth order (key = tile id only, 4 B);
-//   3. a STABLE partition by tile id (ceil(log2 T)/8 = 2 passes over 8 B x R at 1080p) then leaves every
-//      tile's list in (depth, index) order - the same total order as the 64-bit sort.
-// The instance-level traffic drops from 6 x 24 B to 2 x 16 B per instance.
-//
-// duplicate: one workgroup per 256 (depth-ordered) Gaussians; ALL lanes walk the workgroup's instance
-// range cooperatively (binary search of the owner in LDS): coalesced stores, no lane serialised on a
-// Gaussian that covers thousands of tiles (the reference loops one thread over a Gaussian's tiles).
+//      (Gaussians without instances dropped by the first pass) - 4 passes over 8 B x P: this file;
+//   2. in that depth order every Gaussian emits one ENTRY per 4 x 4-tile region it reaches (region id + 16-bit tile mask),
+//      the entries are stably partitioned by region id with the same passes (1-2 over 8 B x entries), and the regions are
+//      expanded into the tile lists: gs_tilebin.hip.  Every tile's list comes out in (depth, index) order - the total order
+//      of the 64-bit sort - and point_list / ranges are the reference's bit for bit.
 //
 // All kernels read element counts from device memory so the host never waits for them; grids are sized
 // from a host-side upper bound.
@@ -283,200 +275,6 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// instance emission in depth order
-// ------------------------------------------------------------------------------------------------
-// per-workgroup sums of tiles_touched in depth order
-__global__ void __launch_bounds__(GS_BLOCK) sorted_block_sums_kernel(const uint32_t* __restrict__ order,
-                                                                     const uint32_t* __restrict__ tiles_touched,
-                                                                     const uint32_t* __restrict__ n_ordered,
-                                                                     uint32_t* __restrict__ sums) {
-  __shared__ uint32_t red[GS_BLOCK / 64];
-  const uint32_t i = blockIdx.x * GS_BLOCK + threadIdx.x;
-  uint32_t v = (i < *n_ordered) ? tiles_touched[order[i]] : 0u;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-// Instance emission (duplicateWithKeys, rasterizer_impl.cu:70-111) in depth order.  The unit of work is one
-// TILE ROW of one Gaussian: a workgroup takes 256 consecutive Gaussians of the depth order, expands them into
-// their rectangle rows (binary search over the row-count prefix in LDS), evaluates each row's column span once
-// (whole row, or the ellipse span of gs_tilecull.h), scans the span lengths and then writes the instances with
-// one binary search per instance - coalesced stores, no lane serialised on a Gaussian covering thousands of
-// tiles, and no per-instance re-evaluation of the spans.  Rows are processed DUP_RC at a time to bound LDS.
-#define DUP_RC 1024
-__device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t* s_wsum, uint32_t& total) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  __syncthreads();  // s_wsum may still be read from a previous call
-  if (lane == 63) s_wsum[wid] = inc;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (int w = 0; w < wid; w++) woff += s_wsum[w];
-  total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-  return woff + inc - v;
-}
-
-__global__ void __launch_bounds__(GS_BLOCK) duplicate_kernel(GeomView g, const uint32_t* __restrict__ n_ordered, uint32_t grid_x,
-                                                             uint32_t grid_y, int tile_cull,
-                                                             const float* __restrict__ depth_limit,
-                                                             const uint32_t* __restrict__ order,
-                                                             const uint32_t* __restrict__ block_base,
-                                                             uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals) {
-  __shared__ uint32_t s_wsum[GS_BLOCK / 64];
-  __shared__ uint32_t s_rowoff[GS_BLOCK + 1];  // exclusive prefix of rows per Gaussian
-  __shared__ uint32_t s_id[GS_BLOCK];
-  __shared__ uint32_t s_rmin[GS_BLOCK];
-  __shared__ uint32_t s_rmax[GS_BLOCK];
-  __shared__ TileCull s_cull[GS_BLOCK];
-  __shared__ float s_depth[GS_BLOCK];
-  __shared__ int s_dq[GS_BLOCK];
-  __shared__ uint32_t s_span_off[DUP_RC + 1];  // exclusive prefix of span lengths within the row chunk
-  __shared__ uint32_t s_span_key[DUP_RC];      // first tile id of the span
-  __shared__ uint32_t s_span_own[DUP_RC];      // owner (index into s_id)
-  if (g.hdr->overflow) return;
-  const int tid = threadIdx.x;
-  const uint32_t i = blockIdx.x * GS_BLOCK + tid;
-  uint32_t tiles = 0, rows = 0;
-  s_dq[tid] = 0;  // (only Gaussians with culled spans AND depth limits carry a verdict; everything else: spans as they are)
-  if (i < *n_ordered) {
-    const uint32_t id = order[i];
-    // (the count comes from tiles_touched: a Gaussian the depth limits removed entirely has no record at all, and the
-    // one-workgroup sort of small scenes keeps such Gaussians in the order)
-    tiles = g.tiles_touched[id];
-    const float4* rec = reinterpret_cast<const float4*>(&g.splat[id]);
-    uint4 tail = make_uint4(0u, 0u, 0u, 0u);
-    if (tiles) tail = reinterpret_cast<const uint4*>(rec)[3];  // rect_min, rect_max, tiles, clamped
-    s_id[tid] = id;
-    s_rmin[tid] = tail.x;
-    s_rmax[tid] = tail.y;
-    if (tiles) {
-      rows = (tail.y >> 16) - (tail.x >> 16);
-      if (tile_cull) {
-        const float4 ra = rec[0], rc = rec[1];
-        s_cull[tid] = tilecull_setup(1, ra.x, ra.y, rc.x, rc.y, rc.z, rc.w);
-        s_depth[tid] = ra.z;
-        s_dq[tid] = depth_limit ? (int)((tail.w >> 8) & 3u) : 0;  // the preprocess kernel's verdict (gs_tilecull.h)
-      } else {
-        s_cull[tid].mode = 0;
-      }
-    }
-  }
-  uint32_t total_rows, expected;
-  const uint32_t my_rowoff = block_exclusive_scan256(rows, s_wsum, total_rows);
-  s_rowoff[tid] = my_rowoff;
-  if (tid == 0) s_rowoff[GS_BLOCK] = total_rows;
-  (void)block_exclusive_scan256(tiles, s_wsum, expected);  // what the prefix sum reserved for this workgroup
-  uint32_t written = 0;                                    // instances emitted so far (uniform)
-  const uint32_t base = block_base[blockIdx.x];
-  uint32_t last_key = 0, last_own = 0;
-  for (uint32_t rbase = 0; rbase < total_rows; rbase += DUP_RC) {
-    const uint32_t nrow = min((uint32_t)DUP_RC, total_rows - rbase);
-    // each thread evaluates DUP_RC / 256 consecutive rows
-    uint32_t n4[DUP_RC / GS_BLOCK], local = 0;
-#pragma unroll
-    for (int j = 0; j < DUP_RC / GS_BLOCK; j++) {
-      const uint32_t r = tid * (DUP_RC / GS_BLOCK) + j;
-      uint32_t n = 0;
-      if (r < nrow) {
-        const uint32_t rs = rbase + r;
-        int lo = 0, hi = GS_BLOCK - 1;  // largest owner with s_rowoff[owner] <= rs
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (s_rowoff[mid] <= rs) lo = mid; else hi = mid - 1;
-        }
-        const uint32_t rmin = s_rmin[lo], rmax = s_rmax[lo];
-        const uint32_t ty = (rmin >> 16) + (rs - s_rowoff[lo]);
-        uint32_t tx0;
-        n = tilecull_row_span(s_cull[lo], ty, rmin & 0xFFFFu, rmax & 0xFFFFu, tx0);
-        const int dq = depth_limit ? s_dq[lo] : 0;
-        if (dq == 2) n = tilecull_trim_span(depth_limit, grid_x, ty, s_depth[lo], tx0, n);
-        if (dq == 3) n = tilecull_trim_span_segments(depth_limit + (size_t)grid_x * grid_y, grid_x, ty, s_depth[lo], tx0, n);
-        s_span_key[r] = ty * grid_x + tx0;
-        s_span_own[r] = (uint32_t)lo;
-      }
-      n4[j] = n;
-      local += n;
-    }
-    uint32_t chunk_total;
-    uint32_t off = block_exclusive_scan256(local, s_wsum, chunk_total);
-#pragma unroll
-    for (int j = 0; j < DUP_RC / GS_BLOCK; j++) {
-      const uint32_t r = tid * (DUP_RC / GS_BLOCK) + j;
-      if (r < nrow) s_span_off[r] = off;
-      off += n4[j];
-    }
-    if (tid == 0) s_span_off[nrow] = chunk_total;
-    __syncthreads();
-    // never write past what the prefix sum reserved (the two evaluations of the spans agree; this keeps the
-    // kernel memory-safe even if they did not)
-    const uint32_t room = expected - min(expected, written);
-    const uint32_t emit = min(chunk_total, room);
-    for (uint32_t k = tid; k < emit; k += GS_BLOCK) {
-      int lo = 0, hi = (int)nrow - 1;  // largest row with s_span_off[row] <= k
-#pragma unroll
-      for (int it = 0; it < 10; it++) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (s_span_off[mid] <= k) lo = mid; else hi = mid - 1;
-      }
-      tkeys[base + written + k] = s_span_key[lo] + (k - s_span_off[lo]);
-      tvals[base + written + k] = s_id[s_span_own[lo]];
-    }
-    if (nrow > 0) {
-      last_key = s_span_key[nrow - 1];
-      last_own = s_span_own[nrow - 1];
-    }
-    written += emit;
-    __syncthreads();  // the chunk arrays are rewritten by the next iteration
-  }
-  // (unreachable when both evaluations agree) fill what is left with a valid instance of this workgroup
-  for (uint32_t k = written + tid; k < expected; k += GS_BLOCK) {
-    tkeys[base + k] = last_key;
-    tvals[base + k] = s_id[last_own];
-  }
-}
-
-// rasterizer_impl.cu:116-138 (keys hold the tile id only)
-__global__ void __launch_bounds__(GS_BLOCK) tile_ranges_kernel(const uint32_t* __restrict__ tkeys, const uint32_t* n_dev,
-                                                               uint2* __restrict__ ranges) {
-  // four keys per thread (one 16-byte load + the key in front of them)
-  const uint32_t L = *n_dev;
-  const uint32_t i0 = (blockIdx.x * GS_BLOCK + threadIdx.x) * 4u;
-  if (i0 >= L) return;
-  uint32_t k[4];
-  if (i0 + 3 < L) {
-    const uint4 q = reinterpret_cast<const uint4*>(tkeys)[i0 >> 2];
-    k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; e++) k[e] = (i0 + e < L) ? tkeys[i0 + e] : 0u;
-  }
-  uint32_t prev = i0 ? tkeys[i0 - 1] : 0u;
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const uint32_t idx = i0 + e;
-    if (idx >= L) break;
-    const uint32_t cur = k[e];
-    if (idx == 0) {
-      ranges[cur].x = 0;
-    } else if (cur != prev) {
-      ranges[prev].y = idx;
-      ranges[cur].x = idx;
-    }
-    if (idx == L - 1) ranges[cur].y = L;
-    prev = cur;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T, hipStream_t s) {
   uint32_t cap32 = capacity > 0xFFFFFFFFll ? 0xFFFFFFFFu : (capacity < 0 ? 0u : (uint32_t)capacity);
   hipLaunchKernelGGL(bin_prepare_kernel, dim3((uint32_t)((T + GS_BLOCK - 1) / GS_BLOCK > 0 ? (T + GS_BLOCK - 1) / GS_BLOCK : 1)),
@@ -623,24 +421,7 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
   return 0;
 }
 
-int launch_emit_instances(const GeomView& g, int P, const uint32_t* n_ordered, int grid_x, int grid_y, int tile_cull,
-                          const float* tile_depth_limit, const uint32_t* order, uint32_t* tkeys, uint32_t* tvals, hipStream_t s,
-                          int debug) {
-  const int nb = (P + GS_BLOCK - 1) / GS_BLOCK;
-  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, order, g.tiles_touched, n_ordered, g.sorted_sums);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, g.sorted_sums, nb);
-  GS_LAUNCH_CHECK(s, debug);
-  hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(GS_BLOCK), 0, s, g, n_ordered, (uint32_t)grid_x, (uint32_t)grid_y,
-                     tile_cull, tile_cull ? tile_depth_limit : nullptr, order, g.sorted_sums, tkeys, tvals);
-  GS_LAUNCH_CHECK(s, debug);
-  return 0;
-}
-
-int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_bound, uint2* ranges, int T,
-                       hipStream_t s) {
-  // `ranges` was zeroed by launch_bin_prepare at the start of the phase
-  if (n_bound > 0)
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((uint32_t)((n_bound + 4 * GS_BLOCK - 1) / (4 * GS_BLOCK))), dim3(GS_BLOCK), 0, s,
-                       tkeys, n_dev, ranges);
+int launch_scan_sums(uint32_t* sums, int nb, hipStream_t s) {
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nb);
   return 0;
 }

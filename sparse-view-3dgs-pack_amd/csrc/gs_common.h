@@ -9,7 +9,9 @@
 //           block_sums / sorted_sums [ceil(P/256)+1] u32   workgroup sums of tiles_touched (index / depth order)
 //           gsort            radix-sort buffers of the per-Gaussian depth sort (16 B x P + histograms)
 //  img    : final_T[N] f32 | n_contrib[N] u32 | ranges[T] uint2 | tile_work[T] u32 | tile_order[T] u32 | region_count[<= T] u32
-//  binning: tile keys[2][cap] u32 | Gaussian ids[2][cap] u32 | radix histograms   (16 B per instance)
+//  binning: keys[2][cap] u32 | Gaussian ids[2][cap] u32 | radix histograms   (16 B per instance of capacity) | region / chunk /
+//           tile tables (gs_tilebin.hip).  tile_cull = 0 / 1: the arrays hold the region ENTRIES (key = region id | tile mask << 16)
+//           while they are partitioned, then ids[0] receives point_list
 //           region binning (GsView.tile_cull = 2): the key halves hold the region buckets [regions][cap / regions] of
 //           (depth bits, Gaussian index), Gaussian ids[0] is point_list
 //
@@ -154,8 +156,37 @@ static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T
   return v;
 }
 
-// binning buffer = one SortBufs over the instances: keys = tile id, values = Gaussian index
-static inline __host__ __device__ size_t bin_bytes(size_t cap) { return sort_bytes(cap); }
+// ---- two-level binning of tile_cull = 0 / 1 (gs_tilebin.hip): what lies behind the SortBufs in the binning buffer ----
+#define TB_CHUNK 1024  // entries of one region a workgroup counts / writes at a time
+struct TileBinView {
+  uint2* region_ranges;    // [regions] range of each region's entries in the partitioned entry arrays
+  uint32_t* chunk_first;   // [regions + 1] exclusive prefix of the regions' chunk counts
+  uint32_t* chunk_region;  // [max_chunks] region of each chunk
+  uint32_t* chunk_counts;  // [max_chunks][16] entries of each of the region's tiles in the chunk -> exclusive prefix over the region's chunks
+  uint32_t* tile_start;    // [T + 1] start of each tile's list in point_list (tile order)
+  uint32_t max_chunks;
+};
+// sum over regions of ceil(entries / TB_CHUNK) <= entries / TB_CHUNK + regions; entries <= capacity, regions <= T
+static inline __host__ __device__ size_t tilebin_max_chunks(size_t cap, size_t T) { return cap / TB_CHUNK + T + 1; }
+static inline __host__ __device__ size_t tilebin_bytes(size_t cap, size_t T) {
+  const size_t mc = tilebin_max_chunks(cap, T);
+  return gs_align(8 * T) + gs_align(4 * (T + 1)) + gs_align(4 * mc) + gs_align(64 * mc) + gs_align(4 * (T + 1));
+}
+static inline __host__ __device__ TileBinView tilebin_view(void* buf, size_t cap, size_t T) {
+  char* p = (char*)buf;
+  TileBinView v;
+  const size_t mc = tilebin_max_chunks(cap, T);
+  v.region_ranges = (uint2*)p; p += gs_align(8 * T);
+  v.chunk_first = (uint32_t*)p; p += gs_align(4 * (T + 1));
+  v.chunk_region = (uint32_t*)p; p += gs_align(4 * mc);
+  v.chunk_counts = (uint32_t*)p; p += gs_align(64 * mc);
+  v.tile_start = (uint32_t*)p;
+  v.max_chunks = (uint32_t)mc;
+  return v;
+}
+// binning buffer = one SortBufs sized for the instances (region entries: key = region id | tile mask << 16, value = Gaussian
+// index; ids[0] ends up as point_list) + the region / chunk / tile tables
+static inline __host__ __device__ size_t bin_bytes(size_t cap, size_t T) { return sort_bytes(cap) + tilebin_bytes(cap, T); }
 
 // per-Gaussian gradient row accumulated by the backward blend: FLOAT64 slots (round 4), one 128-B line per Gaussian.
 // A tile's totals are fp32 (fixed lane order, fixed reduction tree: deterministic); what is run-dependent is the order in
@@ -252,10 +283,10 @@ int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T
 // first_keys != NULL: the first pass reads its keys from there (left untouched) and takes value = index
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
                       const uint32_t* first_keys, hipStream_t s, int debug, uint32_t* n_kept = nullptr);
-int launch_emit_instances(const GeomView& g, int P, const uint32_t* n_ordered, int grid_x, int grid_y, int tile_cull, const float* tile_depth_limit,
-                          const uint32_t* order, uint32_t* tkeys, uint32_t* tvals, hipStream_t s, int debug);
-int launch_tile_ranges(const uint32_t* tkeys, const uint32_t* n_dev, int64_t n_host_bound, uint2* ranges, int T,
-                       hipStream_t s);
+int launch_scan_sums(uint32_t* sums, int nb, hipStream_t s);  // in-place exclusive scan of sums[nb], total -> sums[nb]
+// the lists of tile_cull = 0 / 1 from the depth order (g.gsort.vals[0]): gs_tilebin.hip
+int launch_tile_binning(const GeomView& g, const SortBufs& bv, const TileBinView& tb, int P, int64_t capacity, int grid_x, int grid_y,
+                        int tile_cull, const float* tile_depth_limit, uint2* ranges, int force_rowwise, hipStream_t s, int debug);
 
 // ---- region binning (gs_regionbin.hip) ----
 #define RG_TILES 4            // a region is RG_TILES x RG_TILES tiles (64 x 64 pixels)

@@ -35,7 +35,7 @@ struct KnnTmp {
 #define KNN_MM_BLOCKS 512
 static size_t knn_bytes(size_t P) {
   size_t nb = (P + KNN_BOX - 1) / KNN_BOX;
-  return sizeof(KnnHeader) + gs_align(KNN_MM_BLOCKS * 24) + gs_align(bin_bytes(P)) + gs_align(nb * 24) + gs_align(16 * P);
+  return sizeof(KnnHeader) + gs_align(KNN_MM_BLOCKS * 24) + gs_align(sort_bytes(P)) + gs_align(nb * 24) + gs_align(16 * P);
 }
 static KnnTmp knn_view(void* buf, size_t P) {
   char* p = (char*)buf;
@@ -44,7 +44,7 @@ static KnnTmp knn_view(void* buf, size_t P) {
   t.nb = (P + KNN_BOX - 1) / KNN_BOX;
   t.hdr = (KnnHeader*)p; p += sizeof(KnnHeader);
   t.partial = (float*)p; p += gs_align(KNN_MM_BLOCKS * 24);
-  t.bin = p; p += gs_align(bin_bytes(P));
+  t.bin = p; p += gs_align(sort_bytes(P));
   t.boxes = (float*)p; p += gs_align(t.nb * 24);
   t.sorted = (float4*)p;
   return t;

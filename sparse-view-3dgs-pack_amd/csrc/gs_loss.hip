@@ -98,6 +98,35 @@ __global__ void __launch_bounds__(GS_BLOCK) l1_bwd_kernel(const float* __restric
   }
 }
 
+// Depth regularisation of the step (LGDWT-GS/train.py:204-216): Ll1depth_pure = mean |(invDepth - mono) * mask|.  One pass
+// over the three images gives both the term (per-workgroup partial sums, added by the caller in index order) and its
+// gradient coef * sign((d - m) k) k - which does not depend on the sum, so the train step needs no second launch.
+__global__ void __launch_bounds__(GS_BLOCK) depth_l1_kernel(const float* __restrict__ d, const float* __restrict__ m,
+                                                            const float* __restrict__ k, int64_t n, float* __restrict__ partials,
+                                                            float coef, const float* __restrict__ coef_dev,
+                                                            float* __restrict__ grad) {
+  if (coef_dev) coef *= coef_dev[0];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * GS_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GS_BLOCK) {
+    const float w = k ? k[i] : 1.0f;
+    const float v = (d[i] - m[i]) * w;
+    acc += fabsf(v);
+    if (grad) grad[i] = coef * sgnf(v) * w;
+  }
+  if (partials) {
+    __shared__ float red[GS_BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < GS_BLOCK / 64; w++) t += red[w];
+      partials[blockIdx.x] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ single-level DWT
 __global__ void __launch_bounds__(GS_BLOCK) dwt_fwd_kernel(const float* __restrict__ x, int NC, int H, int W, float* ll,
                                                            float* lh, float* hl, float* hh) {
@@ -844,6 +873,18 @@ int gs_l1_fwd_p(const float* a, const float* b, int64_t n, float* partials, void
   GS_PROF(ST_L1, s);
   if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return GS_E_UNSUPPORTED;
   hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblocks(n / 4 + 1, GS_BLOCK, 512)), dim3(GS_BLOCK), 0, s, a, b, n, (float*)nullptr, partials);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+int64_t gs_depth_l1_partials_count(int64_t n) { return n <= 0 ? 0 : (int64_t)nblocks(n, 4 * GS_BLOCK, 1024); }
+int gs_depth_l1(const float* invdepth, const float* mono, const float* mask, int64_t n, float* partials, float coef,
+                const float* coef_dev, float* grad, void* stream) {
+  if (!invdepth || !mono || (!partials && !grad)) return GS_E_NULL;
+  if (n <= 0) return GS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GS_PROF(ST_L1, s);
+  hipLaunchKernelGGL(depth_l1_kernel, dim3(nblocks(n, 4 * GS_BLOCK, 1024)), dim3(GS_BLOCK), 0, s, invdepth, mono, mask, n, partials,
+                     coef, coef_dev, grad);
   GS_LAUNCH_CHECK(s, 0);
   return GS_OK;
 }

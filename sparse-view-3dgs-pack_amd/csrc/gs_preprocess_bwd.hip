@@ -203,7 +203,9 @@ __device__ __forceinline__ void nt_store4(float* p, float4 v) {
   w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
   __builtin_nontemporal_store(w, reinterpret_cast<gs_f4v*>(p));
 }
-// MODE (the two-phase step, StepArgs.phase; sel[r] = "Gaussian r of the workgroup's piece has NO instances"): the two
+// SPARSE ("sparse_adam", GsStepState.sparse; train.py:282-284): bit 1 of sel[r] = "Gaussian r is not visible in this view" -
+// its elements are left alone in every mode, and a float4 that holds nothing else is neither read nor written.
+// MODE (the two-phase step, StepArgs.phase; bit 0 of sel[r] = "Gaussian r of the workgroup's piece has NO instances"): the two
 // phases split the float4s of a piece between them - 1: only float4s ALL of whose elements belong to Gaussians without
 // instances (zero gradient); 2: the float4s with at least one element of a Gaussian WITH instances, every element of
 // them (the gradient image holds zeros for the others) - so every float4 is read and written once per step, as in
@@ -229,11 +231,12 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
       for (int u = 0; u < U; u++) {
         const int j = j0 + u * 4 * GS_BLOCK;
         any[u] = j < nfl;
-        if (MODE != 0 && j < nfl) {
+        if ((MODE != 0 || sel) && j < nfl) {
 #pragma unroll
           for (int e = 0; e < 4; e++) es[u][e] = sel[(j + e) / N];
-          const bool all_flagged = (es[u][0] & es[u][1] & es[u][2] & es[u][3]) != 0;
-          any[u] = MODE == 1 ? all_flagged : !all_flagged;
+          const unsigned char all = es[u][0] & es[u][1] & es[u][2] & es[u][3];
+          const bool all_flagged = (all & 1) != 0;
+          any[u] = (MODE == 0 || (MODE == 1 ? all_flagged : !all_flagged)) && (all & 2) == 0;
         }
         if (any[u]) {
           if (MODE == 1 && GS_PHASE1_NT) {  // phase 1 streams next to the backward blend: keep its lines out of that kernel's L2
@@ -255,7 +258,7 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const float lr = (LR_SPLIT > 0 && ((j + e) % 48) >= LR_SPLIT) ? lr_b : lr_a;
-            adam_update(pe[e], grad(j + e), me[e], ve[e], lr, isb, b1, b2, eps);
+            if (!(es[u][e] & 2)) adam_update(pe[e], grad(j + e), me[e], ve[e], lr, isb, b1, b2, eps);
             // phase 1 runs next to the backward blend, which needs the registers: one element's IEEE sqrt / division
             // temporaries at a time instead of four interleaved (the kernel waits on HBM, not on issue)
             if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
@@ -272,7 +275,8 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
     }
   } else {
     for (int j = threadIdx.x; j < nfl; j += GS_BLOCK) {
-      if (MODE != 0 && (sel[j / N] != 0) != (MODE == 1)) continue;
+      if (MODE != 0 && ((sel[j / N] & 1) != 0) != (MODE == 1)) continue;
+      if (sel && (sel[j / N] & 2)) continue;
       float pe = pf[j], me = mf[j], ve = vf[j];
       const float lr = (LR_SPLIT > 0 && (j % 48) >= LR_SPLIT) ? lr_b : lr_a;
       adam_update(pe, grad(j), me, ve, lr, isb, b1, b2, eps);
@@ -341,8 +345,10 @@ template <int PHASE>
 __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(PreprocessBwdArgs a, StepArgs sa) {
   __shared__ float s_sh[GS_BLOCK * SH_LDS_ROW];
   __shared__ float s_g[SG_TOTAL];
-  __shared__ unsigned char s_sel[PHASE == 0 ? 1 : GS_BLOCK];
+  __shared__ unsigned char s_sel_buf[GS_BLOCK];
   const GsStepState& st = sa.st;
+  const bool sparse = st.sparse != 0;
+  unsigned char* const s_sel = (PHASE != 0 || sparse) ? s_sel_buf : nullptr;   // (adam_block's flags; phase 0 needs them only when sparse)
   const bool grads_out = st.grad_out[0] != nullptr;  // data-parallel form: gradients out, no Adam (gsplat.h)
   // the forward ran out of binning capacity (possible only when the caller did not re-run it: a replayed graph): the
   // image was not rendered, so nothing may be updated - the host sees the flag and repeats the step eagerly
@@ -385,7 +391,8 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   // still counts as seen (statistics) and still takes its Adam step, but its records, sums and SH row are not read
   const bool instanced = !(a.skip_uninstanced && a.tiles_touched[idx] == 0);
   const bool mine = PHASE == 0 || (in_range && instanced);  // this launch does this Gaussian's statistics
-  if (PHASE != 0) s_sel[tid] = (in_range && !instanced) ? 1 : 0;  // (adam_block's flag: a Gaussian WITHOUT instances)
+  // adam_block's flags: bit 0 = a Gaussian WITHOUT instances (the other phase's), bit 1 = not stepped at all (sparse_adam: not visible)
+  if (s_sel) s_sel[tid] = (unsigned char)(((PHASE != 0 && in_range && !instanced) ? 1 : 0) | ((sparse && !visible) ? 2 : 0));
   const bool active = visible && instanced;
 
   GeomBack gb = {};
@@ -411,6 +418,10 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
   const bool gain_block = st.extra && blockIdx.x == 0;  // (gain_step below is this workgroup's)
   if (PHASE == 2 && !grads_out && !gain_block) {
     if (!__syncthreads_or((in_range && instanced) ? 1 : 0)) return;
+  }
+  // ... and with sparse_adam the one-launch form has nothing to do for a workgroup without a visible Gaussian
+  if (PHASE == 0 && sparse && !grads_out && !gain_block) {
+    if (!__syncthreads_or((in_range && visible) ? 1 : 0)) return;
   }
   // ---- activation backward of this Gaussian's rows into the LDS gradient image
   {
@@ -546,6 +557,7 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) step_uninstanced_kernel(Preproces
     }
   }
   const float b1 = st.beta1, b2 = st.beta2, eps = st.eps;
+  const bool sparse = st.sparse != 0;
   const int tid = threadIdx.x;
   struct Zero {
     __device__ __forceinline__ float operator()(int) const { return 0.f; }
@@ -567,17 +579,19 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) step_uninstanced_kernel(Preproces
     const int idx = blk * GS_BLOCK + tid;
     const bool in_range = idx < a.P;
     const bool mine = in_range && a.tiles_touched[idx] == 0;
-    s_sel[tid] = mine ? 1 : 0;
+    const int radius = (mine && (st.max_radii2D || sparse)) ? a.radii[idx] : 0;
+    const bool frozen = sparse && radius <= 0;   // sparse_adam: a Gaussian that is not visible in this view is not stepped
+    s_sel[tid] = (unsigned char)((mine ? 1 : 0) | (frozen ? 2 : 0));
     if (mine && st.max_radii2D) {  // seen, with a zero gradient (train.py:266-268)
-      const int radius = a.radii[idx];
       if (radius > 0) {
         st.max_radii2D[idx] = fmaxf(st.max_radii2D[idx], (float)radius);
         st.denom[idx] += 1.0f;   // (xyz_gradient_accum += 0)
       }
     }
-    __syncthreads();
-    // a dormant block (GsStepState.dormant: every moment of every row +0): the zero-gradient update changes nothing
-    if (st.dormant && eps > 0.f && st.dormant[blk] != 0) {
+    const int live = __syncthreads_or((mine && !frozen) ? 1 : 0);
+    // a dormant block (GsStepState.dormant: every moment of every row +0): the zero-gradient update changes nothing;
+    // a block none of whose Gaussians this launch steps (all of them instanced, or - sparse_adam - not visible) likewise
+    if (!live || (st.dormant && eps > 0.f && st.dormant[blk] != 0)) {
       __syncthreads();  // (s_sel is rewritten by the next block)
       continue;
     }

@@ -91,7 +91,7 @@ class GsLgdwtParams(C.Structure):
 
 class GsAdamSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr_a", C.c_float), ("lr_b", C.c_float),
-                ("period", C.c_int32), ("split", C.c_int32), ("step", C.c_int32), ("_pad", C.c_int32)]
+                ("period", C.c_int32), ("split", C.c_int32), ("step", C.c_int32), ("row_width", C.c_int32)]
 
 
 class GsStepState(C.Structure):
@@ -106,7 +106,7 @@ class GsStepState(C.Structure):
                 ("extra", C.c_void_p), ("extra_m", C.c_void_p), ("extra_v", C.c_void_p), ("gain", C.c_void_p),
                 ("gain_m", C.c_void_p), ("gain_v", C.c_void_p), ("lr_extra", C.c_float), ("lr_gain", C.c_float),
                 ("step_extra", C.c_int32), ("step_gain", C.c_int32), ("grad_out_extra", C.c_void_p),
-                ("grad_out_gain", C.c_void_p), ("grad_mask", C.c_void_p), ("dormant", C.c_void_p)]
+                ("grad_out_gain", C.c_void_p), ("grad_mask", C.c_void_p), ("dormant", C.c_void_p), ("sparse", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -170,6 +170,8 @@ PROTOTYPES = {
     "l1_dwt2_patch_fwd_clamp_p": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "l1_partials_count": (C.c_int64, [_I64]),
     "l1_fwd_p": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "depth_l1_partials_count": (C.c_int64, [_I64]),
+    "depth_l1": (C.c_int, [_P, _P, _P, _I64, _P, _F, _P, _P, _P]),
     "lgdwt_combine_pp": (C.c_int, [_P, _P, _I64, _P, _I64, _P, _I64, _P, C.POINTER(GsLgdwtParams), _P, _P]),
     "l1_bwd_dev": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P]),
     "l1_dwt2_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P]),
@@ -185,6 +187,7 @@ PROTOTYPES = {
     "ssim_fwd_partials": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "adam_step": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P]),
     "adam_step_gated": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P, _P]),
+    "adam_step_masked": (C.c_int, [_P, _P, _P, _P, _I64, C.POINTER(GsAdamSeg), _I32, _F, _F, _F, _I32, _P, _P, _P]),
     "activations_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P]),
     "activations_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "densify_stats": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P]),

@@ -165,7 +165,30 @@ class LossOps:
                              _stream(img1))
                 return None, None, grad, None, None, None
 
+        class _DepthL1(torch.autograd.Function):
+            """Ll1depth_pure of LGDWT-GS/train.py:204-216: mean |(invDepth - mono_invdepth) * depth_mask|."""
+
+            @staticmethod
+            def forward(ctx, invdepth, mono, mask):
+                d, m = _c(invdepth), _c(mono)
+                k = None if mask is None else _c(mask)
+                n = d.numel()
+                part = torch.empty((int(ops.api.raw("depth_l1_partials_count")(n)),), dtype=torch.float32, device=d.device)
+                ops.api.call("depth_l1", d.data_ptr(), m.data_ptr(), _p(k), n, part.data_ptr(), 0.0, None, None, _stream(d))
+                ctx.save_for_backward(d, m, k)
+                return (part.sum() / n).reshape(())
+
+            @staticmethod
+            def backward(ctx, g):
+                d, m, k = ctx.saved_tensors
+                coef = g.reshape(1).to(torch.float32).contiguous()
+                grad = torch.empty_like(d)
+                ops.api.call("depth_l1", d.data_ptr(), m.data_ptr(), _p(k), d.numel(), None, 1.0 / d.numel(), coef.data_ptr(),
+                             grad.data_ptr(), _stream(d))
+                return grad, None, None
+
         self._L1, self._Haar, self._Dwt2L1, self._PatchDwt, self._SSIMMap = _L1, _Haar, _Dwt2L1, _PatchDwt, _SSIMMap
+        self._DepthL1 = _DepthL1
 
     # ---------------------------------------------------------------- loss_utils.py names
     def unit_grad(self, device):
@@ -180,6 +203,22 @@ class LossOps:
 
     def l1_loss(self, network_output, gt):
         return self._L1.apply(network_output, gt)
+
+    def depth_l1(self, invdepth, mono_invdepth, depth_mask=None):
+        """The pure depth-regularisation term of LGDWT-GS/train.py:204-216 on the rasterizer's inverse-depth output:
+        torch.abs((invDepth - mono_invdepth) * depth_mask).mean(); the caller multiplies by depth_l1_weight(iteration)."""
+        return self._DepthL1.apply(invdepth, mono_invdepth, depth_mask)
+
+    def depth_l1_step(self, invdepth, mono_invdepth, depth_mask, weight):
+        """The same term for a train step that drives the backward itself: ONE launch -> (weight * term, dL/dinvDepth of it)."""
+        d, m = _c(invdepth), _c(mono_invdepth)
+        k = None if depth_mask is None else _c(depth_mask)
+        n = d.numel()
+        part = torch.empty((int(self.api.raw("depth_l1_partials_count")(n)),), dtype=torch.float32, device=d.device)
+        grad = torch.empty_like(d)
+        self.api.call("depth_l1", d.data_ptr(), m.data_ptr(), _p(k), n, part.data_ptr(), float(weight) / n, None, grad.data_ptr(),
+                      _stream(d))
+        return part.sum() * (float(weight) / n), grad
 
     def fused_ssim(self, img1, img2, padding="same", train=True):
         """fused-ssim/fused_ssim/__init__.py:34-41: img [B,C,H,W] -> scalar mean SSIM."""

@@ -135,6 +135,8 @@ class RasterBackend:
         v.scale_modifier = float(scale_modifier)
         v.sh_degree = int(degree)
         v.prefiltered, v.antialiasing, v.debug = int(bool(prefiltered)), int(bool(antialiasing)), int(bool(debug))
+        if self.force_rowwise_entries:   # (test hook: GsView.debug bit 1, csrc/gs_tilebin.hip)
+            v.debug |= 2
         v.tile_cull = int(self.tile_cull)
         if self.tile_cull and self.binning in ("region", "auto") and device.type == "cuda" and \
                 (self._region_key is None or self._region_key not in self._region_off):
@@ -396,6 +398,7 @@ class RasterBackend:
     # kernel of gs_backward_step (phase 2) waits for it.  From TWO_PHASE_MIN_P Gaussians on (below, the extra launch and
     # the stream hand-offs cost more than the hidden stream saves); GS_TWO_PHASE_STEP=0 switches it off.
     # depth-limited lists for callers that name their cameras (GaussianRasterizer.camera_key); GS_KEYED_LIMITS=0: never
+    force_rowwise_entries = False
     KEYED_LIMITS = os.environ.get("GS_KEYED_LIMITS", "1") != "0"
     # region-binned forwards whose verdict is collected later (deferred eager steps, replayed graphs): the status block is
     # written into the pinned host block by the forward's own last kernel (GsScratch.status_host) instead of by a copy

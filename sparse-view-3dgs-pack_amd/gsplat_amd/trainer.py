@@ -66,6 +66,12 @@ class FlatAdam:
         self.lr = dict(LRS)
         self.lr["xyz"] = LRS["xyz"] * model.spatial_lr_scale
         self._Seg = GsAdamSeg
+        # optimizer_type = "sparse_adam" (arguments/__init__.py:101, train.py:282-284: `visible = radii > 0;
+        # optimizer.step(visible, N)`): only the Gaussians visible in the step's view(s) are stepped; parameters and moments of
+        # the others keep their bits.  (The optimizer class the reference would use, SparseGaussianAdam, lives in the 3dgs_accel
+        # branch of the rasterizer, which the reference does not vendor - its pinned branch is dr_aa; the update applied to a
+        # visible row here is torch.optim.Adam's, bias correction by the group's step count included.)
+        self.sparse = False
 
     def alloc_moments(self):
         """Zeroed moment buffers for the model's current size, padded like the parameters (the sharded optimizer
@@ -121,15 +127,17 @@ class FlatAdam:
                 else:
                     segs[k].lr_a, segs[k].lr_b, segs[k].period, segs[k].split = self.lr[name], 0.0, 0, 0
                 segs[k].step = self.seg_steps[name]
+                segs[k].row_width = n
                 k += 1
             off += P * n
         return segs, k
 
-    def step(self, skip=()):
+    def step(self, skip=(), row_mask=None):
         """skip: fields without a gradient this iteration (their tensor was replaced after backward: torch's
-        optimizer.step() leaves such a parameter, its moments and its step count alone)."""
+        optimizer.step() leaves such a parameter, its moments and its step count alone).
+        row_mask (sparse_adam): float [P], > 0 = the Gaussian is stepped."""
         self.begin_step(skip)
-        self.step_range(0, self.model.flat.numel(), skip)
+        self.step_range(0, self.model.flat.numel(), skip, row_mask=row_mask)
 
     def begin_step(self, skip=()):
         self.t += 1
@@ -179,7 +187,7 @@ class FlatAdam:
         self._nir_into(st, True)
         return st
 
-    def step_range(self, lo, hi, skip=(), grads=None, gate=None):
+    def step_range(self, lo, hi, skip=(), grads=None, gate=None, row_mask=None):
         """The update of elements [lo, hi) of the flat buffers (lo a multiple of 4): the data-parallel step applies
         Adam chunk by chunk as the chunks of the gradient all-reduce arrive.  The segment table is shifted by -lo so
         that the kernel's element index i stands for element lo + i (a negative `begin` keeps the phase of the
@@ -196,6 +204,14 @@ class FlatAdam:
         stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
         # grads: a tensor holding the gradients of elements [lo, hi) (default: that slice of the flat gradient buffer)
         gptr = m.flat_grad.data_ptr() + 4 * lo if grads is None else grads.data_ptr()
+        if self.sparse:
+            if row_mask is None:
+                raise RuntimeError("sparse_adam: the step needs the view's visibility (row_mask)")
+            self.api.call("adam_step_masked", m.flat.data_ptr() + 4 * lo, gptr,
+                          self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
+                          self.betas[0], self.betas[1], self.eps, self.t, None if gate is None else gate.data_ptr(),
+                          row_mask.data_ptr(), stream)
+            return
         if gate is not None:  # a device float: the update is a no-op on the device when it is non-zero (gs_adam_step_gated)
             self.api.call("adam_step_gated", m.flat.data_ptr() + 4 * lo, gptr,
                           self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
@@ -261,6 +277,7 @@ class FlatAdam:
             st.step_extra = 0
         if self.USE_DORMANT and m.flat.is_cuda:
             st.dormant = self.dormant_flags().data_ptr()
+        st.sparse = 1 if self.sparse else 0
         return st
 
     def field_views(self, buf):
@@ -867,6 +884,9 @@ class TrainOptions:
         self.min_opacity = 0.005          # train.py:273
         self.size_threshold = 20          # train.py:272
         self.sh_increase_interval = 1000  # train.py:102
+        self.depth_l1_weight_init = 1.0   # arguments/__init__.py:98-99; train.py:69: expon schedule over `iterations`
+        self.depth_l1_weight_final = 0.01
+        self.optimizer_type = "default"   # arguments/__init__.py:101 ("sparse_adam": Trainer(optimizer_type=...))
         self.white_background = False
         self.cameras_extent = 1.0         # scene.cameras_extent = getNerfppNorm radius (dataset_readers.py:48-69)
         self.seed = 0
@@ -887,7 +907,7 @@ class Trainer:
     `train_iteration(it, opt)` is one iteration of the reference's loop with its schedule."""
 
     def __init__(self, model, cameras, gt_images, criterion, Rasterizer, Settings, bg, rank=0, world_size=1,
-                 optimizer_step=True, masks=None, sharded_optimizer=None, sparse_exchange=None):
+                 optimizer_step=True, masks=None, sharded_optimizer=None, sparse_exchange=None, optimizer_type="default"):
         # sharded_optimizer (default: env GS_SHARDED_ADAM=1): reduce-scatter the gradients, Adam on this rank's 1/N of
         # the rows, all-gather the parameters - instead of all-reduce + the full Adam pass on every replica
         import os
@@ -902,11 +922,27 @@ class Trainer:
         self.sparse_exchange = (os.environ.get("GS_SPARSE_EXCHANGE", "0") == "1") if sparse_exchange is None \
             else bool(sparse_exchange)
         self.last_exchange = None
+        # optimizer_type = "sparse_adam" (train.py:68, 282-284): only the Gaussians with radii > 0 in the step's view - on N
+        # GPUs: in SOME rank's view - are stepped (FlatAdam.sparse).  The moments then cannot be sharded by element range
+        # (a shard would need the visibility of rows it does not own the statistics of): all-reduce or sparse exchange.
+        if optimizer_type not in ("default", "sparse_adam"):
+            raise ValueError("optimizer_type must be 'default' or 'sparse_adam'")
+        self.optimizer_type = optimizer_type
+        if optimizer_type == "sparse_adam":
+            if not isinstance(model.optimizer, FlatAdam):
+                raise RuntimeError("sparse_adam needs the flat Adam state (a model built with an api)")
+            model.optimizer.sparse = True
+            self.sharded_optimizer = False
         self.model, self.cameras, self.gts, self.criterion = model, cameras, gt_images, criterion
         self.Rasterizer, self.Settings, self.bg = Rasterizer, Settings, bg
         self.rank, self.world_size = rank, world_size
         self.optimizer_step = optimizer_step
         self.masks = masks  # per-camera ELF patch masks (depend on the ground truth only): cached
+        # Depth regularisation (train.py:204-216): per camera None or (mono_invdepth [1,H,W], depth_mask [1,H,W] or None) - the
+        # reference's viewpoint_cam.invdepthmap / depth_mask of a camera with depth_reliable (scene/cameras.py:60-80) - and the
+        # current weight (train_iteration sets it from the schedule of train.py:69; 0 = term off)
+        self.depth_priors = None
+        self.depth_l1_weight = 0.0
         self.last = None
         # who this trainer is in the backend's per-camera state (keys ("trainer", uid, camera index)): a counter, not id() -
         # the address of a dead trainer is handed to the next one, which would then inherit its cameras' hints and limits
@@ -957,6 +993,8 @@ class Trainer:
                                exposure_max_steps=opt.iterations)
         if iteration % opt.sh_increase_interval == 0:
             m.oneupSHdegree()
+        if self.depth_priors is not None:   # train.py:69
+            self.depth_l1_weight = expon_lr(iteration, opt.depth_l1_weight_init, opt.depth_l1_weight_final, max_steps=opt.iterations)
         ci = self.draw_cameras(opt.seed)
         # What the schedule will do after the backward is known beforehand, so the optimizer step can run inside the
         # step (fused into the backward on one GPU, overlapped with the all-reduce on several).  Its order against
@@ -1103,10 +1141,16 @@ class Trainer:
                                              empty, rs)
             verdict = backend.take_deferred() if deferred else None
             loss, parts = self.criterion.fused_call(color, self.gts[ci], mask=mask, manual_ctx=lctx)
+            grad_depth = None
+            prior = self._depth_prior(ci)
+            if prior is not None:   # train.py:204-216: one launch gives the term and its inverse-depth image gradient
+                dl, grad_depth = self.criterion.ops.depth_l1_step(depth, prior[0], prior[1], self.depth_l1_weight)
+                loss = loss + dl
+                parts = dict(parts, depth_l1=dl)
             self._arm_side_launch(backend.launch_uninstanced_early)
             from .losses import FusedLGDWTLoss
             grad_img = FusedLGDWTLoss.backward(lctx, self.criterion.ops.unit_grad(loss.device), None)[1]
-            fn.backward(rctx, grad_img, None, None)
+            fn.backward(rctx, grad_img, None, grad_depth)
         pkg = {"render": color, "viewspace_points": None, "visibility_filter": None, "radii": radii, "depth": depth}
         return pkg, loss, parts, verdict
 
@@ -1117,10 +1161,24 @@ class Trainer:
                       clamp=not fused, fused=True, use_trained_exp=m.exposure is not None, camera_index=ci,
                       raw_activations=raw, camera_key=("trainer", self.uid, ci))
 
+    def _depth_prior(self, ci):
+        """(mono_invdepth, depth_mask) of camera ci when the depth term is on for it (train.py:206), else None"""
+        if self.depth_priors is None or not self.depth_l1_weight > 0:
+            return None
+        return self.depth_priors[ci]
+
+    def _depth_term(self, pkg, ci, loss, parts):
+        prior = self._depth_prior(ci)
+        if prior is None:
+            return loss, parts
+        dl = self.depth_l1_weight * self.criterion.ops.depth_l1(pkg["depth"], prior[0], prior[1])
+        return loss + dl, dict(parts, depth_l1=dl.detach())
+
     def _criterion_backward(self, pkg, ci, mask, fused, side_launch):
         """-> (loss, parts); runs the backward.  side_launch: callable that issues the two-phase step's side launch (or None)"""
         if fused:
             loss, parts = self.criterion.fused_call(pkg["render"], self.gts[ci], mask=mask)
+            loss, parts = self._depth_term(pkg, ci, loss, parts)
             # two-phase step: the Adam stream of the Gaussians without instances starts on its side stream from inside the
             # criterion's backward (RasterBackend.UNINST_AT) - it needs nothing of the loss - and runs beside the blend
             self._arm_side_launch(side_launch)
@@ -1128,6 +1186,7 @@ class Trainer:
             torch.autograd.backward(loss, self.criterion.ops.unit_grad(loss.device))
         else:
             loss, parts = self.criterion(pkg["render"], self.gts[ci], mask=mask)
+            loss, parts = self._depth_term(pkg, ci, loss, parts)
             loss.backward()
         return loss, parts
 
@@ -1144,6 +1203,7 @@ class Trainer:
 
     def _unfused_tail(self, pkg, radii, optimizer_step, skip):
         m = self.model
+        self.last_radii = radii
         with torch.no_grad():
             m.collect_grads()
             m.update_view_statistics(radii, pkg["viewspace_points"].grad, into_delta=self.world_size > 1)
@@ -1257,7 +1317,10 @@ class Trainer:
         chunked = isinstance(opt, FlatAdam)
         if self.world_size <= 1:
             if optimizer_step:
-                opt.step(*([skip] if skip else []))
+                if getattr(opt, "sparse", False):   # train.py:283: visible = radii > 0
+                    opt.step(skip, row_mask=(self.last_radii > 0).to(torch.float32))
+                else:
+                    opt.step(*([skip] if skip else []))
             return
         timed = getattr(self, "exchange_events", None) is not None and m.flat.is_cuda
         if timed:  # bench.py: how long the compute stream sees the exchange + optimizer take
@@ -1293,10 +1356,15 @@ class Trainer:
         wmax = dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)
         if optimizer_step and chunked:
             opt.begin_step(skip)
+        sparse = chunked and opt.sparse
         for i, w in enumerate(works):
             w.wait()
-            if optimizer_step and chunked:
+            if optimizer_step and chunked and not sparse:
                 opt.step_range(bounds[i], min(bounds[i + 1], n_grad), skip, gate=gate)
+        if optimizer_step and sparse:
+            # sparse_adam: the rows to step are those visible in some rank's view - the summed `denom` increments, which
+            # travel behind the gradients in the last chunk: one update when everything has arrived
+            opt.step_range(0, n_grad, skip, gate=gate, row_mask=m.stat_delta[1])
         if optimizer_step and not chunked:
             opt.step()
         wmax.wait()
@@ -1350,11 +1418,11 @@ class Trainer:
                 src.index_copy_(0, idx, dst)
         self.last_exchange = dict(union_rows=K, rows=P, sparse_bytes=4 * K * W + P + 4 * int(m.stat_tail.numel()),
                                   dense_bytes=4 * (n_grad + int(m.stat_tail.numel())))
-        if gate is not None:
-            ws.wait()  # the gate is the reduced flag
+        if gate is not None or opt.sparse:
+            ws.wait()  # the gate is the reduced flag; sparse_adam: the summed visibility is the rows to step
         if optimizer_step:
             opt.begin_step(skip)
-            opt.step_range(0, n_grad, skip, gate=gate)
+            opt.step_range(0, n_grad, skip, gate=gate, row_mask=m.stat_delta[1] if opt.sparse else None)
         ws.wait()
         wmax.wait()
         self._add_statistics(gate)
@@ -1559,6 +1627,7 @@ class TrainerNIR(Trainer):
 
     def _unfused_tail(self, pkg, radii, optimizer_step, skip):
         m = self.model
+        self.last_radii = radii
         with torch.no_grad():
             m.collect_grads()
             vg = pkg["viewspace_points"].grad
@@ -1905,9 +1974,10 @@ class GraphedStep:
         self.settle()
         ci = tr.camera_index(k)
         be = self._backend()
-        if tr.model.exposure is not None or not tr._fused_step_ok(be, True) or be._capacity_hint <= 0:
-            # what the capture cannot hold (a torch optimizer for the exposure, N > 1, ...), or no view has been
-            # rendered yet to size the binning capacity from
+        if tr.model.exposure is not None or not tr._fused_step_ok(be, True) or be._capacity_hint <= 0 or \
+                tr._depth_prior(ci) is not None:
+            # what the capture cannot hold (a torch optimizer for the exposure, N > 1, the depth term's weight - a kernel
+            # argument that changes every iteration - ...), or no view has been rendered yet to size the binning capacity from
             self.eager_steps += 1
             self.s_loss = tr._step_camera(ci, True, ())
             return self.s_loss

@@ -38,6 +38,9 @@ Fixtures are data only (inputs + the reference's outputs); no reference source i
                   Haar analysis step - in sys.modules; everything AROUND the 2x2 Haar butterfly (band slicing, unfold
                   order, kthvalue index, ">=" selection, the HH weight, 1e-8, align_corners=False, l1 means) is the
                   reference's code running.  -> pins D1 (layout), D2, D3, D4 of SURVEY 8(a)
+  depth_reg.npz   the depth-regularisation term of the step (LGDWT-GS/train.py:69, 204-216): the reference's own statements,
+                  read from train.py by gen_depth_reg when it runs and executed on CPU stand-ins; weights of the schedule,
+                  the term, its gradient w.r.t. the rendered inverse depth -> pins gs_depth_l1_* and Trainer's depth term
 """
 import importlib.util
 import math
@@ -373,7 +376,62 @@ def gen_lgdwt_loss():
     np.savez_compressed(os.path.join(HERE, "lgdwt_loss.npz"), **out)
 
 
+def gen_depth_reg():
+    """depth_reg.npz: the depth-regularisation term of the step, LGDWT-GS/train.py:69 (the weight schedule) and :204-216 (the
+    term).  train.py cannot be imported (CUDA, the scene stack, argparse at import), so the generator READS those statements
+    from the reference file when it runs, compiles them and executes them on CPU stand-ins for `viewpoint_cam` and `render_pkg`
+    (tensors whose .cuda() is the identity): the reference's own statements compute the fixture - nothing of them is kept in
+    this repository.  Outputs: the weights at a few iterations, and per case the pure term, the total loss increment and the
+    autograd gradient with respect to the rendered inverse depth."""
+    import argparse
+    import textwrap
+    import types
+    src = open(REF + "/LGDWT-GS/train.py").read().split("\n")
+    sched = [l for l in src if l.strip().startswith("depth_l1_weight = get_expon_lr_func(")]
+    assert len(sched) == 1, sched
+    a = next(i for i, l in enumerate(src) if l.strip() == "# Depth regularization")
+    b = next(i for i in range(a, len(src)) if src[i].strip() == "loss.backward()")
+    block = textwrap.dedent("\n".join(src[a + 1:b]))
+    assert "Ll1depth_pure" in block and "depth_mask" in block and block.count("\n") < 20
+    args = load(REF + "/LGDWT-GS/arguments/__init__.py", "ref_lgdwt_arguments_depth")
+    opt = args.OptimizationParams(argparse.ArgumentParser())
+    ns = dict(get_expon_lr_func=general.get_expon_lr_func, opt=opt, torch=torch)
+    exec(compile(sched[0].strip(), "train.py:69", "exec"), ns)
+    its = np.array([1, 100, 1000, 7000, 15000, 29999, 30000])
+    out = dict(weight_init=np.array(opt.depth_l1_weight_init), weight_final=np.array(opt.depth_l1_weight_final),
+               iterations=np.array(opt.iterations), weight_at=its, weight=np.array([ns["depth_l1_weight"](int(i)) for i in its]))
+
+    class OnCpu:   # viewpoint_cam.invdepthmap.cuda() / .depth_mask.cuda()
+        def __init__(self, t):
+            self.t = t
+
+        def cuda(self):
+            return self.t
+    g = torch.Generator().manual_seed(20261005)
+    code = compile(block, "train.py:204-216", "exec")
+    for tag, (H, W), it, reliable in (("a", (40, 56), 1, True), ("b", (75, 141), 7000, True), ("c", (32, 32), 100, False)):
+        inv = (torch.rand((1, H, W), generator=g) * 0.8).requires_grad_(True)
+        mono = torch.rand((1, H, W), generator=g) * 0.8
+        mono[:, 3:9, 5:20] = inv.detach()[:, 3:9, 5:20]           # exact ties: sign(0) = 0
+        mask = (torch.rand((1, H, W), generator=g) > 0.25).float()
+        mask[:, : H // 4] *= 0.5                                   # the mask is a weight, not only 0 / 1 (cameras.py:63)
+        cam = types.SimpleNamespace(depth_reliable=reliable, invdepthmap=OnCpu(mono), depth_mask=OnCpu(mask))
+        ns2 = dict(ns, iteration=it, viewpoint_cam=cam, render_pkg={"depth": inv}, loss=torch.zeros(()), torch=torch)
+        exec(code, ns2)
+        loss = ns2["loss"]
+        if loss.requires_grad:
+            loss.backward()
+        out["invdepth_" + tag], out["mono_" + tag], out["mask_" + tag] = inv.detach().numpy(), mono.numpy(), mask.numpy()
+        out["iteration_" + tag], out["reliable_" + tag] = np.array(it), np.array(reliable)
+        out["pure_" + tag] = np.array(float(ns2["Ll1depth_pure"]))
+        out["loss_" + tag] = np.array(float(loss))
+        out["logged_" + tag] = np.array(float(ns2["Ll1depth"]))
+        out["grad_" + tag] = np.zeros_like(out["invdepth_" + tag]) if inv.grad is None else inv.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "depth_reg.npz"), **out)
+
+
 if __name__ == "__main__":
+    gen_depth_reg()
     gen_lgdwt_loss()
     gen_sh()
     gen_cameras()

@@ -33,7 +33,7 @@ def test_hip_library_exports_every_declared_symbol_and_loads():
     assert os.path.exists(LIB_PATH), "libgsplat_hip.so not built (python __graft_entry__.py)"
     assert exported(LIB_PATH, "gs_") == header_functions()
     api = hip_api()  # dlopen + bind every prototype; no device call
-    assert api.raw("abi_version")() == 5
+    assert api.raw("abi_version")() == 6
     assert b"gfx950" in api.raw("build_info")()
     # pure host entry: scratch sizing
     out = (ctypes.c_size_t * 3)()
