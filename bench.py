@@ -267,10 +267,13 @@ def valu_roofline(kernel, ms_per_launch, P=None, R=None, counters="sq_insts.json
         return {"bound": "valu", "achieved": None, "frac": None, "dropped": why}
     ceil = measured_valu_ceilings()
     ach = insts / (ms_per_launch * 1e-3) / 1e9
-    return {"bound": "valu", "achieved": ach, "peak": ceil["fma"], "unit": "G wave-instructions/s",
-            "frac": ach / ceil["fma"], "insts_per_launch": insts,
-            "peak_from": ceil["from"], "peak_nominal": VALU_PEAK_NOMINAL_GINST,
-            "frac_of_nominal": ach / VALU_PEAK_NOMINAL_GINST,
+    # `frac` / `peak` = against the NOMINAL issue peak (1 024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction); the measured
+    # ceiling of a plain-f32 stream (0.90 of it at 4 waves per SIMD) beside it
+    return {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_NOMINAL_GINST, "unit": "G wave-instructions/s",
+            "frac": ach / VALU_PEAK_NOMINAL_GINST, "insts_per_launch": insts,
+            "peak_from": "nominal: 1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md)",
+            "peak_measured": ceil["fma"], "peak_measured_from": ceil["from"],
+            "frac_of_measured_ceiling": ach / ceil["fma"],
             "mix_ceiling": ceil["blendmix"],
             "mix_ceiling_note": "measured rate of a stream of 11 plain f32 ops per v_exp_f32 (the alpha test's shape): a "
                                 "transcendental costs ~7 plain issue slots, so a kernel with them cannot reach `peak`",
@@ -332,10 +335,11 @@ def main():
     # single GPU: the steady-state step is replayed from a hipGraph (gsplat_amd.trainer.GraphedStep: same kernels and
     # arguments as the eager step, one graph launch instead of ~45 kernel launches with their Python glue);
     # GS_BENCH_GRAPH=0 times the eager step.  The event timers need eager launches: stage passes run eagerly.
-    # GS_BENCH_GRAPH = auto (default): both forms are timed over a few untimed steps and the faster one runs the timed
-    # region (a replay saves the launches and their Python glue but waits for the device once per step, which costs
-    # more than it saves once a step is longer than ~1 ms: C1 0.75 -> 0.50 ms, C3 1.57 -> 1.63 ms); 0 / 1 force a form.
-    graph_mode = os.environ.get("GS_BENCH_GRAPH", "auto")
+    # GS_BENCH_GRAPH: 0 (default since round 5) = the eager step - since the step left the autograd engine (round 4) the replay
+    # no longer wins at C1 or C3 (0.349 vs 0.326 ms, 0.955 vs 0.867 ms: profiles/r04_bench_c*.json), only at C2 - so the bench
+    # no longer picks a form by trial; auto = both forms are timed over a few untimed steps and the faster one runs the
+    # timed region; 1 = the replay.
+    graph_mode = os.environ.get("GS_BENCH_GRAPH", "0")
     nir_unfused = args.config in NIR_CONFIGS and os.environ.get("GS_BENCH_NIR_FUSED", "1") == "0"
     use_graph = world == 1 and not nir_unfused and graph_mode != "0"
     graphed, graph_choice = None, None
@@ -817,7 +821,13 @@ def main():
             roofline.update({"kernel": dom, "traffic": None, "algorithmic_bytes_per_launch": sb[dom],
                              "ms_per_launch": stages[dom]["ms_per_launch"],
                              "step_algorithmic_GB_per_view": (902 * P + 172 * R_last + 84 * N) / 1e9,
-                             "step_algorithmic_GBps": (902 * P + 172 * R_last + 84 * N) / 1e9 * value / world})
+                             "step_algorithmic_GBps": (902 * P + 172 * R_last + 84 * N) / 1e9 * value / world,
+                             # SURVEY 8(d)'s byte model ends at the gradients; the timed step also holds the optimizer:
+                             # parameters and both moments of all 59 floats read and written (the fused step never writes
+                             # or re-reads the gradients): + 24 B x 59 x P
+                             "step_algorithmic_GB_per_view_with_optimizer": (902 * P + 172 * R_last + 84 * N + 24 * 59 * P) / 1e9,
+                             "step_algorithmic_GBps_with_optimizer":
+                                 (902 * P + 172 * R_last + 84 * N + 24 * 59 * P) / 1e9 * value / world})
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tf) and args.config == "c3":  # counters were collected on the C3 workload
                 try:

@@ -42,15 +42,17 @@ __global__ void __launch_bounds__(GS_BLOCK) bin_prepare_kernel(GeomHeader* hdr, 
 // drop_max (first pass of the depth sort): keys 0xFFFFFFFF - Gaussians that emit no instance: culled, or cut away entirely
 // by the depth limits, 80 % of them at the bench workload - are not counted and not scattered: the pass filters while it
 // sorts, and the later passes (and everything downstream of the order) handle the survivors only.
+template <int BITS>
 __global__ void __launch_bounds__(RS_HIST_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* n_dev,
                                                                   int shift, uint32_t* __restrict__ hist, uint32_t nblk,
                                                                   int drop_max) {
-  __shared__ uint32_t h[RS_HIST_THREADS / 64][RS_RADIX];  // one private histogram per wave
+  constexpr int RADIX = 1 << BITS;
+  __shared__ uint32_t h[RS_HIST_THREADS / 64][RADIX];  // one private histogram per wave
   const uint32_t n = *n_dev;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   constexpr int NW = RS_HIST_THREADS / 64, PER_WAVE = RS_TILE / NW, ROUNDS = PER_WAVE / 64;
 #pragma unroll
-  for (int k = tid; k < NW * RS_RADIX; k += RS_HIST_THREADS) (&h[0][0])[k] = 0;
+  for (int k = tid; k < NW * RADIX; k += RS_HIST_THREADS) (&h[0][0])[k] = 0;
   __syncthreads();
   const uint32_t w0 = blockIdx.x * RS_TILE + wid * PER_WAVE;
   if (w0 < n) {
@@ -63,11 +65,11 @@ __global__ void __launch_bounds__(RS_HIST_THREADS) rs_hist_kernel(const uint32_t
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
       const uint32_t i = w0 + r * 64 + lane;
-      if (i < n && !(drop_max && k[r] == 0xFFFFFFFFu)) atomicAdd(&h[wid][(k[r] >> shift) & 0xFFu], 1u);
+      if (i < n && !(drop_max && k[r] == 0xFFFFFFFFu)) atomicAdd(&h[wid][(k[r] >> shift) & (uint32_t)(RADIX - 1)], 1u);
     }
   }
   __syncthreads();
-  if (tid < RS_RADIX) {
+  if (tid < RADIX) {
     uint32_t t = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) t += h[w][tid];
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(GS_BLOCK) rs_rowscan_kernel(uint32_t* __restri
 // digit histogram.  Phase 2: 256 threads turn the NW wave histograms into per-wave offsets inside the tile.
 // Phase 3: keys/values are exchanged through LDS into digit order and stored as contiguous runs.
 #define RS_SCATTER_THREADS 512
-template <int NT>
+template <int NT, int BITS>
 __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restrict__ kin,
                                                         const uint32_t* __restrict__ vin,  // NULL: value = index
                                                         uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
@@ -156,16 +158,17 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
                                                         const uint32_t* __restrict__ hist, uint32_t nblk,
                                                         const uint32_t* __restrict__ totals, int drop_max,
                                                         uint32_t* __restrict__ n_kept) {
+  constexpr int RADIX = 1 << BITS;
   constexpr int NW = NT / 64;               // waves; wave w ranks the contiguous RS_TILE / NW keys [w0, w0 + ...)
   constexpr int ITEMS = RS_TILE / NT;       // keys per thread = ranking rounds per wave
-  static_assert(NT >= RS_RADIX && RS_TILE % NT == 0, "one thread per digit in phase 2");
-  __shared__ uint32_t s_hist[NW][RS_RADIX];  // phase 1: wave digit counts; phase 3: output bases
+  static_assert(NT >= RADIX && RS_TILE % NT == 0, "one thread per digit in phase 2");
+  __shared__ uint32_t s_hist[NW][RADIX];  // phase 1: wave digit counts; phase 3: output bases
   const uint32_t n = *n_dev;
   const uint32_t t0 = blockIdx.x * RS_TILE;
   if (t0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #pragma unroll
-  for (int k = tid; k < NW * RS_RADIX; k += NT) (&s_hist[0][0])[k] = 0;
+  for (int k = tid; k < NW * RADIX; k += NT) (&s_hist[0][0])[k] = 0;
   __syncthreads();
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint32_t w0 = t0 + wid * (RS_TILE / NW);
@@ -182,10 +185,10 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = w0 + r * 64 + lane;
     const bool valid = i < n && !(drop_max && key[r] == 0xFFFFFFFFu);
-    const uint32_t d = (key[r] >> shift) & 0xFFu;
+    const uint32_t d = (key[r] >> shift) & (uint32_t)(RADIX - 1);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < RS_BITS; b++) {
+    for (int b = 0; b < BITS; b++) {
       const unsigned long long bal = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? bal : ~bal;
     }
@@ -199,10 +202,10 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
   __syncthreads();
   // Phase 2: thread d < 256 owns digit d: wave prefixes, workgroup-local exclusive digit offset (scan over the 256
   // digit totals) and the distance from the local to the global position of that digit's run.
-  __shared__ uint32_t s_delta[RS_RADIX];  // global start - local start
-  __shared__ uint32_t s_wtot[RS_RADIX / 64];
-  __shared__ uint32_t s_gtot[RS_RADIX / 64];
-  const bool digit_thread = tid < RS_RADIX;
+  __shared__ uint32_t s_delta[RADIX];  // global start - local start
+  __shared__ uint32_t s_wtot[RADIX / 64];
+  __shared__ uint32_t s_gtot[RADIX / 64];
+  const bool digit_thread = tid < RADIX;
   uint32_t cw[NW];
   uint32_t tot = 0, gt = 0;
   if (digit_thread) {
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
       gbase += s_gtot[w];
     }
     s_delta[tid] = gbase + hist[(size_t)tid * nblk + blockIdx.x] - loc;
-    if (tid == RS_RADIX - 1) {
+    if (tid == RADIX - 1) {
       s_cnt = loc + tot;                                     // end of the last digit's run = keys that take part
       if (n_kept && blockIdx.x == 0) *n_kept = gbase + gt;   // ... and in the whole array
     }
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     if (pre[r] != 0xFFFFFFFFu) {
-      const uint32_t lp = s_hist[wid][(key[r] >> shift) & 0xFFu] + pre[r];
+      const uint32_t lp = s_hist[wid][(key[r] >> shift) & (uint32_t)(RADIX - 1)] + pre[r];
       s_key[lp] = key[r];
       s_val[lp] = val[r];
     }
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
     const uint32_t i = r * NT + tid;
     if (i < cnt) {
       const uint32_t k = s_key[i];
-      const uint32_t pos = i + s_delta[(k >> shift) & 0xFFu];
+      const uint32_t pos = i + s_delta[(k >> shift) & (uint32_t)(RADIX - 1)];
       kout[pos] = k;
       vout[pos] = s_val[i];
     }
@@ -386,8 +389,10 @@ __global__ void __launch_bounds__(1024) rs_small_sort_kernel(const uint32_t* __r
   }
 }
 
+// digit_bits: 8, or 9 for a sort that is then ONE pass over keys below 512 (the partition of the region entries at 1080p:
+// 510 regions) - after it b.scan_tmp[d] holds the number of keys of digit d
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound, int end_bit, int start_buf,
-                      const uint32_t* first_keys, hipStream_t s, int debug, uint32_t* n_kept) {
+                      const uint32_t* first_keys, hipStream_t s, int debug, uint32_t* n_kept, int digit_bits) {
   int cur = start_buf;
   if (n_bound <= 0) return 0;
   if (first_keys != nullptr && n_bound <= RS_SMALL_MAX) {
@@ -399,19 +404,33 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
     return 0;
   }
   const uint32_t nblk = (uint32_t)((n_bound + RS_TILE - 1) / RS_TILE);
+  if (digit_bits == 9) {
+    if (end_bit > 9 || first_keys != nullptr) return GS_E_SHAPE;
+    hipLaunchKernelGGL(rs_hist_kernel<9>, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, b.keys[cur], n_dev, 0, b.hist, nblk, 0);
+    GS_LAUNCH_CHECK(s, debug);
+    hipLaunchKernelGGL(rs_rowscan_kernel, dim3(512), dim3(GS_BLOCK), 0, s, b.hist, nblk, b.scan_tmp);
+    GS_LAUNCH_CHECK(s, debug);
+    hipLaunchKernelGGL((rs_scatter_kernel<RS_SCATTER_THREADS, 9>), dim3(nblk), dim3(RS_SCATTER_THREADS), 0, s, b.keys[cur], b.vals[cur],
+                       b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, 0, b.hist, nblk, b.scan_tmp, 0, (uint32_t*)nullptr);
+    GS_LAUNCH_CHECK(s, debug);
+    return 0;
+  }
   bool first = true;
+  // (round 5 tried to count the NEXT pass's per-tile digits in this pass's scatter kernel - one-way atomics where the keys land,
+  //  wave-aggregated - to save the histogram launch of passes 2-4: the counters of neighbouring tiles share cache lines and
+  //  device-scope atomics on one line serialise at the memory side: a pass of 8 us took 0.3-1.9 ms.  Removed.)
   for (int shift = 0; shift < end_bit; shift += RS_BITS) {
     const bool ext = first && first_keys != nullptr;
     const uint32_t* kin = ext ? first_keys : b.keys[cur];
     const uint32_t* vin = ext ? nullptr : b.vals[cur];
     const int drop = ext && n_kept ? 1 : 0;  // the first pass of the depth sort filters (see rs_hist_kernel)
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, kin, n_dev, shift, b.hist, nblk, drop);
+    hipLaunchKernelGGL(rs_hist_kernel<RS_BITS>, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, kin, n_dev, shift, b.hist, nblk, drop);
     GS_LAUNCH_CHECK(s, debug);
     hipLaunchKernelGGL(rs_rowscan_kernel, dim3(RS_RADIX), dim3(GS_BLOCK), 0, s, b.hist, nblk, b.scan_tmp);
     GS_LAUNCH_CHECK(s, debug);
     // 512 threads per 4096-key tile (8 ranking rounds per wave): 0.213 ms for the two instance passes against 0.226 with
     // 256 threads and 0.217 with 1024 - the pass is bound by one workgroup's dependent chain, not by throughput
-    hipLaunchKernelGGL(rs_scatter_kernel<RS_SCATTER_THREADS>, dim3(nblk), dim3(RS_SCATTER_THREADS), 0, s, kin, vin,
+    hipLaunchKernelGGL((rs_scatter_kernel<RS_SCATTER_THREADS, RS_BITS>), dim3(nblk), dim3(RS_SCATTER_THREADS), 0, s, kin, vin,
                        b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, shift, b.hist, nblk, b.scan_tmp, drop, drop ? n_kept : nullptr);
     GS_LAUNCH_CHECK(s, debug);
     if (drop) n_dev = n_kept;  // the later passes see the survivors only

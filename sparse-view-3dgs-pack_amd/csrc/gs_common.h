@@ -67,6 +67,7 @@ static inline __host__ __device__ size_t gs_align(size_t x) { return (x + 255) &
 // radix sort geometry: 8-bit digits, 256 threads x 16 keys per workgroup
 #define RS_BITS 8
 #define RS_RADIX 256
+#define RS_RADIX_MAX 512  // the one-pass partition of up to 512 regions uses 9-bit digits (tables are sized for it)
 #define RS_ITEMS 16
 #define RS_TILE (GS_BLOCK * RS_ITEMS)
 
@@ -74,27 +75,27 @@ static inline __host__ __device__ size_t gs_align(size_t x) { return (x + 255) &
 struct SortBufs {
   uint32_t* keys[2];
   uint32_t* vals[2];
-  uint32_t* hist;      // [RS_RADIX][nblk] digit-major workgroup histograms
-  uint32_t* scan_tmp;  // [RS_RADIX] digit totals of the current pass (rs_rowscan_kernel)
+  uint32_t* hist;      // [RS_RADIX_MAX][nblk] digit-major workgroup histograms
+  uint32_t* scan_tmp;  // [RS_RADIX_MAX] digit totals of the current pass (rs_rowscan_kernel)
 };
 static inline __host__ __device__ size_t sort_bytes(size_t cap) {
   if (cap == 0) cap = 1;
   size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
-  size_t hist_n = nblk * RS_RADIX;
-  return 4 * gs_align(4 * cap) + gs_align(4 * hist_n) + gs_align(4 * RS_RADIX);
+  size_t hist_n = nblk * RS_RADIX_MAX;
+  return 4 * gs_align(4 * cap) + gs_align(4 * hist_n) + gs_align(4 * RS_RADIX_MAX);
 }
 static inline __host__ __device__ SortBufs sort_view(void* buf, size_t cap) {
   if (cap == 0) cap = 1;
   char* p = (char*)buf;
   SortBufs b;
   size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
-  size_t hist_n = nblk * RS_RADIX;
+  size_t hist_n = nblk * RS_RADIX_MAX;
   b.keys[0] = (uint32_t*)p; p += gs_align(4 * cap);
   b.keys[1] = (uint32_t*)p; p += gs_align(4 * cap);
   b.vals[0] = (uint32_t*)p; p += gs_align(4 * cap);
   b.vals[1] = (uint32_t*)p; p += gs_align(4 * cap);
   b.hist = (uint32_t*)p; p += gs_align(4 * hist_n);
-  b.scan_tmp = (uint32_t*)p; p += gs_align(4 * RS_RADIX);
+  b.scan_tmp = (uint32_t*)p; p += gs_align(4 * RS_RADIX_MAX);
   return b;
 }
 
@@ -156,12 +157,21 @@ static inline __host__ __device__ ImgView img_view(void* buf, size_t N, size_t T
   return v;
 }
 
+// Region entries of a Gaussian (two-level binning, gs_tilebin.hip), counted by the preprocess kernel where that is cheap and left in
+// bits 16-31 of Splat.clamped: 15 bits of count, bit 15 = "row-wise enumeration" (gs_tilebin.hip); all ones = not counted
+#define TB_ENTRIES_UNKNOWN 0xFFFFu
+#define TB_ENTRIES_MAX 0x7FFEu
+static inline __host__ __device__ uint32_t tb_rect_entries(uint32_t minx, uint32_t miny, uint32_t maxx, uint32_t maxy) {
+  // the reference's rectangle [min, max) in tiles -> 4 x 4-tile regions it reaches (every one of them holds a tile of it)
+  const uint32_t n = ((maxx - 1u) / 4u - minx / 4u + 1u) * ((maxy - 1u) / 4u - miny / 4u + 1u);
+  return n > TB_ENTRIES_MAX ? TB_ENTRIES_UNKNOWN : n;
+}
 // ---- two-level binning of tile_cull = 0 / 1 (gs_tilebin.hip): what lies behind the SortBufs in the binning buffer ----
-#define TB_CHUNK 1024  // entries of one region a workgroup counts / writes at a time
+#define TB_CHUNK 256   // entries of one region a WAVE counts / writes at a time (four rounds of 64)
 struct TileBinView {
   uint2* region_ranges;    // [regions] range of each region's entries in the partitioned entry arrays
   uint32_t* chunk_first;   // [regions + 1] exclusive prefix of the regions' chunk counts
-  uint32_t* chunk_region;  // [max_chunks] region of each chunk
+  uint4* chunk_desc;       // [max_chunks] (first entry, end of the chunk's entries, region, -): one load tells a workgroup its work
   uint32_t* chunk_counts;  // [max_chunks][16] entries of each of the region's tiles in the chunk -> exclusive prefix over the region's chunks
   uint32_t* tile_start;    // [T + 1] start of each tile's list in point_list (tile order)
   uint32_t max_chunks;
@@ -170,7 +180,7 @@ struct TileBinView {
 static inline __host__ __device__ size_t tilebin_max_chunks(size_t cap, size_t T) { return cap / TB_CHUNK + T + 1; }
 static inline __host__ __device__ size_t tilebin_bytes(size_t cap, size_t T) {
   const size_t mc = tilebin_max_chunks(cap, T);
-  return gs_align(8 * T) + gs_align(4 * (T + 1)) + gs_align(4 * mc) + gs_align(64 * mc) + gs_align(4 * (T + 1));
+  return gs_align(8 * T) + gs_align(4 * (T + 1)) + gs_align(16 * mc) + gs_align(64 * mc) + gs_align(4 * (T + 1));
 }
 static inline __host__ __device__ TileBinView tilebin_view(void* buf, size_t cap, size_t T) {
   char* p = (char*)buf;
@@ -178,7 +188,7 @@ static inline __host__ __device__ TileBinView tilebin_view(void* buf, size_t cap
   const size_t mc = tilebin_max_chunks(cap, T);
   v.region_ranges = (uint2*)p; p += gs_align(8 * T);
   v.chunk_first = (uint32_t*)p; p += gs_align(4 * (T + 1));
-  v.chunk_region = (uint32_t*)p; p += gs_align(4 * mc);
+  v.chunk_desc = (uint4*)p; p += gs_align(16 * mc);
   v.chunk_counts = (uint32_t*)p; p += gs_align(64 * mc);
   v.tile_start = (uint32_t*)p;
   v.max_chunks = (uint32_t)mc;
@@ -282,7 +292,7 @@ int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, ui
 int launch_bin_prepare(const GeomView& g, int64_t capacity, uint2* ranges, int T, hipStream_t s);
 // first_keys != NULL: the first pass reads its keys from there (left untouched) and takes value = index
 int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_host_bound, int end_bit, int start_buf,
-                      const uint32_t* first_keys, hipStream_t s, int debug, uint32_t* n_kept = nullptr);
+                      const uint32_t* first_keys, hipStream_t s, int debug, uint32_t* n_kept = nullptr, int digit_bits = 8);
 int launch_scan_sums(uint32_t* sums, int nb, hipStream_t s);  // in-place exclusive scan of sums[nb], total -> sums[nb]
 // the lists of tile_cull = 0 / 1 from the depth order (g.gsort.vals[0]): gs_tilebin.hip
 int launch_tile_binning(const GeomView& g, const SortBufs& bv, const TileBinView& tb, int P, int64_t capacity, int grid_x, int grid_y,

@@ -68,7 +68,7 @@ static inline size_t preprocess_limit_lds_floats(const PreprocessArgs& a) {
 
 __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs a, GeomView g, int lds_floats) {
   const int idx = blockIdx.x * GS_BLOCK + threadIdx.x;
-  uint32_t tiles = 0;
+  uint32_t tiles = 0, entries = TB_ENTRIES_UNKNOWN;
   const int T = a.grid_x * a.grid_y;
   // region binning: up to four bucket counters waiting to be bumped (selects, not an indexed array: that would live in
   // scratch memory), the slots they returned, and this Gaussian's bucket entry.
@@ -259,14 +259,27 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
         const TileCull tc = tilecull_setup(1, sp.x, sp.y, sp.cxx, sp.cxy, sp.cyy, sp.opacity);
         if (tc.mode == 0) {
           tiles = (maxy - miny) * (maxx - minx);
+          if (!a.tile_depth_limit) entries = tb_rect_entries(minx, miny, maxx, maxy);
         } else if (tc.mode == 2) {
           // the tiles the ellipse really reaches (far fewer than the bounding square's), their bounding box and - with
           // depth limits - how many of them survive the segment rule (gs_tilecull.h)
           uint32_t bx0 = 0xFFFFFFFFu, bx1 = 0, by0 = 0xFFFFFFFFu, by1 = 0, tiles_seg = 0;
+          // (+ the region entries of the two-level binning, gs_tilebin.hip: per region row the hull of its four tile rows'
+          //  spans, or - should the hull hold more regions than the Gaussian has tiles - per tile row; without depth limits only:
+          //  with them the spans are trimmed further down and the binning counts for itself)
+          uint32_t hull = 0, rowwise = 0, h_lo = 0xFFFFFFFFu, h_hi = 0;
           for (uint32_t ty = miny; ty < maxy; ty++) {
             uint32_t tx0;
             const uint32_t n = tilecull_row_span(tc, ty, minx, maxx, tx0);
             tiles += n;
+            if (n) {
+              h_lo = min(h_lo, tx0); h_hi = max(h_hi, tx0 + n - 1u);
+              rowwise += (tx0 + n - 1u) / RG_TILES - tx0 / RG_TILES + 1u;
+            }
+            if ((ty % RG_TILES) == RG_TILES - 1u || ty + 1u == maxy) {  // the region row ends here
+              if (h_lo <= h_hi) hull += h_hi / RG_TILES - h_lo / RG_TILES + 1u;
+              h_lo = 0xFFFFFFFFu; h_hi = 0;
+            }
             if (n && a.tile_depth_limit) {
               bx0 = min(bx0, tx0); bx1 = max(bx1, tx0 + n);
               by0 = min(by0, ty); by1 = ty + 1;
@@ -276,6 +289,7 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
               }
             }
           }
+          if (!a.tile_depth_limit) entries = hull > tiles ? (rowwise | 0x8000u) : hull;
           if (a.tile_depth_limit && tiles) {
             // The verdict travels to the duplicate kernel in the record (bits 8-9 of `clamped`): 0 nothing cut, 1 all,
             // 2 cut by the exact rule (Gaussians inside a 4 x 4 tile box: their <= 16 bounds fetched at once, rows then
@@ -306,7 +320,11 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
         }
       } else {
         tiles = (maxy - miny) * (maxx - minx);
+        entries = tb_rect_entries(minx, miny, maxx, maxy);
       }
+      // bits 16-31 of `clamped`: region entries of this Gaussian (bit 15 of them: row-wise enumeration), TB_ENTRIES_UNKNOWN when
+      // the binning has to count for itself
+      sp.clamped |= (tiles ? entries : 0u) << 16;
       // the colour comes last: a Gaussian whose every pair the depth limits removed is blended nowhere, so its 192 B of SH
       // coefficients are neither read nor evaluated (its gradient is zero as well, see preprocess_bwd)
       if (!(a.tile_depth_limit && tiles == 0)) {

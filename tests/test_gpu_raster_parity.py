@@ -220,6 +220,34 @@ def test_empty_and_all_culled(hip):
     assert vis.tolist() == [False, True]
 
 
+def test_mark_visible_vs_oracle_around_the_near_plane(hip, oracle):
+    """markVisible (rasterizer_impl.cu:54-66, in_frustum of auxiliary.h:139-160: view-space z > 0.2): HIP against the oracle on a
+    million points whose depths straddle 0.2 - a slab of them within a few ulps of the plane, where the fp32 evaluation order
+    of the 4 x 4 transform decides - for three cameras; and against the float64 value away from the plane."""
+    import numpy as np
+    P = 1_000_000
+    rng = np.random.RandomState(11)
+    for ci in (0, 9, 20):
+        cam = synthetic.orbit_cameras(640, 480)[ci]
+        V = cam.world_view_transform.double()          # (row-vector convention: p_view = [p, 1] @ V)
+        pts = torch.from_numpy(rng.uniform(-6.0, 6.0, size=(P, 3)))
+        # move the first 600 k points onto the plane z_view = 0.2 (+- a spread from 1e-8 to 1e-2), along the view axis
+        z = (torch.cat((pts, torch.ones((P, 1), dtype=torch.float64)), dim=1) @ V)[:, 2]
+        axis = V[:3, 2] / (V[:3, 2] @ V[:3, 2])
+        n = 600_000
+        spread = torch.from_numpy(10.0 ** rng.uniform(-8, -2, size=n) * rng.choice([-1.0, 1.0], size=n))
+        pts[:n] += ((0.2 + spread) - z[:n])[:, None] * axis[None, :]
+        pts[n:n + 1000] += (0.2 - z[n:n + 1000])[:, None] * axis[None, :]      # as exactly on it as float64 gets
+        p32 = pts.float()
+        h = hip.mark_visible(p32.cuda(), cam.world_view_transform.cuda(), cam.full_proj_transform.cuda()).cpu()
+        o = oracle.backend.mark_visible(p32, cam.world_view_transform, cam.full_proj_transform)
+        assert torch.equal(h, o), (ci, int((h != o).sum()))
+        z32 = (torch.cat((p32.double(), torch.ones((P, 1), dtype=torch.float64)), dim=1) @ V)[:, 2]
+        clear = (z32 - 0.2).abs() > 1e-5
+        assert torch.equal(h[clear], (z32 > 0.2)[clear])
+        assert 0.2 < float(h.float().mean()) < 0.8 and int((~clear).sum()) > 100_000
+
+
 @pytest.mark.parametrize("P,seed", [(5, 0), (1000, 1), (4097, 2), (100000, 3), (1000000, 4), (1000000, 5)])
 def test_knn_bit_exact_vs_oracle(hip, oracle, P, seed):
     import numpy as np
