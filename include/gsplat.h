@@ -666,6 +666,21 @@ int gs_densify_stats(const int32_t* radii, const float* dL_dmeans2D /*[P,3]*/, i
                      float* max_radii2D /*[P]*/, float* xyz_gradient_accum /*[P]*/, float* denom /*[P]*/,
                      void* stream);
 
+/* ---- the visibility-sparse gradient exchange of the data-parallel step (N > 1; no reference counterpart: the reference trains
+ * on one GPU).  Only Gaussians that emitted instances in SOME rank's view have a non-zero gradient row, so the ranks exchange
+ * the rows of the union only.  The flat gradient buffer is field-major: field f is a [P, widths[f]] row-major block, the blocks
+ * back to back.  pos[i] = (number of j <= i with mask[j] != 0) - 1: the inclusive prefix of the union mask, minus one.
+ * gs_rows_pack: packed = the K union rows of every field, field after field ([K, widths[f]] blocks): one launch instead of an
+ * index_select per field.  gs_rows_unpack: the inverse, into the rows of the union (the others are not touched). */
+int gs_rows_pack(const float* flat, int32_t P, int32_t nfields, const int32_t* widths /*host*/, const uint8_t* mask,
+                 const int32_t* pos, int32_t K, float* packed, void* stream);
+int gs_rows_unpack(float* flat, int32_t P, int32_t nfields, const int32_t* widths /*host*/, const uint8_t* mask,
+                   const int32_t* pos, int32_t K, const float* packed, void* stream);
+/* mask[i] = 1 when Gaussian i emitted instances in the forward whose geometry state `scratch` holds (what gs_backward_step's
+ * data-parallel form writes into GsStepState.grad_mask later - available as soon as the forward's geometry phase has run,
+ * so the union of the ranks' masks can be exchanged while the loss and the backward are still running). */
+int gs_export_row_mask(const GsScratch* scratch, int32_t P, uint8_t* mask, void* stream);
+
 /* ---- optional per-stage timing (HIP events recorded on the caller's stream around every kernel
  * group).  Off by default.  bench.py enables it over the timed region to get each kernel's average
  * launch duration on the stream it is launched on.  (No reference counterpart: the reference only

@@ -428,6 +428,38 @@ int gso_adam_step_masked(float* p, const float* g, float* m, float* v, int64_t n
   return GS_OK;
 }
 
+/* the visibility-sparse gradient exchange's pack / unpack (include/gsplat.h; product-side feature, mirrored so that the CPU
+ * data-parallel tests run the same glue) */
+static int rows_pack_cpu(float* flat, int32_t P, int32_t nf, const int32_t* widths, const uint8_t* mask, const int32_t* pos,
+                         int32_t K, float* packed, bool unpack) {
+  if (P < 0 || K < 0 || nf < 0 || nf > 8) return GS_E_SHAPE;
+  if (P == 0 || K == 0 || nf == 0) return GS_OK;
+  if (!flat || !widths || !mask || !pos || !packed) return GS_E_NULL;
+  int64_t fo = 0, po = 0;
+  for (int q = 0; q < nf; q++) {
+    const int w = widths[q];
+    for (int i = 0; i < P; i++) {
+      if (!mask[i] || pos[i] < 0 || pos[i] >= K) continue;
+      float* a = flat + fo + (int64_t)i * w;
+      float* b = packed + po + (int64_t)pos[i] * w;
+      for (int j = 0; j < w; j++) {
+        if (unpack) a[j] = b[j]; else b[j] = a[j];
+      }
+    }
+    fo += (int64_t)P * w;
+    po += (int64_t)K * w;
+  }
+  return GS_OK;
+}
+int gso_rows_pack(const float* flat, int32_t P, int32_t nf, const int32_t* widths, const uint8_t* mask, const int32_t* pos,
+                  int32_t K, float* packed, void*) {
+  return rows_pack_cpu(const_cast<float*>(flat), P, nf, widths, mask, pos, K, packed, false);
+}
+int gso_rows_unpack(float* flat, int32_t P, int32_t nf, const int32_t* widths, const uint8_t* mask, const int32_t* pos, int32_t K,
+                    const float* packed, void*) {
+  return rows_pack_cpu(flat, P, nf, widths, mask, pos, K, const_cast<float*>(packed), true);
+}
+
 /* ---- per-Gaussian elementwise work of the train step (restates LGDWT-GS/scene/gaussian_model.py:40-60,102-117
  * activations with torch's autograd formulas, and train.py:266-268 + gaussian_model.py:471-473 statistics;
  * pinned against torch itself in tests/test_model_ops.py) ---- */

@@ -123,3 +123,93 @@ int gs_densify_stats(const int32_t* radii, const float* dL_dmeans2D, int32_t P, 
   return GS_OK;
 }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The visibility-sparse gradient exchange (include/gsplat.h): rows of the union in and out of the packed buffer.
+// One thread per (row, float of the row's 59 / 60): reads and writes runs of a field's width - a gather of short rows.
+// ------------------------------------------------------------------------------------------------------------------
+#define GS_PACK_MAX_FIELDS 8
+struct PackFields {
+  int n;
+  int width[GS_PACK_MAX_FIELDS];
+  long long flat_off[GS_PACK_MAX_FIELDS];    // start of the field's [P, width] block in the flat buffer
+  long long packed_off[GS_PACK_MAX_FIELDS];  // start of its [K, width] block in the packed buffer
+  int col_off[GS_PACK_MAX_FIELDS + 1];       // first column of the field among a row's total floats
+};
+template <bool UNPACK>
+__global__ void __launch_bounds__(GS_BLOCK) rows_pack_kernel(float* __restrict__ flat, int P, PackFields f, const uint8_t* __restrict__ mask,
+                                                             const int32_t* __restrict__ pos, int K, float* __restrict__ packed) {
+  const int W = f.col_off[f.n];
+  const long long total = (long long)P * W;
+  for (long long t = (long long)blockIdx.x * GS_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * GS_BLOCK) {
+    const int i = (int)(t / W), col = (int)(t - (long long)i * W);
+    if (!mask[i]) continue;
+    const int k = pos[i];
+    if (k < 0 || k >= K) continue;
+    int fi = 0;
+#pragma unroll
+    for (int q = 1; q < GS_PACK_MAX_FIELDS; q++) fi = (q < f.n && col >= f.col_off[q]) ? q : fi;
+    const int j = col - f.col_off[fi];
+    float* a = flat + f.flat_off[fi] + (long long)i * f.width[fi] + j;
+    float* b = packed + f.packed_off[fi] + (long long)k * f.width[fi] + j;
+    if (UNPACK) *a = *b; else *b = *a;
+  }
+}
+static int rows_pack_impl(float* flat, int32_t P, int32_t nfields, const int32_t* widths, const uint8_t* mask, const int32_t* pos,
+                          int32_t K, float* packed, bool unpack, void* stream) {
+  if (P < 0 || K < 0 || nfields < 0 || nfields > GS_PACK_MAX_FIELDS) return GS_E_SHAPE;
+  if (P == 0 || K == 0 || nfields == 0) return GS_OK;
+  if (!flat || !widths || !mask || !pos || !packed) return GS_E_NULL;
+  PackFields f;
+  f.n = nfields;
+  long long fo = 0, po = 0;
+  int co = 0;
+  for (int q = 0; q < GS_PACK_MAX_FIELDS; q++) {
+    const int w = q < nfields ? widths[q] : 0;
+    if (w < 0) return GS_E_SHAPE;
+    f.width[q] = w;
+    f.flat_off[q] = fo;
+    f.packed_off[q] = po;
+    f.col_off[q] = co;
+    fo += (long long)P * w;
+    po += (long long)K * w;
+    co += w;
+  }
+  f.col_off[GS_PACK_MAX_FIELDS] = co;
+  for (int q = nfields; q < GS_PACK_MAX_FIELDS; q++) f.col_off[q] = co;
+  f.col_off[nfields] = co;
+  if (co == 0) return GS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  long long blocks = ((long long)P * co + GS_BLOCK - 1) / GS_BLOCK;
+  blocks = blocks > 65536 ? 65536 : blocks;
+  GS_PROF(ST_MODEL, s);
+  if (unpack)
+    hipLaunchKernelGGL(rows_pack_kernel<true>, dim3((unsigned)blocks), dim3(GS_BLOCK), 0, s, flat, P, f, mask, pos, K, packed);
+  else
+    hipLaunchKernelGGL(rows_pack_kernel<false>, dim3((unsigned)blocks), dim3(GS_BLOCK), 0, s, flat, P, f, mask, pos, K, packed);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}
+extern "C" int gs_rows_pack(const float* flat, int32_t P, int32_t nfields, const int32_t* widths, const uint8_t* mask,
+                            const int32_t* pos, int32_t K, float* packed, void* stream) {
+  return rows_pack_impl(const_cast<float*>(flat), P, nfields, widths, mask, pos, K, packed, false, stream);
+}
+extern "C" int gs_rows_unpack(float* flat, int32_t P, int32_t nfields, const int32_t* widths, const uint8_t* mask,
+                              const int32_t* pos, int32_t K, const float* packed, void* stream) {
+  return rows_pack_impl(flat, P, nfields, widths, mask, pos, K, const_cast<float*>(packed), true, stream);
+}
+__global__ void __launch_bounds__(GS_BLOCK) row_mask_kernel(const uint32_t* __restrict__ tiles_touched, int P, uint8_t* __restrict__ mask) {
+  const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+  if (i < P) mask[i] = tiles_touched[i] != 0u ? 1 : 0;
+}
+extern "C" int gs_export_row_mask(const GsScratch* sc, int32_t P, uint8_t* mask, void* stream) {
+  if (!sc || !sc->geom || !mask) return GS_E_NULL;
+  if (P < 0) return GS_E_SHAPE;
+  if (P == 0) return GS_OK;
+  if (sc->geom_bytes < geom_bytes((size_t)P)) return GS_E_SCRATCH;
+  GeomView gv = geom_view(sc->geom, (size_t)P);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(row_mask_kernel, dim3((P + GS_BLOCK - 1) / GS_BLOCK), dim3(GS_BLOCK), 0, s, gv.tiles_touched, P, mask);
+  GS_LAUNCH_CHECK(s, 0);
+  return GS_OK;
+}

@@ -370,114 +370,91 @@ __global__ void __launch_bounds__(GS_BLOCK) tb_emit_kernel(GeomView g, const uin
     return;
   }
   if constexpr (CULL) {
-    // culled spans: the rows of ALL the large Gaussians, concatenated, go through one row table TB_BIG_ROWS rows at a time
-    // (span per row -> prefix -> a thread per entry): a handful of barriers per workgroup, not per Gaussian
-    __shared__ TbOwner s_bo[GS_BLOCK];
-    __shared__ TileCull s_bc[GS_BLOCK];
-    __shared__ uint32_t s_bid[GS_BLOCK], s_boff[GS_BLOCK], s_bword[GS_BLOCK], s_brow[GS_BLOCK + 1], s_bdone[GS_BLOCK];
-    __shared__ uint32_t s_rowb[TB_BIG_ROWS];
-    if (v > TB_SMALL) {
-      uint32_t slot = 0;
-      for (uint32_t b = 0; b < nbig; b++) slot = s_big[b] == (uint32_t)tid ? b : slot;
-      s_bo[slot] = o;
-      s_bc[slot] = c;
-      s_bid[slot] = id;
-      s_boff[slot] = off;
-      s_bword[slot] = word;
-    }
-    __syncthreads();
-    uint32_t rows_big;   // rows of all of them: region rows (hull) or tile rows (row-wise)
-    {
-      uint32_t mine = 0;
-      if ((uint32_t)tid < nbig) {
-        const TbOwner bo = s_bo[tid];
-        const uint32_t y0 = bo.rmin >> 16, y1 = bo.rmax >> 16;
-        mine = (s_bword[tid] & TB_ROWWISE) ? y1 - y0 : (y1 - 1u) / RG_TILES - y0 / RG_TILES + 1u;
-        s_bdone[tid] = 0;
+    // culled spans: one large Gaussian after the other through a row table (span per row -> prefix -> a thread per entry).
+    // (Round 5 also built the one-table form over the concatenated rows of ALL of them, as the rectangles have it above: 99 us
+    //  against 76 at C3 - every entry re-derives its row's four ellipse spans from LDS-resident state there.)
+    __shared__ TbOwner s_o;
+    __shared__ TileCull s_c;
+    __shared__ uint32_t s_big_id, s_big_off, s_big_word;
+    for (uint32_t b = 0; b < nbig; b++) {
+      if ((uint32_t)tid == s_big[b]) {
+        s_o = o;
+        s_c = c;
+        s_big_id = id;
+        s_big_off = off;
+        s_big_word = word;
       }
-      s_brow[tid] = tb_block_exclusive_scan256(mine, s_wsum, rows_big);
-      if (tid == 0) s_brow[GS_BLOCK] = rows_big;
-    }
-    __syncthreads();
-    auto row_of = [&](uint32_t b, uint32_t j, uint32_t& ry, TbRowSpans& rs, uint32_t& c0) -> uint32_t {  // spans of row j of big b
-      const TbOwner bo = s_bo[b];
-      if (s_bword[b] & TB_ROWWISE) {
-        const uint32_t ty = (bo.rmin >> 16) + j;
-        uint32_t tx0;
-        const uint32_t nt = tb_tile_span(s_bc[b], bo, ty, depth_limit, grid_x, grid_y, tx0);
+      __syncthreads();
+      const TbOwner bo = s_o;
+      const uint32_t bid = s_big_id, bword = s_big_word, bv = bword & ~TB_ROWWISE;
+      const bool brow = (bword & TB_ROWWISE) != 0u;
+      const uint32_t r_lo = brow ? (bo.rmin >> 16) : (bo.rmin >> 16) / RG_TILES;
+      const uint32_t r_hi = brow ? (bo.rmax >> 16) : ((bo.rmax >> 16) - 1u) / RG_TILES + 1u;   // rows [r_lo, r_hi)
+      uint32_t written = 0;
+      for (uint32_t r0 = r_lo; r0 < r_hi; r0 += TB_BIG_ROWS) {
+        const uint32_t nrow = min((uint32_t)TB_BIG_ROWS, r_hi - r0);
+        uint32_t n2[TB_BIG_ROWS / GS_BLOCK], local = 0;   // spans of up to two rows per thread, their exclusive prefix
 #pragma unroll
-        for (uint32_t kk = 0; kk < RG_TILES; kk++) {
-          rs.n[kk] = kk == ty % RG_TILES ? nt : 0u;
-          rs.tx0[kk] = kk == ty % RG_TILES ? tx0 : 0u;
+        for (int j = 0; j < TB_BIG_ROWS / GS_BLOCK; j++) {
+          const uint32_t r = tid * (TB_BIG_ROWS / GS_BLOCK) + j;
+          uint32_t n = 0, c0 = 0;
+          if (r < nrow) {
+            if (brow) {
+              uint32_t tx0;
+              const uint32_t nt = tb_tile_span(s_c, bo, r0 + r, depth_limit, grid_x, grid_y, tx0);
+              if (nt) {
+                c0 = tx0 / RG_TILES;
+                n = (tx0 + nt - 1u) / RG_TILES - c0 + 1u;
+              }
+            } else {
+              TbRowSpans rs;
+              n = tb_region_row(s_c, bo, r0 + r, depth_limit, grid_x, grid_y, rs, c0);
+            }
+            s_rowc0[r] = c0;
+          }
+          n2[j] = n;
+          local += n;
         }
-        ry = ty / RG_TILES;
-        if (nt == 0) return 0u;
-        c0 = tx0 / RG_TILES;
-        return (tx0 + nt - 1u) / RG_TILES - c0 + 1u;
-      }
-      ry = (bo.rmin >> 16) / RG_TILES + j;
-      return tb_region_row(s_bc[b], bo, ry, depth_limit, grid_x, grid_y, rs, c0);
-    };
-    for (uint32_t R0 = 0; R0 < rows_big; R0 += TB_BIG_ROWS) {
-      const uint32_t nrow = min((uint32_t)TB_BIG_ROWS, rows_big - R0);
-      uint32_t n2[TB_BIG_ROWS / GS_BLOCK], local = 0;
+        uint32_t chunk_total;
+        uint32_t roff = tb_block_exclusive_scan256(local, s_wsum, chunk_total);
 #pragma unroll
-      for (int jj = 0; jj < TB_BIG_ROWS / GS_BLOCK; jj++) {
-        const uint32_t r = tid * (TB_BIG_ROWS / GS_BLOCK) + jj;
-        uint32_t n = 0;
-        if (r < nrow) {
-          const uint32_t gr = R0 + r;
-          int lo = 0, hi = (int)nbig - 1;  // largest big with s_brow[b] <= gr
+        for (int j = 0; j < TB_BIG_ROWS / GS_BLOCK; j++) {
+          const uint32_t r = tid * (TB_BIG_ROWS / GS_BLOCK) + j;
+          if (r < nrow) s_rowoff[r] = roff;
+          roff += n2[j];
+        }
+        if (tid == 0) s_rowoff[nrow] = chunk_total;
+        __syncthreads();
+        for (uint32_t k = tid; k < chunk_total && written + k < bv; k += GS_BLOCK) {
+          int lo = 0, hi = (int)nrow - 1;  // largest row with s_rowoff[row] <= k
           while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (s_brow[mid] <= gr) lo = mid; else hi = mid - 1;
+            if (s_rowoff[mid] <= k) lo = mid; else hi = mid - 1;
           }
+          const uint32_t row = r0 + (uint32_t)lo, rx = s_rowc0[lo] + (k - s_rowoff[lo]);
           TbRowSpans rs;
-          uint32_t ry, c0 = 0;
-          n = row_of((uint32_t)lo, gr - s_brow[lo], ry, rs, c0);
-          s_rowc0[r] = c0;
-          s_rowb[r] = (uint32_t)lo;
-        }
-        n2[jj] = n;
-        local += n;
-      }
-      uint32_t chunk_total;
-      uint32_t roff = tb_block_exclusive_scan256(local, s_wsum, chunk_total);
+          uint32_t ry;
+          if (brow) {
+            uint32_t tx0;
+            const uint32_t nt = tb_tile_span(s_c, bo, row, depth_limit, grid_x, grid_y, tx0);
 #pragma unroll
-      for (int jj = 0; jj < TB_BIG_ROWS / GS_BLOCK; jj++) {
-        const uint32_t r = tid * (TB_BIG_ROWS / GS_BLOCK) + jj;
-        if (r < nrow) s_rowoff[r] = roff;
-        roff += n2[jj];
-      }
-      if (tid == 0) s_rowoff[nrow] = chunk_total;
-      __syncthreads();
-      for (uint32_t k = tid; k < chunk_total; k += GS_BLOCK) {
-        int lo = 0, hi = (int)nrow - 1;  // largest row with s_rowoff[row] <= k
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (s_rowoff[mid] <= k) lo = mid; else hi = mid - 1;
+            for (uint32_t kk = 0; kk < RG_TILES; kk++) {
+              rs.n[kk] = kk == row % RG_TILES ? nt : 0u;
+              rs.tx0[kk] = kk == row % RG_TILES ? tx0 : 0u;
+            }
+            ry = row / RG_TILES;
+          } else {
+            uint32_t c0;
+            (void)tb_region_row(s_c, bo, row, depth_limit, grid_x, grid_y, rs, c0);
+            ry = row;
+          }
+          put(s_big_off + written + k, ry * rg_x + rx, tb_mask(rs, rx), bid);
         }
-        const uint32_t bb = s_rowb[lo];
-        const uint32_t first = max(s_brow[bb], R0) - R0;                       // the Gaussian's first row in this chunk
-        const uint32_t at = s_bdone[bb] + (s_rowoff[lo] - s_rowoff[first]) + (k - s_rowoff[lo]);
-        const uint32_t bvv = s_bword[bb] & ~TB_ROWWISE;
-        if (at >= bvv) continue;
-        TbRowSpans rs;
-        uint32_t ry, c0;
-        (void)row_of(bb, R0 + (uint32_t)lo - s_brow[bb], ry, rs, c0);
-        const uint32_t rx = s_rowc0[lo] + (k - s_rowoff[lo]);
-        put(s_boff[bb] + at, ry * rg_x + rx, tb_mask(rs, rx), s_bid[bb]);
+        written += chunk_total;
+        __syncthreads();  // the row tables are rewritten by the next chunk
       }
-      __syncthreads();
-      if ((uint32_t)tid < nbig) {   // entries of each large Gaussian this chunk has covered
-        const uint32_t fa = max(s_brow[tid], R0), fb = min(s_brow[tid + 1], R0 + nrow);   // (s_brow[nbig ..] = rows_big)
-        if (fb > fa) s_bdone[tid] += s_rowoff[fb - R0] - s_rowoff[fa - R0];
-      }
-      __syncthreads();  // the row tables are rewritten by the next chunk
-    }
-    if ((uint32_t)tid < nbig) {   // (unreachable when count and emission agree: entries with an empty mask)
-      const uint32_t bvv = s_bword[tid] & ~TB_ROWWISE;
-      for (uint32_t k = min(s_bdone[tid], bvv); k < bvv; k++) put(s_boff[tid] + k, 0u, 0u, s_bid[tid]);
+      for (uint32_t k = min(written, bv) + tid; k < bv; k += GS_BLOCK) put(s_big_off + k, 0u, 0u, bid);  // (unreachable, as above)
+      __syncthreads();    // (s_o ... are rewritten for the next large Gaussian)
     }
   }
 }

@@ -195,6 +195,9 @@ PROTOTYPES = {
     "profile_only": (C.c_int, [_I32]),
     "profile_reset": (C.c_int, []),
     "profile_stage_count": (C.c_int, []),
+    "rows_pack": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_int32), _P, _P, _I32, _P, _P]),
+    "rows_unpack": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_int32), _P, _P, _I32, _P, _P]),
+    "export_row_mask": (C.c_int, [C.POINTER(GsScratch), _I32, _P, _P]),
     "profile_stage_name": (C.c_char_p, [_I32]),
     "profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
 }
@@ -202,7 +205,7 @@ PROTOTYPES = {
 # entry points only the device library has to provide (the CPU oracle is timed with a wall clock)
 # (and the fused 4-channel pass is a product-side fusion of two reference passes: its parity target is the
 # reference's two 3-channel passes, so the checker does not need it)
-DEVICE_ONLY = ("backward_step", "backward_step_x", "step_uninstanced", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "adam_step_gated", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
+DEVICE_ONLY = ("export_row_mask", "backward_step", "backward_step_x", "step_uninstanced", "export_tile_order", "export_tile_stop_depth", "forward_status", "forward_bin", "export_binning_region", "debug_blend_stats", "adam_step_gated", "tile_depth_limit_floats", "profile_enable", "profile_only", "profile_reset", "profile_stage_count", "profile_stage_name", "profile_read",
                "forward_render_x", "backward_x", "forward_tile_order")
 
 ERRORS = {-1: "GS_E_NULL", -2: "GS_E_SHAPE", -3: "GS_E_SCRATCH", -4: "GS_E_OVERFLOW", -5: "GS_E_UNSUPPORTED"}

@@ -76,11 +76,21 @@ def render(cam, pc, bg_color, camera_key=None):
             "radii": radii, "depth": depth_image}
 
 
+class _Pipe:   # arguments/__init__.py PipelineParams defaults
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+    antialiasing = False
+
+
+_PIPE = _Pipe()
+
+
 class DropInLoop:
     """One object = one training run's state (model, optimizer, the running mean of train.py:75)."""
 
     def __init__(self, scene, cameras, gt_images, device, dwt=True, patch=True, optimizer="torch", use_camera_key=False,
-                 fused_criterion=False):
+                 fused_criterion=False, raw_render=False):
         self.pc = DropInModel(scene, device)
         self.cameras, self.gts = cameras, gt_images
         self.bg = torch.zeros(3, device=device)
@@ -89,6 +99,9 @@ class DropInLoop:
         self.lambda_dssim, self.patch_dwt_weight = 0.2, 0.1
         self.dwt_weights = {"LL1": 1.0, "LH1": 1.0, "HL1": 1.0, "HH1": 0.0, "LL2": 0.0, "LH2": 0.0, "HL2": 0.0, "HH2": 0.0}
         self.use_camera_key = use_camera_key
+        # `from gsplat_amd.render_raw import render` instead of the reference's gaussian_renderer.render
+        # (same signature and dict; the model's six raw tensors go to the library, no activation / cat kernels)
+        self.raw_render = raw_render
         # INTEGRATION.md section 1, "optional, faster": the loss calls of train.py:128-202 replaced by ONE call of
         # lgdwt_loss.criterion() (same terms, the running mean kept on the device: no `.item()`), ELF masks cached per camera
         self.criterion, self.masks = None, {}
@@ -107,7 +120,12 @@ class DropInLoop:
         from fused_ssim import fused_ssim
         from lgdwt_loss import compute_elf_map, compute_patch_dwt_loss, get_dwt_subbands, l1_loss
         pc = self.pc
-        pkg = render(self.cameras[ci], pc, self.bg, camera_key=("dropin", ci) if self.use_camera_key else None)
+        key = ("dropin", ci) if self.use_camera_key else None
+        if self.raw_render:
+            from .render_raw import render as render_raw
+            pkg = render_raw(self.cameras[ci], pc, _PIPE, self.bg, camera_key=key)
+        else:
+            pkg = render(self.cameras[ci], pc, self.bg, camera_key=key)
         image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
         gt = self.gts[ci]
         if self.criterion is not None:

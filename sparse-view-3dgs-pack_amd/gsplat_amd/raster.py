@@ -586,6 +586,7 @@ class RasterBackend:
         # (the train step's side launch and its backward describe the same view and the same Gaussians: they take these
         #  structs - and the tensors `keep` holds alive - instead of building them again; keyed by this forward's geometry buffer)
         self._built = dict(geom=geom.data_ptr(), view=view, g=g, keep=keep, raw=raw)
+        self._last_geom = (geom, P)   # (export_row_mask: the data-parallel step's early mask exchange)
 
         def new_binning(cap):
             _, _, bb, _ = self.scratch_bytes(P, W, H, cap)
@@ -1047,6 +1048,18 @@ class RasterBackend:
                 out["rotations"])
 
     # ------------------------------------------------------------------ markVisible
+    def export_row_mask(self, out):
+        """out [P] uint8 <- 1 where the Gaussian emitted instances in the LAST forward (gs_export_row_mask: what the
+        data-parallel backward later writes into GsStepState.grad_mask).  False when there is no such forward to ask."""
+        last = getattr(self, "_last_geom", None)
+        if last is None or last[0].device != out.device or last[1] != out.numel() or not hasattr(self.api, "_export_row_mask"):
+            return False
+        geom, P = last
+        empty = torch.empty((0,), dtype=torch.uint8, device=geom.device)
+        s = self._scratch(geom, empty, empty, 0)
+        self.api.call("export_row_mask", C.byref(s), P, out.data_ptr(), self._stream(geom.device))
+        return True
+
     def mark_visible(self, means3D, viewmatrix, projmatrix):
         """= markVisible (rasterize_points.cu:225-244)."""
         self._check_device(means3D)

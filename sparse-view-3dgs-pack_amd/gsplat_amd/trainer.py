@@ -443,6 +443,10 @@ class GaussianModelLite:
         self.gain_grad_word = self.exchange[n_pad + 2 * P + 1:n_pad + 2 * P + 2]   # multispectral model: dL/dgain of this view
         # data-parallel step: 1 where this view's gradient row of the Gaussian may be non-zero (sparse exchange)
         self.grad_mask = torch.zeros((P,), dtype=torch.uint8, device=self.device)
+        # ... and the union of the ranks' masks, exchanged EARLY (as soon as the forward knows which Gaussians have instances,
+        # Trainer._begin_union), with its inclusive prefix - 1 (the packed row of every union member)
+        self.union_mask = torch.zeros((P,), dtype=torch.uint8, device=self.device)
+        self.union_pos = torch.zeros((P,), dtype=torch.int32, device=self.device)
         self.params = {}
         off = 0
         shapes = self._shapes(P)
@@ -1249,6 +1253,13 @@ class Trainer:
         else:
             pkg = self._render_view(ci, fused, (fused_step or fused_dp) and self.RAW_ACTIVATIONS)
             verdict = backend.take_deferred() if deferred else None
+            if self.world_size > 1 and self.sparse_exchange:
+                # which rows this view's gradient can touch is known NOW: the exchange of the masks starts behind the forward
+                # (side stream), under the criterion and the backward
+                if fused_dp and hasattr(backend, "export_row_mask") and backend.export_row_mask(m.union_mask):
+                    self._begin_union()
+                else:
+                    self._begin_union(pkg["radii"] > 0)
             if verdict is not None and not fused:
                 rm = getattr(self.criterion, "dwt_running_mean", None)
                 rm = None if rm is None else rm.clone()
@@ -1382,40 +1393,82 @@ class Trainer:
             m.xyz_gradient_accum += (m.stat_delta[0] * ok).unsqueeze(1)
             m.denom += (m.stat_delta[1] * ok).unsqueeze(1)
 
+    # ---- the visibility-sparse exchange
+    def _begin_union(self, mask_src=None):
+        """Start the exchange of the row masks NOW: `union_mask` <- this rank's mask (mask_src, or what the forward's geometry
+        state says: Gaussians with instances), all-reduced (MAX) over the ranks, then its prefix (the packed row of every
+        member) and its size K.  On the GPU all of it is enqueued on a SIDE stream right behind the forward - the collective is
+        1 byte per Gaussian - while the criterion and the backward run on the main stream; K travels to a pinned host word,
+        and the host reads it only when the backward has been enqueued (_exchange_and_step_sparse): off the critical path.
+        No-op unless the sparse exchange is on."""
+        if not (self.sparse_exchange and self.world_size > 1):
+            return
+        m = self.model
+        dev = m.flat.device
+
+        def work():
+            if mask_src is not None:
+                m.union_mask.copy_(mask_src.view(torch.uint8) if mask_src.dtype == torch.bool else mask_src)
+            dist.all_reduce(m.union_mask, op=dist.ReduceOp.MAX)
+            torch.cumsum(m.union_mask, dim=0, dtype=torch.int32, out=m.union_pos)
+            m.union_pos.sub_(1)
+        if dev.type == "cuda":
+            main = torch.cuda.current_stream(dev)
+            side = getattr(self, "_union_stream", None)
+            if side is None:
+                side = self._union_stream = torch.cuda.Stream(device=dev)
+                self._union_k = torch.zeros((1,), dtype=torch.int32).pin_memory()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                work()
+                self._union_k.copy_(m.union_pos[-1:], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            self._union = dict(event=ev, stream=side)
+        else:
+            work()
+            self._union = dict(event=None, stream=None, K=int(m.union_pos[-1]) + 1 if m.P else 0)
+
     def _exchange_and_step_sparse(self, optimizer_step, skip=(), gate=None):
-        """The visibility-sparse exchange.  Only Gaussians that emitted instances in SOME rank's view of this step
-        have a non-zero gradient row - with depth-limited lists a fifth of them per view, and never more than the ~40 % any
-        camera reaches - so: all-reduce (MAX) the per-rank row masks (1 byte per Gaussian), pack the union's rows of the
-        field-major gradient buffer into one contiguous buffer, all-reduce THAT, scatter the sums back, and run the dense
-        gated Adam on every replica (rows outside the union hold the exact sum already: zero on every rank - their update
-        is the zero-gradient one, identical everywhere, no traffic).  Statistics + flag (8 B/Gaussian) and max_radii2D
-        travel dense as in the other forms.  With two ranks the sums are the dense all-reduce's bit for bit (a + b
-        commutes); with more the reduction order is the library's choice in either form.  One host read per step (the
-        union's size, which the collective's message length needs)."""
+        """Only Gaussians that emitted instances in SOME rank's view of this step have a non-zero gradient row - with
+        depth-limited lists a fifth of them per view, and never more than the ~40 % any camera reaches - so: the union of the
+        ranks' row masks (1 byte per Gaussian, exchanged early: _begin_union), the union's rows of the field-major gradient
+        buffer packed into one contiguous buffer by ONE kernel (gs_rows_pack), THAT all-reduced, the sums scattered back
+        (gs_rows_unpack), and the dense gated Adam on every replica (rows outside the union hold the exact sum already: zero
+        on every rank - their update is the zero-gradient one, identical everywhere, no traffic).  Statistics + flag
+        (8 B/Gaussian) and max_radii2D travel dense as in the other forms.  With two ranks the sums are the dense
+        all-reduce's bit for bit (a + b commutes); with more the reduction order is the library's choice in either form.  The
+        host reads the union's size (the collective's message length) from a pinned word the side stream filled while the
+        backward ran."""
+        import ctypes as C
         m, opt = self.model, self.model.optimizer
         P, W = m.P, m.width
         n_grad = m.flat_grad.numel()
+        u = getattr(self, "_union", None)
+        self._union = None
+        if u is None:   # (nobody started it early: the backward's own mask, now)
+            self._begin_union(m.grad_mask)
+            u, self._union = self._union, None
         ws = dist.all_reduce(m.stat_tail, op=dist.ReduceOp.SUM, async_op=True)   # statistic increments + validity flag
         wmax = dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)
-        dist.all_reduce(m.grad_mask, op=dist.ReduceOp.MAX)
-        idx = m.grad_mask.nonzero().squeeze(1)        # (host sync: K)
-        K = int(idx.numel())
+        if u["event"] is not None:
+            u["event"].synchronize()          # (recorded behind the mask exchange on the side stream: long done)
+            K = int(self._union_k[0]) + 1
+            torch.cuda.current_stream(m.flat.device).wait_stream(u["stream"])
+        else:
+            K = u["K"]
         if K:
             need = (K * W + 3) // 4 * 4
             buf = getattr(self, "_packed", None)
             if buf is None or buf.numel() < need or buf.device != m.flat.device:
                 buf = self._packed = torch.empty((int(need * 1.25) + 1024,), dtype=torch.float32, device=m.flat.device)
-            views, off, poff = [], 0, 0
-            for name, n in m.fields:
-                src = m.flat_grad[off:off + P * n].view(P, n)
-                dst = buf[poff:poff + K * n].view(K, n)
-                torch.index_select(src, 0, idx, out=dst)
-                views.append((src, dst))
-                off += P * n
-                poff += K * n
+            widths = (C.c_int32 * len(m.fields))(*[n for _, n in m.fields])
+            stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
+            opt.api.call("rows_pack", m.flat_grad.data_ptr(), P, len(m.fields), widths, m.union_mask.data_ptr(),
+                         m.union_pos.data_ptr(), K, buf.data_ptr(), stream)
             dist.all_reduce(buf[:K * W], op=dist.ReduceOp.SUM)
-            for src, dst in views:
-                src.index_copy_(0, idx, dst)
+            opt.api.call("rows_unpack", m.flat_grad.data_ptr(), P, len(m.fields), widths, m.union_mask.data_ptr(),
+                         m.union_pos.data_ptr(), K, buf.data_ptr(), stream)
         self.last_exchange = dict(union_rows=K, rows=P, sparse_bytes=4 * K * W + P + 4 * int(m.stat_tail.numel()),
                                   dense_bytes=4 * (n_grad + int(m.stat_tail.numel())))
         if gate is not None or opt.sparse:
