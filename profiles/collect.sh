@@ -7,7 +7,7 @@
 set -e
 TAG=${1:-r03}
 # kernel-level numbers: eager launches (a hipGraph replay shows the same kernels), no reference-lists leg
-export GS_BENCH_GRAPH=0 GS_BENCH_REFERENCE_LISTS=0 GS_BENCH_OTHER_SCENES=0 GS_BENCH_DROP_IN=0
+export GS_BENCH_GRAPH=0 GS_BENCH_REFERENCE_LISTS=0 GS_BENCH_OTHER_SCENES=0 GS_BENCH_DROP_IN=0 GS_BENCH_OPTIONS=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=/tmp/prof_$TAG
 SUM=$R/gpurun_out/prof_${TAG}_summary
@@ -29,6 +29,12 @@ export GS_BENCH_SCENE=init_like
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_init_like -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_trace_init_like.json 2> $OUT/bench_trace_init_like.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq_init_like -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > /dev/null 2> $OUT/bench_sq_init_like.err
 unset GS_BENCH_SCENE
+# the two-level binning of tile_cull = 0 (the reference's lists, R = 23 M at C3; csrc/gs_tilebin.hip): forwards only
+BP="python3 $R/tests/tools/binning_probe.py c3 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_binning -- $BP 12 > $OUT/binning_trace.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/sq_binning -- $BP 6 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_binning -- $BP 6 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_binning -- $BP 6 > /dev/null 2>&1
 python3 $R/profiles/summarize.py $OUT $TAG $SUM > $SUM/summarize.log 2>&1 || tail -5 $SUM/summarize.log
 cp $OUT/bench_trace.json $SUM/${TAG}_bench_under_rocprof.json
 ls -la $SUM

@@ -39,7 +39,9 @@ OURS = ("preprocess_fwd_kernel", "scan_block_sums_kernel", "rs_hist_kernel", "rs
         "l1_bwd_kernel", "dwt2_l1_fwd_kernel", "dwt2_l1_bwd_kernel", "ssim_fwd_kernel", "ssim_bwd_kernel",
         "patch_dwt_kernel", "lgdwt_combine_kernel", "act_fwd_kernel", "act_bwd_kernel", "densify_stats_kernel", "patch_means_kernel", "elf_low_kernel", "bilinear_up_kernel", "knn_search_kernel", "preprocess_bwd_step_kernel",
         "tile_order_kernel", "zero_rows_kernel", "stop_depth_bounds_kernel", "region_bin_kernel", "region_prepare_kernel",
-        "status_tag_kernel", "rs_small_sort_kernel", "step_uninstanced_kernel", "chain_kernel")
+        "status_tag_kernel", "rs_small_sort_kernel", "step_uninstanced_kernel", "chain_kernel",
+        "tb_entries_kernel", "tb_emit_kernel", "tb_regions_from_counts_kernel", "tb_regions_kernel", "tb_tile_count_kernel",
+        "tb_region_scan_kernel", "tb_tile_scan_kernel", "tb_write_kernel", "depth_l1_kernel", "rows_pack_kernel", "row_mask_kernel")
 
 
 def short(name):
@@ -211,3 +213,38 @@ for kind in ("init_like",):
                     ident[stn + "_salu_per_wave"] = sum(sa) / sum(wv) * len(wv) / len(sa)
     json.dump(ident, open(os.path.join(here, "sq_insts_%s.json" % kind), "w"), indent=1)
     print(kind, json.dumps(ident))
+
+
+# the two-level binning of the reference's lists (collect.sh: tests/tools/binning_probe.py c3 0) -> <tag>_binning_kernel_stats.csv
+# (kernel trace summary of the forwards) and <tag>_binning_counters.csv (bytes per launch, LDS bank conflicts)
+st_files = glob.glob(os.path.join(src, "trace_binning", "*", "*_kernel_stats.csv"))
+if st_files:
+    BIN = ("tb_", "rs_", "scan_sums_kernel", "scan_block_sums_kernel", "bin_prepare_kernel", "preprocess_fwd_kernel", "render_fwd_wave_kernel")
+    with open(os.path.join(here, "%s_binning_kernel_stats.csv" % tag), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+        for r in csv.DictReader(open(st_files[0])):
+            if any(b in r["Name"] for b in BIN):
+                w.writerow([r["Name"].split("(")[0][-48:], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"]])
+    try:
+        shutil.copyfile(os.path.join(src, "binning_trace.log"), os.path.join(here, "%s_binning_probe.log" % tag))
+    except OSError:
+        pass
+    cnt = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d_ in ("sq_binning", "fetch_binning", "write_binning"):
+        for f in glob.glob(os.path.join(src, d_, "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                cnt[r["Kernel_Name"].split("(")[0][-48:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(os.path.join(here, "%s_binning_counters.csv" % tag), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "hbm_read_bytes_corrected(x2)", "hbm_write_bytes", "LDS_insts_per_wave",
+                    "LDS_bank_conflict_pct_of_LDS_cycles"])
+        for k, v in sorted(cnt.items()):
+            if not any(b in k for b in BIN):
+                continue
+            last = lambda x: x[-max(1, len(x) // 2):]    # (the steady-state launches: the later half)
+            m = {c: sum(last(x)) / len(last(x)) for c, x in v.items()}
+            w.writerow([k, len(next(iter(v.values()))), "%.0f" % (2048.0 * m.get("FETCH_SIZE", 0)), "%.0f" % (1024.0 * m.get("WRITE_SIZE", 0)),
+                        round(m.get("SQ_INSTS_LDS", 0) / max(1.0, m.get("SQ_WAVES", 0)), 1),
+                        round(100 * m.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, m.get("SQ_LDS_IDX_ACTIVE", 0)), 1)])
+    print(open(os.path.join(here, "%s_binning_counters.csv" % tag)).read())

@@ -42,14 +42,20 @@ __global__ void __launch_bounds__(GS_BLOCK) bin_prepare_kernel(GeomHeader* hdr, 
 // drop_max (first pass of the depth sort): keys 0xFFFFFFFF - Gaussians that emit no instance: culled, or cut away entirely
 // by the depth limits, 80 % of them at the bench workload - are not counted and not scattered: the pass filters while it
 // sorts, and the later passes (and everything downstream of the order) handle the survivors only.
+// The table's row stride is the number of tiles the keys really fill - ceil(n / RS_TILE) with n read on the device - not the
+// host's bound: the partition of the region entries is launched for the binning CAPACITY (instances) but sorts a fifth of that
+// many entries, and a workgroup beyond the last tile used to write its 512 zero counts into a 4.5 x larger table (94 MB of
+// scattered 4-byte writes per pass at C3, profiles/r05_binning_counters.csv).
 template <int BITS>
 __global__ void __launch_bounds__(RS_HIST_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* n_dev,
-                                                                  int shift, uint32_t* __restrict__ hist, uint32_t nblk,
-                                                                  int drop_max) {
+                                                                  int shift, uint32_t* __restrict__ hist, int drop_max) {
   constexpr int RADIX = 1 << BITS;
   __shared__ uint32_t h[RS_HIST_THREADS / 64][RADIX];  // one private histogram per wave
   const uint32_t n = *n_dev;
+  const uint32_t nblk = (n + RS_TILE - 1) / RS_TILE;
+  if (blockIdx.x >= nblk) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   constexpr int NW = RS_HIST_THREADS / 64, PER_WAVE = RS_TILE / NW, ROUNDS = PER_WAVE / 64;
 #pragma unroll
   for (int k = tid; k < NW * RADIX; k += RS_HIST_THREADS) (&h[0][0])[k] = 0;
@@ -62,10 +68,20 @@ __global__ void __launch_bounds__(RS_HIST_THREADS) rs_hist_kernel(const uint32_t
       const uint32_t i = w0 + r * 64 + lane;
       k[r] = i < n ? keys[i] : 0u;
     }
+    // the lanes of a wave that share a digit elect a leader that adds their number (ballot match, as the scatter kernel ranks):
+    // with LDS atomics the high digits of a depth - a handful of values - put 64 lanes on one counter (70 % bank conflicts)
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
       const uint32_t i = w0 + r * 64 + lane;
-      if (i < n && !(drop_max && k[r] == 0xFFFFFFFFu)) atomicAdd(&h[wid][(k[r] >> shift) & (uint32_t)(RADIX - 1)], 1u);
+      const bool valid = i < n && !(drop_max && k[r] == 0xFFFFFFFFu);
+      const uint32_t d = (k[r] >> shift) & (uint32_t)(RADIX - 1);
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < BITS; b++) {
+        const unsigned long long bal = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? bal : ~bal;
+      }
+      if (valid && (peers & lt_mask) == 0ull) h[wid][d] += (uint32_t)__popcll(peers);   // (one lane per digit: no atomic needed)
     }
   }
   __syncthreads();
@@ -108,10 +124,11 @@ __global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t* sums, int nb)
 // (b) of a radix pass in ONE launch: workgroup d scans row d of the digit-major table in place (exclusive, over
 // the workgroups of the sort) and stores the row total; the scatter kernel adds the exclusive scan of the 256
 // totals itself.  (The generic three-kernel scan of the whole table cost two more launches per pass.)
-__global__ void __launch_bounds__(GS_BLOCK) rs_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblk,
+__global__ void __launch_bounds__(GS_BLOCK) rs_rowscan_kernel(uint32_t* __restrict__ hist, const uint32_t* __restrict__ n_dev,
                                                               uint32_t* __restrict__ totals) {
   constexpr int IT = 8;
   __shared__ uint32_t wsum[GS_BLOCK / 64];
+  const uint32_t nblk = (*n_dev + RS_TILE - 1) / RS_TILE;
   uint32_t* row = hist + (size_t)blockIdx.x * nblk;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint32_t carry = 0;
@@ -155,7 +172,7 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
                                                         const uint32_t* __restrict__ vin,  // NULL: value = index
                                                         uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                         const uint32_t* n_dev, int shift,
-                                                        const uint32_t* __restrict__ hist, uint32_t nblk,
+                                                        const uint32_t* __restrict__ hist,
                                                         const uint32_t* __restrict__ totals, int drop_max,
                                                         uint32_t* __restrict__ n_kept) {
   constexpr int RADIX = 1 << BITS;
@@ -164,6 +181,7 @@ __global__ void __launch_bounds__(NT) rs_scatter_kernel(const uint32_t* __restri
   static_assert(NT >= RADIX && RS_TILE % NT == 0, "one thread per digit in phase 2");
   __shared__ uint32_t s_hist[NW][RADIX];  // phase 1: wave digit counts; phase 3: output bases
   const uint32_t n = *n_dev;
+  const uint32_t nblk = (n + RS_TILE - 1) / RS_TILE;   // (the table's row stride: see rs_hist_kernel)
   const uint32_t t0 = blockIdx.x * RS_TILE;
   if (t0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -406,12 +424,12 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
   const uint32_t nblk = (uint32_t)((n_bound + RS_TILE - 1) / RS_TILE);
   if (digit_bits == 9) {
     if (end_bit > 9 || first_keys != nullptr) return GS_E_SHAPE;
-    hipLaunchKernelGGL(rs_hist_kernel<9>, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, b.keys[cur], n_dev, 0, b.hist, nblk, 0);
+    hipLaunchKernelGGL(rs_hist_kernel<9>, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, b.keys[cur], n_dev, 0, b.hist, 0);
     GS_LAUNCH_CHECK(s, debug);
-    hipLaunchKernelGGL(rs_rowscan_kernel, dim3(512), dim3(GS_BLOCK), 0, s, b.hist, nblk, b.scan_tmp);
+    hipLaunchKernelGGL(rs_rowscan_kernel, dim3(512), dim3(GS_BLOCK), 0, s, b.hist, n_dev, b.scan_tmp);
     GS_LAUNCH_CHECK(s, debug);
     hipLaunchKernelGGL((rs_scatter_kernel<RS_SCATTER_THREADS, 9>), dim3(nblk), dim3(RS_SCATTER_THREADS), 0, s, b.keys[cur], b.vals[cur],
-                       b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, 0, b.hist, nblk, b.scan_tmp, 0, (uint32_t*)nullptr);
+                       b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, 0, b.hist, b.scan_tmp, 0, (uint32_t*)nullptr);
     GS_LAUNCH_CHECK(s, debug);
     return 0;
   }
@@ -424,14 +442,14 @@ int launch_radix_sort(const SortBufs& b, const uint32_t* n_dev, int64_t n_bound,
     const uint32_t* kin = ext ? first_keys : b.keys[cur];
     const uint32_t* vin = ext ? nullptr : b.vals[cur];
     const int drop = ext && n_kept ? 1 : 0;  // the first pass of the depth sort filters (see rs_hist_kernel)
-    hipLaunchKernelGGL(rs_hist_kernel<RS_BITS>, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, kin, n_dev, shift, b.hist, nblk, drop);
+    hipLaunchKernelGGL(rs_hist_kernel<RS_BITS>, dim3(nblk), dim3(RS_HIST_THREADS), 0, s, kin, n_dev, shift, b.hist, drop);
     GS_LAUNCH_CHECK(s, debug);
-    hipLaunchKernelGGL(rs_rowscan_kernel, dim3(RS_RADIX), dim3(GS_BLOCK), 0, s, b.hist, nblk, b.scan_tmp);
+    hipLaunchKernelGGL(rs_rowscan_kernel, dim3(RS_RADIX), dim3(GS_BLOCK), 0, s, b.hist, n_dev, b.scan_tmp);
     GS_LAUNCH_CHECK(s, debug);
     // 512 threads per 4096-key tile (8 ranking rounds per wave): 0.213 ms for the two instance passes against 0.226 with
     // 256 threads and 0.217 with 1024 - the pass is bound by one workgroup's dependent chain, not by throughput
     hipLaunchKernelGGL((rs_scatter_kernel<RS_SCATTER_THREADS, RS_BITS>), dim3(nblk), dim3(RS_SCATTER_THREADS), 0, s, kin, vin,
-                       b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, shift, b.hist, nblk, b.scan_tmp, drop, drop ? n_kept : nullptr);
+                       b.keys[cur ^ 1], b.vals[cur ^ 1], n_dev, shift, b.hist, b.scan_tmp, drop, drop ? n_kept : nullptr);
     GS_LAUNCH_CHECK(s, debug);
     if (drop) n_dev = n_kept;  // the later passes see the survivors only
     cur ^= 1;
