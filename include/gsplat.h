@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 6  /* round 5: gs_depth_l1, GsView.debug bit 1, binning buffer = sort arrays + region / chunk / tile tables */
+#define GS_ABI_VERSION 7  /* round 5: gs_depth_l1, GsView.debug bit 1, binning buffer = sort arrays + region / chunk / tile tables;
+                             GsGaussians.shs_rest / GsStepState.grad_out_rest (the model's split SH rows) */
 
 /* error codes (negative = caller error) */
 #define GS_OK 0
@@ -109,6 +110,12 @@ typedef struct GsGaussians {
                                   sigmoid(extra_channel[i]) * clamp(*extra_gain, 0.1, 10) - the multispectral model's raw NIR
                                   albedo and global gain (mult-dwtgs/gaussian_renderer/__init__.py:166-169), activated in
                                   the kernel like the other raw rows.  NULL: extra_channel holds the values to blend */
+  const float* shs_rest;       /* NULL: `shs` holds all M coefficients of a Gaussian in one row.  Otherwise the SPLIT layout of the
+                                  reference's GaussianModel (scene/gaussian_model.py:45-46,127-130): `shs` = _features_dc [P,1,3],
+                                  `shs_rest` = _features_rest [P,M-1,3] - the kernels read the two rows where the model keeps
+                                  them, so no torch.cat copy of 192 B per Gaussian runs per view (gaussian_model.py:get_features).
+                                  Honoured by gs_forward_geometry and by gs_backward_step in its gradients-out form
+                                  (GsStepState.grad_out_rest); the other entries return GS_E_UNSUPPORTED */
 } GsGaussians;
 
 /* Caller-owned scratch.  geom and img sizes depend on (P, W, H); binning on the capacity in
@@ -183,6 +190,10 @@ typedef struct GsGrads {
 int gs_abi_version(void);
 /* Human readable build string: arch, compiler, kernel variants. */
 const char* gs_build_info(void);
+/* sizeof() of a public struct as this library was compiled: 0 GsView, 1 GsGaussians, 2 GsScratch, 3 GsGrads, 4 GsStepState,
+ * 5 GsLgdwtParams, 6 GsAdamSeg; 0 for any other index.  A binding written in another language (the ctypes mirror of
+ * gsplat_amd/capi.py, a cgo / JNI struct) checks its own layout against it at load time. */
+size_t gs_struct_bytes(int32_t which);
 
 /* out[0..2] = bytes needed for geom, img, binning given capacity R_capacity instances.
  * workspace_bytes (may be NULL) = bytes gs_backward needs as its workspace. */
@@ -361,6 +372,10 @@ typedef struct GsStepState {
    * parameter moves by the old momentum).  Visible Gaussians without instances (culled spans, depth limits) still take
    * their zero-gradient step.  Blocks of 256 rows without a visible Gaussian cost no parameter or moment traffic. */
   int32_t sparse;
+  /* Gradients-out form with the split SH layout (GsGaussians.shs_rest != NULL): grad_out[1] receives the gradient of
+   * _features_dc [P,1,3] and grad_out_rest that of _features_rest [P,M-1,3] - each a contiguous tensor as autograd's
+   * AccumulateGrad wants it (a strided slice of one [P,16,3] buffer is copied again).  NULL with the one-row layout. */
+  float* grad_out_rest;
 } GsStepState;
 #define GS_STEP_BLOCK 256
 int gs_backward_step(const GsView* view, const GsGaussians* g, const int32_t* radii,

@@ -25,7 +25,11 @@
  *    order (backward.cu:593-635) are accumulated here in double and rounded once: the
  *    order-independent centre of all valid reference outcomes.
  *  - float->int casts use the CUDA saturating semantics explicitly (gs_oracle_math.h).
- *  - OpenMP parallelism over Gaussians / tiles (results do not depend on thread count).
+ *  - OpenMP parallelism over Gaussians / tiles.  Forward results do not depend on the thread count.  The backward adds the
+ *    tiles' contributions to a Gaussian's double accumulator in the order the threads finish (omp atomic, dynamic schedule):
+ *    the double sums can differ in their last bits between runs, the fp32 gradients they are rounded to are the same except
+ *    where a sum cancels to ~1e-11 of its terms (a value of that size on one run, exactly 0 on another: tests/test_model_ops.py
+ *    allows for it; seen with 128 threads).
  */
 #include <algorithm>
 #include <cfloat>
@@ -362,12 +366,20 @@ static int check_args(const GsView* v, const GsGaussians* g) {
   bool any_sr = g->scales != nullptr || g->rotations != nullptr;
   if ((!has_sr && g->cov3D_precomp == nullptr) || (any_sr && g->cov3D_precomp != nullptr)) return GS_E_SHAPE;
   if (g->shs && (g->M < (v->sh_degree + 1) * (v->sh_degree + 1) || !v->campos)) return GS_E_SHAPE;
+  /* the split SH rows are a memory layout of the product (same numbers from two arrays): the oracle takes the [P,M,3] rows and
+   * tests/test_gpu_render_raw.py compares the product's two layouts bit for bit */
+  if (g->shs_rest) return GS_E_UNSUPPORTED;
   return GS_OK;
 }
 
 extern "C" {
 
 int gso_abi_version(void) { return GS_ABI_VERSION; }
+size_t gso_struct_bytes(int32_t which) {
+  const size_t n[7] = {sizeof(GsView), sizeof(GsGaussians), sizeof(GsScratch), sizeof(GsGrads), sizeof(GsStepState),
+                       sizeof(GsLgdwtParams), sizeof(GsAdamSeg)};
+  return (which >= 0 && which < 7) ? n[which] : 0;
+}
 const char* gso_build_info(void) { return "gs_oracle: CPU restatement, fp32, -ffp-contract=off"; }
 
 int gso_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t R, size_t out[3], size_t* bwd_ws) {

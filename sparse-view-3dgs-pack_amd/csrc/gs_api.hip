@@ -20,6 +20,7 @@ static int check_args(const GsView* v, const GsGaussians* g) {
   if ((!has_sr && g->cov3D_precomp == nullptr) || (any_sr && g->cov3D_precomp != nullptr)) return GS_E_SHAPE;
   if (g->shs && (g->M < (v->sh_degree + 1) * (v->sh_degree + 1) || !v->campos)) return GS_E_SHAPE;
   if (v->sh_degree < 0 || v->sh_degree > 3) return GS_E_SHAPE;
+  if (g->shs_rest && (!g->shs || g->M < 2)) return GS_E_SHAPE;  // split rows: DC in shs, coefficients 1..M-1 in shs_rest
   if (v->image_width > 65535 * TILE_X || v->image_height > 65535 * TILE_Y) return GS_E_UNSUPPORTED;
   return GS_OK;
 }
@@ -61,6 +62,19 @@ static int region_layout(const GsView* v, const GsScratch* sc, RegionLayout& rl)
 extern "C" {
 
 int gs_abi_version(void) { return GS_ABI_VERSION; }
+
+size_t gs_struct_bytes(int32_t which) {
+  switch (which) {
+    case 0: return sizeof(GsView);
+    case 1: return sizeof(GsGaussians);
+    case 2: return sizeof(GsScratch);
+    case 3: return sizeof(GsGrads);
+    case 4: return sizeof(GsStepState);
+    case 5: return sizeof(GsLgdwtParams);
+    case 6: return sizeof(GsAdamSeg);
+    default: return 0;
+  }
+}
 
 const char* gs_build_info(void) {
   return "libgsplat_hip gfx950 | hipcc " __VERSION__
@@ -105,6 +119,7 @@ int gs_forward_geometry(const GsView* v, const GsGaussians* g, GsScratch* sc, in
   a.opacities = g->opacities;
   a.raw_activations = g->raw_activations;
   a.shs = g->shs;
+  a.shs_rest = g->shs_rest;
   a.cov3D_precomp = g->cov3D_precomp;
   a.colors_precomp = g->colors_precomp;
   a.viewmatrix = v->viewmatrix;
@@ -325,6 +340,7 @@ static PreprocessBwdArgs preprocess_bwd_args(const GsView* v, const GsGaussians*
   a.means3D = g->means3D;
   a.radii = radii;
   a.shs = g->shs;
+  a.shs_rest = g->shs_rest;
   a.scales = g->scales;
   a.rotations = g->rotations;
   a.opacities = g->opacities;
@@ -364,6 +380,9 @@ static int step_args(const GsGaussians* g, const GsStepState* st, StepArgs& sa) 
   const bool any_stat = st->max_radii2D || st->xyz_gradient_accum || st->denom;
   if (any_stat && !(st->max_radii2D && st->xyz_gradient_accum && st->denom)) return GS_E_NULL;
   if (g->means3D != st->xyz || g->shs != st->features) return GS_E_SHAPE;  // no activation between them
+  // split SH rows: only the gradients-out form serves them (one gradient tensor per model tensor)
+  if ((g->shs_rest != nullptr) != (st->grad_out_rest != nullptr)) return GS_E_SHAPE;
+  if (g->shs_rest && !grads_out) return GS_E_UNSUPPORTED;
   if (g->M != 16 || g->colors_precomp || g->cov3D_precomp || !g->scales || !g->rotations) return GS_E_UNSUPPORTED;
   // the 4th channel: its raw row and the gain are this step's parameters, or there is no 4th channel at all
   if ((g->extra_channel != nullptr) != (st->extra != nullptr)) return GS_E_UNSUPPORTED;
@@ -405,6 +424,7 @@ static int backward_impl(const GsView* v, const GsGaussians* g, const int32_t* r
   if (rc) return rc;
   if (!sc || !grads || !dL_dcolor) return GS_E_NULL;
   if (g->raw_activations && !step) return GS_E_UNSUPPORTED;  // gradients w.r.t. activated values that were never formed
+  if (g->shs_rest && !step) return GS_E_UNSUPPORTED;         // GsGrads.dL_dsh is one [P,M,3] array
   StepArgs sa;
   if (step && g->P > 0) {
     rc = step_args(g, step, sa);
@@ -537,7 +557,7 @@ int gs_backward_from_rows(const GsView* v, const GsGaussians* g, const int32_t* 
   int rc = check_args(v, g);
   if (rc) return rc;
   if (!sc || !grads) return GS_E_NULL;
-  if (g->raw_activations) return GS_E_UNSUPPORTED;
+  if (g->raw_activations || g->shs_rest) return GS_E_UNSUPPORTED;
   if (depth_mode < 0 || depth_mode > 2) return GS_E_SHAPE;
   const int P = g->P;
   if (P == 0) return GS_OK;

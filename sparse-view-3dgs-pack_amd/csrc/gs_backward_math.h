@@ -401,6 +401,16 @@ GS_DEV V3 sh_backward_row(const PreprocessBwdArgs& a, int idx, V3 dL_dcolor, con
   const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
   const uint32_t clamped = a.splat[idx].clamped;
   const V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
+  if (a.M == 16 && a.shs_rest) {  // split rows, as preprocess_fwd reads them
+    ShRegsB sh;
+    const float* dc = a.shs + (size_t)idx * 3;
+    const float* rest = a.shs_rest + (size_t)idx * 45;
+    const int nfl = 3 * (a.D + 1) * (a.D + 1) - 3;
+    sh.f[0] = dc[0]; sh.f[1] = dc[1]; sh.f[2] = dc[2];
+#pragma unroll
+    for (int k = 0; k < 45; k++) sh.f[3 + k] = k < nfl ? rest[k] : 0.f;
+    return sh_backward(a.D, mean, campos, sh, clamped, dL_dcolor, dsh);
+  }
   if (a.M == 16) {
     ShRegsB sh;
     const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
@@ -420,5 +430,15 @@ GS_DEV V3 sh_backward_row(const PreprocessBwdArgs& a, int idx, V3 dL_dcolor, con
     const float* p;
     __host__ __device__ __forceinline__ V3 operator()(int k) const { return {p[3 * k], p[3 * k + 1], p[3 * k + 2]}; }
   } sh{a.shs + (size_t)idx * a.M * 3};
+  if (a.shs_rest) {
+    struct ShMemSplitB {
+      const float *dc, *rest;
+      __host__ __device__ __forceinline__ V3 operator()(int k) const {
+        const float* p = k == 0 ? dc : rest + 3 * (k - 1);
+        return {p[0], p[1], p[2]};
+      }
+    } shs{a.shs + (size_t)idx * 3, a.shs_rest + (size_t)idx * (a.M - 1) * 3};
+    return sh_backward(a.D, mean, campos, shs, clamped, dL_dcolor, dsh);
+  }
   return sh_backward(a.D, mean, campos, sh, clamped, dL_dcolor, dsh);
 }

@@ -263,6 +263,7 @@ struct PreprocessArgs {
   const float* rotations;
   const float* opacities;
   const float* shs;
+  const float* shs_rest;  // GsGaussians.shs_rest: split rows (shs = [P,1,3], shs_rest = [P,M-1,3]) or NULL
   const float* cov3D_precomp;
   const float* colors_precomp;
   const float* viewmatrix;
@@ -336,6 +337,7 @@ struct PreprocessBwdArgs {
   const float* means3D;
   const int* radii;
   const float* shs;
+  const float* shs_rest;  // GsGaussians.shs_rest: split rows (shs = [P,1,3], shs_rest = [P,M-1,3]) or NULL
   const float* scales;
   const float* rotations;
   const float* opacities;

@@ -47,6 +47,13 @@ struct ShMem {  // generic M: scalar loads
   const float* p;
   __device__ __forceinline__ V3 operator()(int k) const { return {p[3 * k], p[3 * k + 1], p[3 * k + 2]}; }
 };
+struct ShMemSplit {  // generic M, split rows (GsGaussians.shs_rest)
+  const float *dc, *rest;
+  __device__ __forceinline__ V3 operator()(int k) const {
+    const float* p = k == 0 ? dc : rest + 3 * (k - 1);
+    return {p[0], p[1], p[2]};
+  }
+};
 
 // Depth limits (gs_tilecull.h): the look-ups of a Gaussian have nothing to do with its neighbours' in the wave - fully
 // divergent loads, served one lane at a time by the vector memory path.  The tables are small, so each workgroup first
@@ -332,7 +339,19 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
           V3 campos = {cam[0], cam[1], cam[2]};
           V3 rgb;
           uint32_t cl = 0;
-          if (a.M == 16) {
+          if (a.M == 16 && a.shs_rest) {
+            // the model's split rows (GsGaussians.shs_rest): 12 B of _features_dc + the active part of the 180 B row of
+            // _features_rest, dword loads (a 180 B row starts on a 16 B boundary for every fourth Gaussian only)
+            ShRegs sh;
+            const float* dc = a.shs + (size_t)idx * 3;
+            const float* rest = a.shs_rest + (size_t)idx * 45;
+            const int nfl = 3 * (a.D + 1) * (a.D + 1) - 3;
+            sh.f[0] = dc[0]; sh.f[1] = dc[1]; sh.f[2] = dc[2];
+  #pragma unroll
+            for (int k = 0; k < 45; k++) sh.f[3 + k] = k < nfl ? rest[k] : 0.f;
+            bump();
+            rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
+          } else if (a.M == 16) {
             ShRegs sh;
             const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
             const int nvec = a.D == 0 ? 1 : (a.D == 1 ? 3 : (a.D == 2 ? 7 : 12));
@@ -346,6 +365,10 @@ __global__ void __launch_bounds__(GS_BLOCK) preprocess_fwd_kernel(PreprocessArgs
               }
             }
             bump();
+            rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
+          } else if (a.shs_rest) {
+            bump();
+            ShMemSplit sh{a.shs + (size_t)idx * 3, a.shs_rest + (size_t)idx * (a.M - 1) * 3};
             rgb = color_from_sh(a.D, p_orig, campos, sh, cl);
           } else {
             bump();

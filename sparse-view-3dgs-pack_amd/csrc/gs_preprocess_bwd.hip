@@ -516,7 +516,28 @@ __global__ void __launch_bounds__(GS_BLOCK, 4) preprocess_bwd_step_kernel(Prepro
       grad_block<1>(st.grad_out[2], first, cnt, Lds{s_g + SG_OPAC});
       grad_block<3>(st.grad_out[3], first, cnt, Lds{s_g + SG_SCALE});
       grad_block<4>(st.grad_out[4], first, cnt, Lds{s_g + SG_ROT});
-      grad_block<48>(st.grad_out[1], first, cnt, ShGrad{s_sh});
+      if (st.grad_out_rest) {  // split rows: one contiguous gradient per model tensor (_features_dc, _features_rest)
+        struct ShGradDc {
+          const float* s;
+          __device__ __forceinline__ float operator()(int j) const {
+            const int r = j / 3, ch = j - 3 * r;
+            const float* src = s + r * SH_LDS_ROW;
+            return src[0] * src[16 + ch];
+          }
+        };
+        struct ShGradRest {
+          const float* s;
+          __device__ __forceinline__ float operator()(int j) const {
+            const int r = j / 45, c = j - r * 45, k = c / 3, ch = c - 3 * k;
+            const float* src = s + r * SH_LDS_ROW;
+            return src[k + 1] * src[16 + ch];
+          }
+        };
+        grad_block<3>(st.grad_out[1], first, cnt, ShGradDc{s_sh});
+        grad_block<45>(st.grad_out_rest, first, cnt, ShGradRest{s_sh});
+      } else {
+        grad_block<48>(st.grad_out[1], first, cnt, ShGrad{s_sh});
+      }
     }
     return;
   }

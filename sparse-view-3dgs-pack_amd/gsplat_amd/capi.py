@@ -44,6 +44,7 @@ class GsGaussians(C.Structure):
         ("extra_channel", C.c_void_p),
         ("raw_activations", C.c_int32),
         ("extra_gain", C.c_void_p),
+        ("shs_rest", C.c_void_p),
     ]
 
 
@@ -106,7 +107,8 @@ class GsStepState(C.Structure):
                 ("extra", C.c_void_p), ("extra_m", C.c_void_p), ("extra_v", C.c_void_p), ("gain", C.c_void_p),
                 ("gain_m", C.c_void_p), ("gain_v", C.c_void_p), ("lr_extra", C.c_float), ("lr_gain", C.c_float),
                 ("step_extra", C.c_int32), ("step_gain", C.c_int32), ("grad_out_extra", C.c_void_p),
-                ("grad_out_gain", C.c_void_p), ("grad_mask", C.c_void_p), ("dormant", C.c_void_p), ("sparse", C.c_int32)]
+                ("grad_out_gain", C.c_void_p), ("grad_mask", C.c_void_p), ("dormant", C.c_void_p), ("sparse", C.c_int32),
+                ("grad_out_rest", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -119,6 +121,7 @@ _SZ = C.c_size_t
 # declares" (tests/test_abi.py checks this table against the header and against the .so).
 PROTOTYPES = {
     "abi_version": (C.c_int, []),
+    "struct_bytes": (C.c_size_t, [C.c_int32]),
     "build_info": (C.c_char_p, []),
     "scratch_bytes": (C.c_int, [_I32, _I32, _I32, _I64, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "forward_geometry": (C.c_int, [C.POINTER(GsView), C.POINTER(GsGaussians), C.POINTER(GsScratch), _P, _P, _P]),

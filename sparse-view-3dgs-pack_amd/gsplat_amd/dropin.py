@@ -131,7 +131,10 @@ class DropInLoop:
         if self.criterion is not None:
             if self.patch and ci not in self.masks:
                 self.masks[ci] = self.criterion.elf_mask(gt)
-            loss, _ = self.criterion(image, gt, mask=self.masks.get(ci))
+            if "render_unclamped" in pkg:   # render_raw: the whole criterion as ONE autograd node on the un-clamped render
+                loss, _ = self.criterion.fused_call(pkg["render_unclamped"], gt, mask=self.masks.get(ci))
+            else:
+                loss, _ = self.criterion(image, gt, mask=self.masks.get(ci))
             return self._finish(loss, vsp, vis, radii)
         Ll1 = l1_loss(image, gt)
         dwt_loss = torch.tensor(0.0, device=image.device)

@@ -111,6 +111,9 @@ class RasterBackend:
         # (GsGaussians.raw_activations): no activation kernel, no activated copies
         self.raw_activations = False
         self._raw_backward = False
+        # one-shot, set before a forward / a fused backward on raw rows: the model's _features_rest [P,M-1,3]; `sh` is then
+        # _features_dc [P,1,3] (GsGaussians.shs_rest: the kernels read the split rows, no torch.cat)
+        self.sh_rest = None
         # parity probes: keep the backward workspace (the per-Gaussian 16-slot float64 gradient rows of the blend backward)
         self.keep_workspace = False
         self.last_workspace = None
@@ -147,7 +150,7 @@ class RasterBackend:
         return v
 
     def _gauss(self, keep, device, means3D, sh, colors, opacities, scales, rotations, cov3D, extra=None, raw=False,
-               extra_gain=None):
+               extra_gain=None, sh_rest=None):
         g = GsGaussians()
         g.raw_activations = int(bool(raw))
         extra = _prep(extra, device)
@@ -162,6 +165,13 @@ class RasterBackend:
         keep += [means3D, sh, colors, opacities, scales, rotations, cov3D]
         g.P = int(means3D.shape[0]) if means3D is not None else 0
         g.M = int(sh.shape[1]) if sh is not None else 0
+        if sh_rest is not None:
+            if sh is None or int(sh.shape[1]) != 1 or sh_rest.shape[0] != sh.shape[0]:
+                raise RuntimeError("sh_rest goes with sh = the DC rows [P,1,3]")
+            sh_rest = _prep(sh_rest, device)
+            keep.append(sh_rest)
+            g.M = 1 + int(sh_rest.shape[1])
+            g.shs_rest = _ptr(sh_rest)
         g.means3D, g.shs, g.colors_precomp, g.opacities = _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacities)
         g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D)
         return g
@@ -526,6 +536,9 @@ class RasterBackend:
 
         raw, self.raw_activations = self.raw_activations, False
         self._raw_backward = raw
+        sh_rest, self.sh_rest = self.sh_rest, None
+        if sh_rest is not None and not raw:
+            raise RuntimeError("split SH rows are served with raw activations only (gsplat_amd.render_raw)")
         if raw and fsgs:
             raise RuntimeError("raw activations do not serve the FSGS rasterizer generation")
         if (extra_gain is not None) != (raw and extra is not None):
@@ -576,7 +589,7 @@ class RasterBackend:
         view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
                           degree, prefiltered, antialiasing, debug)
         g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra, raw=raw,
-                        extra_gain=extra_gain)
+                        extra_gain=extra_gain, sh_rest=sh_rest)
         stream = self._stream(device)
 
         gb, ib, _, _ = self.scratch_bytes(P, W, H, 0)
@@ -868,6 +881,9 @@ class RasterBackend:
         arena, self.grad_arena = self.grad_arena, None
         step, self.fused_step = self.fused_step, None
         raw, self._raw_backward = self._raw_backward, False
+        sh_rest, self.sh_rest = self.sh_rest, None
+        if sh_rest is not None and (step is None or not raw or not step.grad_out_rest):
+            raise RuntimeError("split SH rows: the backward is gs_backward_step's gradients-out form with grad_out_rest")
         if raw and (step is None or P == 0):
             raise RuntimeError("a forward on raw activations must be followed by the fused train-step backward")
         if step is not None and P != 0:
@@ -881,7 +897,7 @@ class RasterBackend:
                 view = self._view(keep, device, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W, scale_modifier,
                                   degree, False, antialiasing, debug)
                 g = self._gauss(keep, device, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, extra,
-                                raw=raw, extra_gain=extra_gain)
+                                raw=raw, extra_gain=extra_gain, sh_rest=sh_rest)
             if extra is not None:
                 dL_dout_extra = torch.zeros((1, H, W), **f32) if dL_dout_extra is None else _prep(dL_dout_extra, device)
             dL_dout_color = _prep(dL_dout_color, device)

@@ -33,8 +33,14 @@ def test_hip_library_exports_every_declared_symbol_and_loads():
     assert os.path.exists(LIB_PATH), "libgsplat_hip.so not built (python __graft_entry__.py)"
     assert exported(LIB_PATH, "gs_") == header_functions()
     api = hip_api()  # dlopen + bind every prototype; no device call
-    assert api.raw("abi_version")() == 6
+    assert api.raw("abi_version")() == 7
     assert b"gfx950" in api.raw("build_info")()
+    # the ctypes mirrors have the layout the library was compiled with
+    from gsplat_amd import capi
+    for which, cls in enumerate((capi.GsView, capi.GsGaussians, capi.GsScratch, capi.GsGrads, capi.GsStepState,
+                                 capi.GsLgdwtParams, capi.GsAdamSeg)):
+        assert api.raw("struct_bytes")(which) == ctypes.sizeof(cls), cls.__name__
+    assert api.raw("struct_bytes")(99) == 0
     # pure host entry: scratch sizing
     out = (ctypes.c_size_t * 3)()
     ws = ctypes.c_size_t(0)

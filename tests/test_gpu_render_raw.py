@@ -31,7 +31,7 @@ def test_raw_row_render_equals_the_drop_in_render(hip, P, W, H, deg):
     for name in ("torch", "raw"):
         pc = DropInModel(sc, dev)
         pkg = render(cam, pc, bg) if name == "torch" else render_raw(cam, pc, _PIPE, bg)
-        assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
+        assert set(pkg) - {"render_unclamped"} == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
         ((pkg["render"] * cot).sum() + (pkg["depth"] * cot_d).sum()).backward()
         vis = pkg["visibility_filter"].squeeze(1)
         stat = torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1)      # gaussian_model.py:472
@@ -64,3 +64,90 @@ def test_drop_in_loop_with_the_raw_row_render_trains(hip):
     pa, pb = loops["torch"].pc, loops["raw"].pc
     assert torch.equal(pa.denom, pb.denom) and torch.equal(pa.max_radii2D, pb.max_radii2D)
     assert float((pa.xyz_gradient_accum - pb.xyz_gradient_accum).abs().max()) <= 1e-3 * float(pa.xyz_gradient_accum.abs().max())
+
+
+def _raw_forward_backward(backend, rs, pc, cot, cot_d, split):
+    """The node of render_raw by hand, with the SH rows either as ONE [P,16,3] array (torch.cat copy) or as the model's two
+    tensors (GsGaussians.shs_rest / GsStepState.grad_out_rest)."""
+    from gsplat_amd.capi import GsStepState
+    dev, P = pc._xyz.device, int(pc._xyz.shape[0])
+    f32 = dict(dtype=torch.float32, device=dev)
+    e = torch.Tensor([])
+    with torch.no_grad():
+        f_dc, f_rest = pc._features_dc.detach(), pc._features_rest.detach()
+        sh = f_dc if split else torch.cat((f_dc, f_rest), dim=1).contiguous()
+        xyz, op, sc, rot = pc._xyz.detach(), pc._opacity.detach(), pc._scaling.detach(), pc._rotation.detach()
+        backend.raw_activations = True
+        backend.sh_rest = f_rest if split else None
+        out = backend.rasterize_gaussians(rs.bg, xyz, e, op, sc, rot, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
+                                          rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+                                          rs.prefiltered, rs.antialiasing, rs.debug)
+        num_rendered, color, radii, geom, binning, img, invdepth = out
+        gx, gop, gsc, grot = (torch.empty((P, n), **f32) for n in (3, 1, 3, 4))
+        gsh = [torch.empty((P, 1, 3), **f32), torch.empty((P, 15, 3), **f32)] if split else [torch.empty((P, 16, 3), **f32)]
+        stats = torch.zeros((3, P), **f32)
+        st = GsStepState()
+        st.xyz, st.features, st.opacity, st.scaling, st.rotation = (t.data_ptr() for t in (xyz, sh, op, sc, rot))
+        for k, t in enumerate((gx, gsh[0], gop, gsc, grot)):
+            st.grad_out[k] = t.data_ptr()
+            st.step[k] = 1
+        if split:
+            st.grad_out_rest = gsh[1].data_ptr()
+        st.beta1, st.beta2, st.eps = 0.9, 0.999, 1e-15
+        st.xyz_gradient_accum, st.denom, st.max_radii2D = (stats[k].data_ptr() for k in range(3))
+        backend._raw_backward = True
+        backend.sh_rest = f_rest if split else None
+        backend.fused_step = st
+        backend.rasterize_gaussians_backward(rs.bg, xyz, radii, e, op, sc, rot, rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
+                                             rs.tanfovx, rs.tanfovy, cot, cot_d, sh, rs.sh_degree, rs.campos, geom, num_rendered,
+                                             binning, img, rs.antialiasing, rs.debug)
+        torch.cuda.synchronize()
+    gsh_all = torch.cat(gsh, dim=1)
+    return dict(color=color, radii=radii, invdepth=invdepth, gx=gx, gsh=gsh_all, gop=gop, gsc=gsc, grot=grot, stats=stats)
+
+
+@pytest.mark.parametrize("P,W,H,deg", [(20000, 480, 320, 3), (3001, 131, 75, 2), (700, 64, 48, 0)])
+def test_split_sh_rows_are_bit_identical_to_the_one_row_layout(hip, P, W, H, deg):
+    """GsGaussians.shs_rest + GsStepState.grad_out_rest (the model's _features_dc / _features_rest read and written in place)
+    against the same call on the concatenated [P,16,3] rows: every output and every gradient bit for bit."""
+    import math
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, _RasterizeGaussians
+    dev = torch.device("cuda")
+    sc = synthetic.trained_like(P, seed=11, sh_degree=deg)
+    cam = camera_to(synthetic.orbit_cameras(W, H)[2], dev)
+    pc = DropInModel(sc, dev)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.tensor([0.2, 0.1, 0.4], device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False,
+        debug=False, antialiasing=False)
+    backend = _RasterizeGaussians._impl.backend
+    g = torch.Generator().manual_seed(4)
+    cot = torch.randn((3, H, W), generator=g).to(dev)
+    cot_d = (torch.randn((1, H, W), generator=g) * 0.2).to(dev)
+    a = _raw_forward_backward(backend, rs, pc, cot, cot_d, split=False)
+    b = _raw_forward_backward(backend, rs, pc, cot, cot_d, split=True)
+    assert int((a["radii"] > 0).sum()) > P // 10
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["gsh"].abs().max()) > 0
+
+
+def test_split_sh_rows_are_refused_where_they_are_not_served(hip):
+    """gs_backward (one dL_dsh array) and the Adam form of gs_backward_step return GS_E_UNSUPPORTED / GS_E_SHAPE; the python
+    backend refuses them before the call."""
+    dev = torch.device("cuda")
+    from diff_gaussian_rasterization import _RasterizeGaussians
+    backend = _RasterizeGaussians._impl.backend
+    sc = synthetic.trained_like(500, seed=1)
+    pc = DropInModel(sc, dev)
+    cam = camera_to(synthetic.orbit_cameras(64, 48)[0], dev)
+    import math
+    e = torch.Tensor([])
+    backend.sh_rest = pc._features_rest.detach()
+    with pytest.raises(RuntimeError, match="raw activations"):
+        backend.rasterize_gaussians(torch.zeros(3, device=dev), pc._xyz.detach(), e, torch.sigmoid(pc._opacity.detach()),
+                                    torch.exp(pc._scaling.detach()), pc._rotation.detach(), 1.0, e, cam.world_view_transform,
+                                    cam.full_proj_transform, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 48, 64,
+                                    pc._features_dc.detach(), 3, cam.camera_center, False, False, False)
+    assert backend.sh_rest is None

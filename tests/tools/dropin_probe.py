@@ -1,5 +1,10 @@
-"""Developer tool: the drop-in loop (gsplat_amd/dropin.py) at C3 size on its own - for rocprofv3 --kernel-trace --stats.
-    python tests/tools/dropin_probe.py [torch|fused|fused_key|fused_key_crit ...] (several modes run one after the other)"""
+"""Developer tool: where an iteration of the drop-in loop (gsplat_amd/dropin.py, the render_raw + FusedAdam + camera_key +
+lgdwt_loss.criterion() variant bench.py reports) spends its time at BASELINE C3.
+   python3 tests/tools/dropin_probe.py [c3] [iters] [cprofile|trace]
+   cd /tmp && rocprofv3 --kernel-trace --stats -d <out> -- python3 <repo>/tests/tools/dropin_probe.py c3 40
+prints wall ms / iteration with and without the reference's `loss.item()` (train.py:224), the host-only enqueue time of an
+iteration (no sync at all), and with `cprofile` the twenty heaviest host functions."""
+import gc
 import os
 import sys
 import time
@@ -10,70 +15,71 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from gsplat_amd import hip_backend  # noqa: E402
-from gsplat_amd._lib import hip_api  # noqa: E402
-from gsplat_amd.capi import read_profile  # noqa: E402
 from gsplat_amd.dropin import DropInLoop  # noqa: E402
 
-modes = sys.argv[1:] or ["torch"]
-n = 20
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
 dev = torch.device("cuda", 0)
-tr, scene, cams, gts = bench.build_workload("c3", dev, 0, 1)
-if os.environ.get("PROBE_TRAINER_FIRST"):
-    tr.depth_limit = "deferred"
-    for k in range(30):
-        tr.step(k)
-    tr.sync()
-if os.environ.get("PROBE_GRAPH"):       # ... and replayed from hipGraphs, as bench.py's launch trial does
-    from gsplat_amd.trainer import GraphedStep
-    gs_ = GraphedStep(tr)
-    for k in range(60):
-        gs_.step(k)
-    gs_.sync()
-if os.environ.get("PROBE_REFLISTS"):    # ... and the reference-lists leg of bench.py (tile_cull off for a dozen steps, then back)
-    be0 = hip_backend()
-    old = be0.tile_cull
-    be0.tile_cull = False
-    for k in range(12):
-        tr.step(100 + k)
-    torch.cuda.synchronize()
-    be0.tile_cull = old
-    for k in range(2):
-        tr.step(120 + k)
-    tr.sync()
-    print("after the reference-lists leg: capacity hints", be0._capacity_hint, be0._capacity_hint_limited, flush=True)
-if not os.environ.get("PROBE_KEEP_TRAINER"):
-    del tr
-be, api = hip_backend(), hip_api()
-for mode in modes:
-    loop = DropInLoop(scene, cams, gts, dev, dwt=True, patch=True, optimizer="torch" if mode == "torch" else "fused",
-                      use_camera_key="key" in mode, fused_criterion="crit" in mode)
-    for j in range(len(cams) + 2):
-        loop.iteration(j % len(cams))
-    torch.cuda.synchronize()
-    d0 = dict(be.depth_limit_stats)
-    prof_ = None
-    if os.environ.get("PROBE_CPROFILE"):
-        import cProfile
-        prof_ = cProfile.Profile()
-        prof_.enable()
-    t0 = time.perf_counter()
-    for j in range(n):
-        loop.iteration((j + 2) % len(cams))
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
-    if prof_ is not None:
-        import pstats
-        prof_.disable()
-        pstats.Stats(prof_).sort_stats("tottime").print_stats(12)
-    api.call("profile_reset")
-    api.call("profile_enable", 1)
-    for j in range(6):
-        loop.iteration((j + 2) % len(cams))
-    torch.cuda.synchronize()
-    api.call("profile_enable", 0)
-    st = {k: round(v[0] / v[1], 4) for k, v in read_profile(api).items()}
-    print("%s: %.3f ms/step" % (mode, ms), "limits used/failed", be.depth_limit_stats["used"] - d0["used"],
-          be.depth_limit_stats["failed"] - d0["failed"], "capacity hints", be._capacity_hint, be._capacity_hint_limited)
-    print("   stages", st, "sum %.3f" % sum(st.values()))
-    del loop
+tr, scene, cams, gts = bench.build_workload(cfg, dev, 0, 1)
+del tr
+loop = DropInLoop(scene, cams, gts, dev, dwt=True, patch=True, optimizer="fused", use_camera_key=True, fused_criterion=True,
+                  raw_render=True)
+n = len(cams)
+for j in range(n + 2):
+    loop.iteration(j % n)
+torch.cuda.synchronize()
+gc.collect()
+gc.disable()
+prof = None
+if mode == "cprofile":
+    import cProfile
+    prof = cProfile.Profile()
+    prof.enable()
+t0 = time.perf_counter()
+for j in range(iters):
+    loop.iteration((j + 2) % n)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / iters
+if prof is not None:
+    import io
+    import pstats
+    prof.disable()
+    buf = io.StringIO()
+    pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(25)
+    print(buf.getvalue())
+print("drop-in raw loop: %.3f ms / iteration (loss.item() every iteration)" % (dt * 1e3))
+
+# the same without the host sync: the loss stays on the device (what `--quiet` style loops could do)
+orig_finish = loop._finish
+
+
+class _NoItem:
+    def item(self):
+        return 0.0
+
+
+def finish_no_item(loss, vsp, vis, radii):
+    pc = loop.pc
+    loss.backward()
+    with torch.no_grad():
+        vf = vis.squeeze(1)
+        pc.max_radii2D[vf] = torch.max(pc.max_radii2D[vf], radii[vf].to(torch.float32))
+        pc.add_densification_stats(vsp, vf)
+        loop.optimizer.step()
+        loop.optimizer.zero_grad(set_to_none=True)
+    return 0.0
+
+
+loop._finish = finish_no_item
+for j in range(4):
+    loop.iteration(j % n)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for j in range(iters):
+    loop.iteration((j + 2) % n)
+t_host = (time.perf_counter() - t0) / iters
+torch.cuda.synchronize()
+dt2 = (time.perf_counter() - t0) / iters
+print("without loss.item(): %.3f ms / iteration; host enqueue alone %.3f ms" % (dt2 * 1e3, t_host * 1e3))
+gc.enable()
