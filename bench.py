@@ -634,7 +634,9 @@ def main():
     # product's defaults (no environment switches): what a maintainer who follows INTEGRATION.md section 1 gets
     # (gsplat_amd/dropin.py).  Then the two one-line additions INTEGRATION.md section 4 offers: the optimizer as one
     # kernel per tensor (gsplat_amd.optim.FusedAdam, same constructor) and a camera_key on the rasterizer (depth-limited
-    # lists on a camera's later visits, verified by the forward).
+    # lists on a camera's later visits, verified by the forward).  Last: section 5's `gsplat_amd.render_raw.render` in place of
+    # the reference's render() (the model's six raw tensors go to the library, SH rows read where the model keeps them) with
+    # the criterion as one node on its un-clamped image (criterion.fused_call).  loss.item() sits where train.py:224 has it.
     drop_in = None
     if world == 1 and args.config not in NIR_CONFIGS and os.environ.get("GS_BENCH_DROP_IN", "1") != "0":
         from gsplat_amd.dropin import DropInLoop
@@ -660,23 +662,11 @@ def main():
             #  tens of milliseconds and used to land in one variant or another: 6.5-8.5 ms/step instead of 3.1)
             gc.collect()
             gc.disable()
-            prof_ = None
-            if os.environ.get("GS_BENCH_DROP_IN_PROFILE"):   # developer switch: where the host time of an iteration goes
-                import cProfile
-                prof_ = cProfile.Profile()
-                prof_.enable()
             t1 = time.perf_counter()
             for j in range(n_di):
                 loop.iteration((j + 2) % len(cams))
             torch.cuda.synchronize()
             gc.enable()
-            if prof_ is not None:
-                import io
-                import pstats
-                prof_.disable()
-                buf_ = io.StringIO()
-                pstats.Stats(prof_, stream=buf_).sort_stats("tottime").print_stats(10)
-                log(label + "\n" + buf_.getvalue())
             drop_in[label] = {"ms_per_step": (time.perf_counter() - t1) / n_di * 1e3, "steps": n_di,
                               "depth_limited_views": bed.depth_limit_stats["used"] - dd0["used"],
                               "fallbacks": bed.depth_limit_stats["failed"] - dd0["failed"]}

@@ -166,10 +166,11 @@ class DropInLoop:
         pc = self.pc
         loss.backward()
         with torch.no_grad():
-            # train.py:266-268
+            value = loss.item()     # train.py:224, the progress bar: the host waits for the backward HERE, before the statistics
+            # train.py:266-268      # and the optimizer are enqueued - they run while the host sets up the next iteration
             vf = vis.squeeze(1)
             pc.max_radii2D[vf] = torch.max(pc.max_radii2D[vf], radii[vf].to(torch.float32))
             pc.add_densification_stats(vsp, vf)
-            self.optimizer.step()
+            self.optimizer.step()   # train.py:284-285
             self.optimizer.zero_grad(set_to_none=True)
-        return loss.item()
+        return value

@@ -50,36 +50,35 @@ if prof is not None:
     print(buf.getvalue())
 print("drop-in raw loop: %.3f ms / iteration (loss.item() every iteration)" % (dt * 1e3))
 
-# the same without the host sync: the loss stays on the device (what `--quiet` style loops could do)
-orig_finish = loop._finish
+# A/B in ONE process (boxes differ by 5-10 %): where the loss.item() of train.py:224 sits, or no host read of the loss at all
+def finish(order):
+    def f(loss, vsp, vis, radii):
+        pc = loop.pc
+        loss.backward()
+        with torch.no_grad():
+            value = loss.item() if order == "after_backward" else 0.0
+            vf = vis.squeeze(1)
+            pc.max_radii2D[vf] = torch.max(pc.max_radii2D[vf], radii[vf].to(torch.float32))
+            pc.add_densification_stats(vsp, vf)
+            loop.optimizer.step()
+            loop.optimizer.zero_grad(set_to_none=True)
+            if order == "last":
+                value = loss.item()
+        return value
+    return f
 
 
-class _NoItem:
-    def item(self):
-        return 0.0
-
-
-def finish_no_item(loss, vsp, vis, radii):
-    pc = loop.pc
-    loss.backward()
-    with torch.no_grad():
-        vf = vis.squeeze(1)
-        pc.max_radii2D[vf] = torch.max(pc.max_radii2D[vf], radii[vf].to(torch.float32))
-        pc.add_densification_stats(vsp, vf)
-        loop.optimizer.step()
-        loop.optimizer.zero_grad(set_to_none=True)
-    return 0.0
-
-
-loop._finish = finish_no_item
-for j in range(4):
-    loop.iteration(j % n)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for j in range(iters):
-    loop.iteration((j + 2) % n)
-t_host = (time.perf_counter() - t0) / iters
-torch.cuda.synchronize()
-dt2 = (time.perf_counter() - t0) / iters
-print("without loss.item(): %.3f ms / iteration; host enqueue alone %.3f ms" % (dt2 * 1e3, t_host * 1e3))
+for rep in range(2):
+    for order in ("after_backward", "last", "none"):
+        loop._finish = finish(order)
+        for j in range(4):
+            loop.iteration(j % n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(iters):
+            loop.iteration((j + 2) % n)
+        t_host = (time.perf_counter() - t0) / iters
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / iters
+        print("loss.item() %-15s %.3f ms / iteration (host side alone %.3f ms)" % (order, dt2 * 1e3, t_host * 1e3))
 gc.enable()
