@@ -515,6 +515,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    # the exchange brackets of the TIMED steps only (the stage-timer passes and the other legs below step the model too)
+    timed_exchange_events = []
+    if world > 1:
+        timed_exchange_events, tr.exchange_events = list(tr.exchange_events or []), None
     dl1 = dict(_hb0().depth_limit_stats)
     R_timed = int(_hb0()._pinned[0]) if _hb0()._pinned is not None else 0
     # how many 256-row blocks of the model are dormant (all Adam moments +0: FlatAdam.dormant_flags) after the timed region
@@ -803,9 +807,8 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # per rank: the step's wall time, of which exchange (collectives + optimizer, as the compute stream sees them)
-        ev = getattr(tr, "exchange_events", None) or []
-        tr.exchange_events = None
-        ex_ms = sum(a.elapsed_time(b) for a, b in ev[-args.steps:]) / max(1, len(ev[-args.steps:]))
+        ev = timed_exchange_events
+        ex_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
         mine = torch.tensor([dt / args.steps * 1e3, ex_ms], dtype=torch.float64, device=device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
