@@ -72,7 +72,7 @@ class RasterBackend:
         self._region_key = None    # (P, W, H, limited) of the forward being served (see _region_off); None in the backward
         self._vm_ids = {}
         self.camera_cache_stats = dict(hits=0, misses=0, hashed=0)
-        self.order_hint_on = os.environ.get("GS_FWD_ORDER_HINT", "1") != "0"
+        self.order_hint_on = True   # (False: image order - outputs do not depend on it, see GsScratch.tile_order_hint)
         # depth-limited emission (GsScratch.tile_depth_limit): on the second and later visits of a camera, (tile, Gaussian)
         # pairs behind the depth at which that tile's blend stopped last time are not emitted.  Checked, not assumed: the
         # forward flags lists that were cut too short and the view is rendered again without limits - which the host
@@ -412,14 +412,14 @@ class RasterBackend:
     KEYED_LIMITS = os.environ.get("GS_KEYED_LIMITS", "1") != "0"
     # region-binned forwards whose verdict is collected later (deferred eager steps, replayed graphs): the status block is
     # written into the pinned host block by the forward's own last kernel (GsScratch.status_host) instead of by a copy
-    # command behind it - one launch less on the stream.  GS_STATUS_IN_RENDER=0: gs_forward_status as before.
-    STATUS_IN_RENDER = os.environ.get("GS_STATUS_IN_RENDER", "1") != "0"
+    # command behind it - one launch less on the stream.  False: gs_forward_status as before.
+    STATUS_IN_RENDER = True
     # Train step (a fused step is armed): the forward's last kernel (tile_order: the backward's launch order, the camera's next
     # hints and depth bounds, the status block) is issued on the SIDE stream - nothing before the backward blend needs it, so
     # it runs beside the criterion's first kernel instead of in front of it (GsScratch.defer_tile_order +
-    # gs_forward_tile_order); the backward waits for it.  GS_SPLIT_TILE_ORDER=0: in line, as the plain forward does.
-    SPLIT_TILE_ORDER = os.environ.get("GS_SPLIT_TILE_ORDER", "1") != "0"
-    REUSE_BUILT = os.environ.get("GS_REUSE_BUILT", "1") != "0"   # the forward's GsView / GsGaussians structs serve its backward too
+    # gs_forward_tile_order); the backward waits for it.  False: in line, as the plain forward does.
+    SPLIT_TILE_ORDER = True
+    REUSE_BUILT = True   # the forward's GsView / GsGaussians structs serve its backward too
 
     def _side_stream(self, device):
         side = self._side_streams.get(device.index)
@@ -438,7 +438,7 @@ class RasterBackend:
     # loss_backward 1.024 (the stream starts 20 us earlier, under dwt2_l1_bwd too, and ssim_bwd takes 103 us beside it),
     # raster_backward 1.012 replayed / 1.15 eager (no head start: the blend's 8 160 one-wave workgroups are dealt out first
     # and the stream's workgroups trickle in behind them, phase 2 waits 0.17 ms for it).
-    UNINST_AT = os.environ.get("GS_UNINST_AT", "ssim_backward")
+    UNINST_AT = "ssim_backward"
 
     def rasterize_gaussians(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                              cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
