@@ -18,8 +18,10 @@ Everything else of train.py stays: `viewspace_point_tensor.grad` is filled so th
 computes the reference's statistic - the node returns (|dL/dmean2D|, 0, 0) per Gaussian, whose norm over the first two
 columns IS |dL/dmean2D| (sqrt(x * x) = |x| exactly in binary floating point).
 
-Not served (the reference's python fall-backs; the plain render() of the drop-in packages covers them): compute_cov3D_python,
-convert_SHs_python, override_color, separate_sh."""
+`separate_sh` (gaussian_renderer/__init__.py:82-100: `dc = pc.get_features_dc, shs = pc.get_features_rest` handed to the accelerated
+rasterizer as two tensors; train.py passes SPARSE_ADAM_AVAILABLE for it) is accepted with either value: the two tensors are what
+the kernels read here anyway.  Not served (the reference's python fall-backs; the plain render() of the drop-in packages covers
+them): compute_cov3D_python, convert_SHs_python, override_color."""
 import math
 
 import torch
@@ -96,8 +98,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     """gaussian_renderer/__init__.py:18-128.  camera_key (optional, not in the reference): a stable identity of the camera - the
     backend then keeps its tile order and verified depth limits between visits."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, _RasterizeGaussians
-    if separate_sh or override_color is not None or getattr(pipe, "compute_cov3D_python", False) or \
-            getattr(pipe, "convert_SHs_python", False):
+    if override_color is not None or getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
         raise NotImplementedError("render_raw serves the rasterizer's own SH / covariance path only "
                                   "(use the drop-in GaussianRasterizer for the python fall-backs)")
     backend = getattr(_RasterizeGaussians._impl, "backend", None)
