@@ -204,9 +204,9 @@ class FlatAdam:
         stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
         # grads: a tensor holding the gradients of elements [lo, hi) (default: that slice of the flat gradient buffer)
         gptr = m.flat_grad.data_ptr() + 4 * lo if grads is None else grads.data_ptr()
-        if self.sparse:
-            if row_mask is None:
-                raise RuntimeError("sparse_adam: the step needs the view's visibility (row_mask)")
+        if self.sparse and row_mask is None:
+            raise RuntimeError("sparse_adam: the step needs the view's visibility (row_mask)")
+        if row_mask is not None:   # (sparse_adam, or one part of a step that is applied in two parts: the sparse exchange)
             self.api.call("adam_step_masked", m.flat.data_ptr() + 4 * lo, gptr,
                           self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo, segs, nseg,
                           self.betas[0], self.betas[1], self.eps, self.t, None if gate is None else gate.data_ptr(),
@@ -447,6 +447,8 @@ class GaussianModelLite:
         # Trainer._begin_union), with its inclusive prefix - 1 (the packed row of every union member)
         self.union_mask = torch.zeros((P,), dtype=torch.uint8, device=self.device)
         self.union_pos = torch.zeros((P,), dtype=torch.int32, device=self.device)
+        # the union as the row masks of gs_adam_step_masked (float, > 0 = stepped): members / everybody else
+        self.union_rows_f = torch.zeros((2, P), dtype=torch.float32, device=self.device)
         self.params = {}
         off = 0
         shapes = self._shapes(P)
@@ -1394,6 +1396,8 @@ class Trainer:
             m.denom += (m.stat_delta[1] * ok).unsqueeze(1)
 
     # ---- the visibility-sparse exchange
+    SPLIT_SPARSE_ADAM = True   # the optimizer of the sparse exchange in two parts, the first under the collective (False: one pass)
+
     def _begin_union(self, mask_src=None):
         """Start the exchange of the row masks NOW: `union_mask` <- this rank's mask (mask_src, or what the forward's geometry
         state says: Gaussians with instances), all-reduced (MAX) over the ranks, then its prefix (the packed row of every
@@ -1412,6 +1416,8 @@ class Trainer:
             dist.all_reduce(m.union_mask, op=dist.ReduceOp.MAX)
             torch.cumsum(m.union_mask, dim=0, dtype=torch.int32, out=m.union_pos)
             m.union_pos.sub_(1)
+            m.union_rows_f[0].copy_(m.union_mask)             # (uint8 -> float: 1.0 for the members)
+            m.union_rows_f[1].copy_(m.union_mask == 0)
         if dev.type == "cuda":
             main = torch.cuda.current_stream(dev)
             side = getattr(self, "_union_stream", None)
@@ -1466,15 +1472,30 @@ class Trainer:
             stream = C.c_void_p(torch.cuda.current_stream(m.flat.device).cuda_stream) if m.flat.is_cuda else None
             opt.api.call("rows_pack", m.flat_grad.data_ptr(), P, len(m.fields), widths, m.union_mask.data_ptr(),
                          m.union_pos.data_ptr(), K, buf.data_ptr(), stream)
-            dist.all_reduce(buf[:K * W], op=dist.ReduceOp.SUM)
-            opt.api.call("rows_unpack", m.flat_grad.data_ptr(), P, len(m.fields), widths, m.union_mask.data_ptr(),
-                         m.union_pos.data_ptr(), K, buf.data_ptr(), stream)
+            wrows = dist.all_reduce(buf[:K * W], op=dist.ReduceOp.SUM, async_op=True)
         self.last_exchange = dict(union_rows=K, rows=P, sparse_bytes=4 * K * W + P + 4 * int(m.stat_tail.numel()),
                                   dense_bytes=4 * (n_grad + int(m.stat_tail.numel())))
         if gate is not None or opt.sparse:
             ws.wait()  # the gate is the reduced flag; sparse_adam: the summed visibility is the rows to step
+        # The optimizer in two parts.  Rows OUTSIDE the union need nothing from the links: their summed gradient is zero on
+        # every rank, so their (zero-gradient, gated) update runs NOW, on the compute stream, while the union's rows are on the
+        # links - more than half of the dense Adam pass hides under the collective.  The union's rows follow when their sums
+        # have been scattered back.  Every row is stepped exactly once with the same bias corrections: the same bits as one
+        # dense pass (tests/test_dp_gloo.py compares with the all-reduce form).  sparse_adam keeps its single masked pass (its
+        # rows - visible in SOME rank's view - are known from the summed statistics only).
+        split = optimizer_step and not opt.sparse and self.SPLIT_SPARSE_ADAM
         if optimizer_step:
             opt.begin_step(skip)
+        if split:
+            opt.step_range(0, n_grad, skip, gate=gate, row_mask=m.union_rows_f[1])
+        if K:
+            wrows.wait()
+            opt.api.call("rows_unpack", m.flat_grad.data_ptr(), P, len(m.fields), widths, m.union_mask.data_ptr(),
+                         m.union_pos.data_ptr(), K, buf.data_ptr(), stream)
+        if split:
+            if K:
+                opt.step_range(0, n_grad, skip, gate=gate, row_mask=m.union_rows_f[0])
+        elif optimizer_step:
             opt.step_range(0, n_grad, skip, gate=gate, row_mask=m.stat_delta[1] if opt.sparse else None)
         ws.wait()
         wmax.wait()

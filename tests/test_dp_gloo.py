@@ -230,3 +230,69 @@ def test_sparse_exchange_through_densification(world):
         if b["sizes"] == a["sizes"]:
             d = (a["flat"] - b["flat"]).double()
             assert float(d.pow(2).mean().sqrt()) <= 1e-3 * float(a["flat"].double().pow(2).mean().sqrt())
+
+
+def _worker_partial_union(rank, world, port, outdir, sparse, split):
+    """As _worker, on a scene a third of whose Gaussians no camera sees (100 units above the orbit): the union of the ranks'
+    row masks is a proper subset, so the two parts of the sparse exchange's optimizer both have rows to step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    from test_trainer_cpu import make_trainer
+    orc = oracle_lib.get()
+    tr = make_trainer(orc, P=400, W=96, H=64, world_size=world, rank=rank)
+    tr.sharded_optimizer, tr.sparse_exchange, tr.SPLIT_SPARSE_ADAM = False, sparse, split
+    with torch.no_grad():
+        tr.model.params["xyz"][::3, 2] += 100.0
+        # every row carries momentum from "earlier steps": the zero-gradient update of an unseen row then changes its bits
+        g = torch.Generator().manual_seed(7)
+        opt = tr.model.optimizer
+        opt.exp_avg.copy_(torch.randn(opt.exp_avg.shape, generator=g) * 1e-3)
+        opt.exp_avg_sq.copy_(torch.rand(opt.exp_avg_sq.shape, generator=g) * 1e-6 + 1e-9)
+        opt.t = 5
+        for name in opt.seg_steps:
+            opt.seg_steps[name] = 5
+    xyz_start = tr.model.params["xyz"].detach().clone()
+    unions = []
+    for k in range(3):
+        tr.step(k)
+        unions.append(None if tr.last_exchange is None else tr.last_exchange["union_rows"])
+    m = tr.model
+    torch.save(dict(flat=m.flat.clone(), grad=m.flat_grad.clone(), m1=m.optimizer.exp_avg.clone(),
+                    m2=m.optimizer.exp_avg_sq.clone(), accum=m.xyz_gradient_accum.clone(), denom=m.denom.clone(),
+                    maxr=m.max_radii2D.clone(), unions=unions, t=m.optimizer.t, seg_steps=dict(m.optimizer.seg_steps),
+                    xyz_start=xyz_start, xyz_now=m.params["xyz"].detach().clone(), union_mask=m.union_mask.clone()),
+               os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sparse_exchange_steps_the_rows_outside_the_union_under_the_collective():
+    """Trainer._exchange_and_step_sparse applies Adam in two parts - the rows outside the union while the union's rows are on the
+    links, the union's rows when their sums are back - and must leave the bits of ONE dense pass: against the dense all-reduce
+    form and against the sparse exchange with a single pass (SPLIT_SPARSE_ADAM = False), with a union that is a proper subset
+    (the rows outside it still move: their moments decay, their parameters follow the old momentum)."""
+    world = 2
+    runs = {}
+    for key, (sparse, split) in dict(dense=(False, True), one_pass=(True, False), two_parts=(True, True)).items():
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker_partial_union, args=(world, _free_port(), d, sparse, split), nprocs=world, join=True)
+            runs[key] = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(world)]
+    ref = runs["dense"][0]
+    assert ref["t"] == 5 + 3
+    for key in ("one_pass", "two_parts"):
+        for r in range(world):
+            got = runs[key][r]
+            assert all(0 < u < 400 for u in got["unions"]), got["unions"]
+            assert got["t"] == ref["t"] and got["seg_steps"] == ref["seg_steps"]
+            for k in ("flat", "grad", "m1", "m2", "accum", "denom", "maxr"):
+                assert torch.equal(got[k], ref[k]), (key, r, k)
+    # the rows nobody sees were stepped too (their momentum moved them), by the part that runs under the collective
+    got = runs["two_parts"][0]
+    unseen = got["union_mask"] == 0
+    assert int(unseen.sum()) >= 400 // 3
+    assert bool((got["xyz_now"][unseen] != got["xyz_start"][unseen]).any(dim=1).all())
