@@ -824,7 +824,7 @@ def main():
                    # the forward and is not in it), slowest rank
                    "exchange_exposed_ms": worst,
                    "exchange_form": ("sparse (union of the ranks' instanced Gaussians: mask all-reduce on a side stream behind the "
-                                     "forward, one pack kernel, all-reduce of the union's rows, one unpack kernel, dense gated Adam)" if lx else
+                                     "forward, one pack kernel, all-reduce of the union's rows, one unpack kernel; gated Adam in two parts - the rows outside the union under the collective, the union's rows behind it)" if lx else
                                      ("sharded (reduce-scatter, Adam on 1/N, all-gather)" if tr.sharded_optimizer else
                                       "chunked all-reduce, Adam behind the chunks")),
                    "exchange_trial": exchange_trial,
