@@ -45,6 +45,8 @@ CONFIGS = {
     "c2": (500_000, 800, 800, True, False, "BASELINE configs[1]: 500k Gaussians, 800x800, global DWT"),
     "c1": (10_000, 400, 400, False, False, "BASELINE configs[0]: 10k Gaussians, 400x400, DWT off"),
     "tiny": (2_000, 256, 160, True, True, "plumbing check"),
+    # not a BASELINE config: a size check of the buffers and index arithmetic (tests/tools/step_probe.py x4k)
+    "x4k": (6_000_000, 3840, 2160, True, True, "stress: 6M Gaussians at 3840x2160"),
     # multispectral step (train_nir.py: L1 + SSIM on RGB and on the NIR image, no DWT terms): ONE fused 4-channel pass
     # as BASELINE.json words it: the 4-channel pass with the LGDWT criterion (global + patch DWT) on the RGB image
     "c5": (1_000_000, 1920, 1080, True, True, "BASELINE configs[4]: RGB+NIR 4-channel render, 1M Gaussians, 1080p, "
