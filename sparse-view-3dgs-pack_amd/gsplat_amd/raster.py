@@ -530,13 +530,14 @@ class RasterBackend:
         radii = alloc((P,), dtype=torch.int32, device=device)
         out_extra = None if (extra is None and not fsgs) else alloc((1, H, W), **f32)
         tail = () if out_extra is None else (out_extra,)
+        # (the one-shot requests of this forward are taken here, whatever follows: an empty model must not leave them armed)
+        raw, self.raw_activations = self.raw_activations, False
+        self._raw_backward = raw and P != 0
+        sh_rest, self.sh_rest = self.sh_rest, None
         if P == 0:  # rasterize_points.cu:88
+            self.camera_key, self.camera_key_limits, self.depth_limit_request = None, False, None
             e = torch.empty((0,), **u8)
             return (0, out_color, radii, e, e.clone(), e.clone(), out_invdepth) + tail
-
-        raw, self.raw_activations = self.raw_activations, False
-        self._raw_backward = raw
-        sh_rest, self.sh_rest = self.sh_rest, None
         if sh_rest is not None and not raw:
             raise RuntimeError("split SH rows are served with raw activations only (gsplat_amd.render_raw)")
         if raw and fsgs:

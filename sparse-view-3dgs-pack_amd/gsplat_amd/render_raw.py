@@ -67,6 +67,9 @@ class _RawRender(torch.autograd.Function):
         rs, backend = ctx.rs, ctx.backend
         dev, P = xyz.device, int(xyz.shape[0])
         f32 = dict(dtype=torch.float32, device=dev)
+        if P == 0:   # an empty model (rasterize_points.cu:88): nothing was rendered, every gradient is empty
+            z = lambda *shape: torch.zeros(shape, **f32)
+            return z(0, 3), z(0, 1, 3), z(0, 15, 3), z(0, 1), z(0, 3), z(0, 4), z(0, 3), None, None, None
         if g_color is None:
             g_color = torch.zeros((3, rs.image_height, rs.image_width), **f32)
         gx, gdc, grest = torch.empty((P, 3), **f32), torch.empty((P, 1, 3), **f32), torch.empty((P, 15, 3), **f32)

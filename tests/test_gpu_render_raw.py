@@ -151,3 +151,34 @@ def test_split_sh_rows_are_refused_where_they_are_not_served(hip):
                                     cam.full_proj_transform, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 48, 64,
                                     pc._features_dc.detach(), 3, cam.camera_center, False, False, False)
     assert backend.sh_rest is None
+
+
+def test_an_empty_model_renders_nothing_and_leaves_no_request_armed(hip):
+    """P = 0 (rasterize_points.cu:88: the reference returns zero images and empty buffers): render_raw returns the same, its
+    backward returns empty gradients, and the one-shot requests it made of the backend (raw activations, split SH rows, camera
+    key) are gone - the next, ordinary render is not affected."""
+    from gsplat_amd.render_raw import render as render_raw
+    from diff_gaussian_rasterization import _RasterizeGaussians
+    dev = torch.device("cuda")
+    cam = camera_to(synthetic.orbit_cameras(96, 64)[0], dev)
+    bg = torch.tensor([0.5, 0.25, 0.125], device=dev)
+
+    class Empty:
+        active_sh_degree = 3
+
+    pc = Empty()
+    for name, shape in (("_xyz", (0, 3)), ("_features_dc", (0, 1, 3)), ("_features_rest", (0, 15, 3)), ("_opacity", (0, 1)),
+                        ("_scaling", (0, 3)), ("_rotation", (0, 4))):
+        setattr(pc, name, torch.nn.Parameter(torch.zeros(shape, device=dev)))
+    pkg = render_raw(cam, pc, _PIPE, bg, camera_key="empty")
+    assert pkg["render"].shape == (3, 64, 96) and float(pkg["render"].abs().max()) == 0.0
+    assert pkg["radii"].numel() == 0 and pkg["visibility_filter"].numel() == 0
+    (pkg["render"].sum() + pkg["depth"].sum()).backward()
+    assert pc._xyz.grad is None or pc._xyz.grad.numel() == 0
+    backend = _RasterizeGaussians._impl.backend
+    assert not backend.raw_activations and backend.sh_rest is None and backend.camera_key is None and not backend._raw_backward
+    # an ordinary render right behind it: activated values, one SH array - must not be read as raw rows
+    full = DropInModel(synthetic.trained_like(2000, seed=2), dev)
+    a = render(cam, full, bg)["render"]
+    b = render(cam, full, bg)["render"]
+    assert torch.equal(a, b) and float(a.max()) > 0
