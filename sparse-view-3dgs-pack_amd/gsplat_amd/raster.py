@@ -111,6 +111,7 @@ class RasterBackend:
         # (GsGaussians.raw_activations): no activation kernel, no activated copies
         self.raw_activations = False
         self._raw_backward = False
+        self._raw_geom = None       # geomBuffer of the last forward on raw rows (whose backward the flag above announces)
         # one-shot, set before a forward / a fused backward on raw rows: the model's _features_rest [P,M-1,3]; `sh` is then
         # _features_dc [P,1,3] (GsGaussians.shs_rest: the kernels read the split rows, no torch.cat)
         self.sh_rest = None
@@ -595,6 +596,7 @@ class RasterBackend:
 
         gb, ib, _, _ = self.scratch_bytes(P, W, H, 0)
         geom = torch.empty((gb,), **u8)
+        self._raw_geom = geom.data_ptr() if raw else None
         img = torch.empty((ib,), **u8)
         empty = torch.empty((0,), **u8)
         # (the train step's side launch and its backward describe the same view and the same Gaussians: they take these
@@ -882,6 +884,10 @@ class RasterBackend:
         arena, self.grad_arena = self.grad_arena, None
         step, self.fused_step = self.fused_step, None
         raw, self._raw_backward = self._raw_backward, False
+        if raw and step is None and self._raw_geom is not None and self._raw_geom != geomBuffer.data_ptr():
+            # this backward belongs to an EARLIER forward on activated values; the raw forward in between (an evaluation render
+            # under no_grad, say) has no backward of its own
+            raw = False
         sh_rest, self.sh_rest = self.sh_rest, None
         if sh_rest is not None and (step is None or not raw or not step.grad_out_rest):
             raise RuntimeError("split SH rows: the backward is gs_backward_step's gradients-out form with grad_out_rest")

@@ -182,3 +182,25 @@ def test_an_empty_model_renders_nothing_and_leaves_no_request_armed(hip):
     a = render(cam, full, bg)["render"]
     b = render(cam, full, bg)["render"]
     assert torch.equal(a, b) and float(a.max()) > 0
+
+
+def test_an_evaluation_render_on_raw_rows_between_a_forward_and_its_backward(hip):
+    """train.py renders test views under no_grad while a training graph may still be alive: a raw-row forward without a backward
+    of its own must not be taken for the forward of the NEXT backward the backend sees."""
+    from gsplat_amd.render_raw import render as render_raw
+    dev = torch.device("cuda")
+    sc = synthetic.trained_like(5000, seed=4)
+    cams = [camera_to(c, dev) for c in synthetic.orbit_cameras(160, 120)[:2]]
+    bg = torch.zeros(3, device=dev)
+    grads = []
+    for evaluate in (False, True):
+        pc = DropInModel(sc, dev)
+        pkg = render(cams[0], pc, bg)                      # the drop-in render on activated values: a training forward
+        if evaluate:
+            with torch.no_grad():
+                img = render_raw(cams[1], pc, _PIPE, bg)["render"]
+            assert float(img.max()) > 0
+        pkg["render"].square().sum().backward()
+        grads.append({k: v.grad.clone() for k, v in leaves(pc).items()})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
