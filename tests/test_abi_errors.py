@@ -109,6 +109,27 @@ def run_table(api, device):
     assert f("lgdwt_combine_p")(None, None, 0, nine.data_ptr(), C.byref(lp), nine.data_ptr(), st) == E_NULL
     assert f("lgdwt_combine_p")(nine.data_ptr(), None, 5, nine.data_ptr(), C.byref(lp), nine.data_ptr(), st) == E_SHAPE
     assert f("lgdwt_combine_p")(nine.data_ptr(), None, -1, nine.data_ptr(), C.byref(lp), nine.data_ptr(), st) == E_SHAPE
+    # round-5 entries: depth regularisation, masked Adam, the sparse exchange's pack / unpack, the layout query
+    one = torch.rand(1, 32, 32, device=device)
+    part = torch.zeros(int(f("depth_l1_partials_count")(1024)), device=device)
+    assert f("depth_l1_partials_count")(0) == 0 and part.numel() >= 1
+    assert f("depth_l1")(None, one.data_ptr(), None, 1024, part.data_ptr(), C.c_float(1.0), None, None, st) == E_NULL
+    assert f("depth_l1")(one.data_ptr(), None, None, 1024, part.data_ptr(), C.c_float(1.0), None, None, st) == E_NULL
+    assert f("depth_l1")(one.data_ptr(), one.data_ptr(), None, 1024, None, C.c_float(1.0), None, None, st) == E_NULL   # no output asked for
+    assert f("depth_l1")(one.data_ptr(), one.data_ptr(), None, 0, part.data_ptr(), C.c_float(1.0), None, None, st) == 0
+    am = f("adam_step_masked")
+    assert am(None, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 16, seg, 1, 0.9, 0.999, 1e-15, 1, None, buf.data_ptr(), st) == E_NULL
+    assert am(buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 16, seg, 9, 0.9, 0.999, 1e-15, 1, None, buf.data_ptr(), st) == E_SHAPE
+    assert am(buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 16, seg, 1, 0.9, 0.999, 1e-15, 0, None, buf.data_ptr(), st) == E_SHAPE
+    widths = (C.c_int32 * 2)(3, 1)
+    mask = torch.ones(4, dtype=torch.uint8, device=device)
+    pos = torch.arange(4, dtype=torch.int32, device=device)
+    for name in ("rows_pack", "rows_unpack"):
+        assert f(name)(buf.data_ptr(), -1, 2, widths, mask.data_ptr(), pos.data_ptr(), 4, buf.data_ptr(), st) == E_SHAPE
+        assert f(name)(buf.data_ptr(), 4, 9, widths, mask.data_ptr(), pos.data_ptr(), 4, buf.data_ptr(), st) == E_SHAPE
+        assert f(name)(buf.data_ptr(), 4, 2, widths, None, pos.data_ptr(), 4, buf.data_ptr(), st) == E_NULL
+        assert f(name)(buf.data_ptr(), 4, 2, widths, mask.data_ptr(), pos.data_ptr(), 0, buf.data_ptr(), st) == 0      # empty union
+    assert f("struct_bytes")(1) == C.sizeof(GsGaussians) and f("struct_bytes")(-1) == 0 and f("struct_bytes")(7) == 0
     return t, v, g, s, bufs, wsb
 
 
@@ -129,4 +150,15 @@ def test_hip_argument_errors(hip):
     assert api.raw("forward_render_fsgs")(C.byref(v2), C.byref(g), C.byref(s), img.data_ptr(), one.data_ptr(), one.data_ptr(), None) == E_UNSUPPORTED
     assert api.raw("forward_render_fsgs")(C.byref(v), C.byref(g), C.byref(s), img.data_ptr(), None, one.data_ptr(), None) == E_NULL
     assert api.raw("forward_render_x")(C.byref(v), C.byref(g), C.byref(s), img.data_ptr(), None, one.data_ptr(), None) == E_NULL
+    # the model's split SH rows (GsGaussians.shs_rest): DC rows + at least one more coefficient; not for the plain backward
+    radii = torch.zeros(8, dtype=torch.int32, device=dev)
+    gs_ = GsGaussians.from_buffer_copy(g)
+    gs_.shs_rest = t["sh"].data_ptr()
+    gs_.M = 1
+    assert api.raw("forward_geometry")(C.byref(v), C.byref(gs_), C.byref(s), radii.data_ptr(), None, None) == E_SHAPE
+    gs_.M = 16
+    grads = GsGrads()
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+    assert api.raw("backward")(C.byref(v), C.byref(gs_), radii.data_ptr(), C.byref(s), 0, img.data_ptr(), None, C.byref(grads),
+                               ws.data_ptr(), wsb, None) == E_UNSUPPORTED
     torch.cuda.synchronize()
