@@ -14,6 +14,14 @@ for p in (PKG, os.path.join(ROOT, "tests"), ROOT):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: larger CPU cases")
+    # torch's CPU pool like the oracle's (oracle_lib.host_cpu_share): the CPUs this process is GRANTED, not the ones it sees
+    try:
+        import torch
+        import oracle_lib
+        if "OMP_NUM_THREADS" not in os.environ:
+            torch.set_num_threads(oracle_lib.host_cpu_share())
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -24,6 +24,24 @@ def build():
     subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
 
+def host_cpu_share():
+    """CPUs this process may really use: min(affinity mask, cgroup quota).  A GPU box shows the checker every hardware thread
+    of the host (128 were seen) and gives the container a quota of 16: OpenMP's default - one thread per visible CPU - then
+    runs eight threads per granted core, and every oracle call of the suite crawls."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("GS_CPU_THREADS", n))))
+
+
 class Oracle:
     def __init__(self):
         import diff_gaussian_rasterization as dgr
@@ -68,8 +86,10 @@ class Oracle:
 
         self.FsgsRasterizer = OracleRasterizerFsgs
         self.FsgsSettings = dgr_fsgs.GaussianRasterizationSettings
-        for name in ("gso_test_sh_fwd", "gso_test_sh_bwd", "gso_knn_mean_dist2_ex", "gso_set_exact_chain"):
+        for name in ("gso_test_sh_fwd", "gso_test_sh_bwd", "gso_knn_mean_dist2_ex", "gso_set_exact_chain", "gso_set_num_threads"):
             getattr(lib, name).restype = C.c_int
+        if "OMP_NUM_THREADS" not in os.environ:   # (the gloo workers set it themselves)
+            self.threads = int(lib.gso_set_num_threads(host_cpu_share()))
 
     def exact_chain(self, on=True):
         """Context manager: while active the oracle's backward evaluates the reference's conic -> cov2D -> cov3D ->
