@@ -296,3 +296,51 @@ def test_sparse_exchange_steps_the_rows_outside_the_union_under_the_collective()
     unseen = got["union_mask"] == 0
     assert int(unseen.sum()) >= 400 // 3
     assert bool((got["xyz_now"][unseen] != got["xyz_start"][unseen]).any(dim=1).all())
+
+
+def _worker_eight(rank, world, port, outdir, form):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    from test_trainer_cpu import make_trainer
+    tr = make_trainer(oracle_lib.get(), P=203, W=64, H=48, world_size=world, rank=rank, dwt=False)   # 203: no multiple of 8
+    tr.sharded_optimizer, tr.sparse_exchange = form == "sharded", form == "sparse"
+    with torch.no_grad():
+        tr.model.params["xyz"][::4, 2] += 100.0          # a quarter of the rows outside every view
+    for k in range(2):
+        tr.step(k)
+    tr.gather_optimizer_state()
+    m = tr.model
+    torch.save(dict(flat=m.flat.clone(), m1=m.optimizer.exp_avg.clone(), m2=m.optimizer.exp_avg_sq.clone(),
+                    accum=m.xyz_gradient_accum.clone(), denom=m.denom.clone(), maxr=m.max_radii2D.clone(),
+                    cams=[tr.camera_index(k) for k in range(2)]), os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_every_exchange_form():
+    """The driver's scaling run goes to N = 8: eight gloo ranks (one thread each), a row count that is no multiple of eight, a
+    quarter of the rows seen by nobody.  Replicas bit-identical in every form; sharded and sparse against the all-reduce form:
+    the same parameters, moments and statistics to rounding (eight addends: the library chooses the order in each form)."""
+    world = 8
+    runs = {}
+    for form in ("allreduce", "sharded", "sparse"):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker_eight, args=(world, _free_port(), d, form), nprocs=world, join=True)
+            runs[form] = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(world)]
+        r0 = runs[form][0]
+        for r in range(1, world):
+            for k in ("flat", "m1", "m2", "accum", "denom", "maxr"):
+                assert torch.equal(r0[k], runs[form][r][k]), (form, r, k)
+        assert sorted(c for rr in runs[form] for c in rr["cams"][:1]) == sorted(k % 4 for k in range(8))   # k * 8 + r over 4 cameras
+    ref = runs["allreduce"][0]
+    for form in ("sharded", "sparse"):
+        got = runs[form][0]
+        assert torch.equal(got["denom"], ref["denom"]) and torch.equal(got["maxr"], ref["maxr"])
+        for k in ("flat", "m1", "m2", "accum"):
+            d = (got[k] - ref[k]).double()
+            assert float(d.abs().max()) <= 1e-5 * max(float(ref[k].abs().max()), 1e-30), (form, k)
