@@ -24,7 +24,10 @@ def _worker(rank, backend, port, outdir, form):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
-    dist.init_process_group(backend, rank=0, world_size=1)
+    if backend == "nccl":   # exactly bench.py's call (eager communicator on the rank's device)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=0, world_size=1)
     tr, hip = _make(0, 2, fused=True)        # told: rank 0 of 2 (cameras 0, 2, 0, 2 ...); the group has one member
     tr.sharded_optimizer, tr.sparse_exchange = False, form == "sparse"
     hip.tile_cull = True
