@@ -1058,8 +1058,8 @@ class Trainer:
     # is overwritten in place.  Anything that reads the model between steps goes through sync() first.
     depth_limit = None
     # the fused step hands the rasterizer the raw scaling / rotation / opacity rows (GsGaussians.raw_activations): the
-    # activation kernel and its three output tensors disappear from the step; GS_RAW_ACTIVATIONS=0 keeps them
-    RAW_ACTIVATIONS = __import__("os").environ.get("GS_RAW_ACTIVATIONS", "1") != "0"
+    # activation kernel and its three output tensors disappear from the step; False keeps them
+    RAW_ACTIVATIONS = True
 
     def sync(self):
         """Settle the verdict of the last depth-limited step (redoing the step if its limits failed), and that of the last
@@ -1237,7 +1237,7 @@ class Trainer:
             backend.raw_activations = self.RAW_ACTIVATIONS
             backend.fused_step = m.optimizer.grads_out_request()
             if not self.RAW_ACTIVATIONS:
-                raise RuntimeError("the data-parallel fused backward takes the raw parameter rows (GS_RAW_ACTIVATIONS=1)")
+                raise RuntimeError("the data-parallel fused backward takes the raw parameter rows (Trainer.RAW_ACTIVATIONS)")
         elif fused_step:
             backend.raw_activations = self.RAW_ACTIVATIONS
             backend.fused_step = m.optimizer.fused_request(skip, coef_dev=getattr(self, "_coef_dev", None))
