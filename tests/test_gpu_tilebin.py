@@ -55,6 +55,7 @@ SHAPES = [
     ("trained", 700, 48, 40, 1),        # one region row; fewer Gaussians than the one-workgroup sort holds
     ("trained", 20000, 2100, 80, 1),    # 132 x 5 tiles: more than 256 regions would need two partition passes... (33 x 2 here)
     ("trained", 20000, 4100, 1100, 1),  # 257 x 69 tiles = 65 x 18 = 1170 regions: two partition passes
+    ("huge", 200, 3840, 2160, 0),       # splats that cover a 4K image: up to 2 040 entries per Gaussian, 256 of them per workgroup
 ]
 
 
@@ -75,7 +76,7 @@ def test_reference_lists_are_the_oracles_bit_for_bit(hip, oracle, kind, P, W, H,
         assert torch.equal(h[k], h2[k]), ("row-wise entries", k)
 
 
-@pytest.mark.parametrize("kind,P,W,H,deg", SHAPES[:6])
+@pytest.mark.parametrize("kind,P,W,H,deg", SHAPES[:6] + SHAPES[-1:])
 def test_culled_lists_do_not_depend_on_the_entry_enumeration(hip, kind, P, W, H, deg):
     sc = scene(kind, P, deg)
     cam = synthetic.orbit_cameras(W, H)[4]
